@@ -1,0 +1,343 @@
+/*
+ * nori_hip.h -- C ABI of the MI355X (gfx950) hot path of the Nori renderer.
+ *
+ * This is the drop-in boundary: the host keeps Nori's
+ * NoriObject/XML object graph, flattens it into the POD `nori_scene_desc`
+ * below, and drives everything that Nori does per sample -- Accel build and
+ * rayIntersect, Mesh::rayIntersect, Integrator::Li, BSDF::sample/eval/pdf,
+ * Warp::*, Independent/pcg32, PerspectiveCamera::sampleRay, ImageBlock::put --
+ * through the entry points declared here.  Plain pointers and sizes only; no
+ * C++ types, no torch types.  Every function returns 0 on success or a
+ * negative `nori_status`; nothing throws across the boundary.  A context is
+ * bound to one GPU and is not thread safe (one host thread per GPU).
+ *
+ * Each entry point cites the reference interface it replaces
+ * (paths relative to the wjakob/nori tree).
+ *
+ * The same POD structs are consumed by the CPU oracle (oracle/oracle.h), which
+ * is test infrastructure only and is never linked into this library.
+ */
+#ifndef NORI_HIP_H
+#define NORI_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ enums */
+
+typedef enum nori_status {
+    NORI_OK = 0,
+    NORI_ERR_INVALID_ARGUMENT = -1,
+    NORI_ERR_NO_DEVICE = -2,       /* no HIP device / HIP runtime error      */
+    NORI_ERR_OUT_OF_MEMORY = -3,
+    NORI_ERR_NOT_READY = -4,       /* e.g. render before build_accel         */
+    NORI_ERR_UNSUPPORTED = -5,
+    NORI_ERR_INTERNAL = -6
+} nori_status;
+
+/* BSDF plugin names: src/diffuse.cpp:90, src/mirror.cpp:50,
+ * src/dielectric.cpp:49, src/microfacet.cpp:90 (NORI_REGISTER_CLASS) */
+typedef enum nori_bsdf_type {
+    NORI_BSDF_DIFFUSE = 0,
+    NORI_BSDF_MIRROR = 1,
+    NORI_BSDF_DIELECTRIC = 2,
+    NORI_BSDF_MICROFACET = 3
+} nori_bsdf_type;
+
+/* Integrator plugin names used by scenes/pa1..pa5 (no implementation ships
+ * in the reference; behaviour spec: DESIGN.md §Integrators) */
+typedef enum nori_integrator_type {
+    NORI_INTEGRATOR_NORMALS = 0,
+    NORI_INTEGRATOR_AO = 1,
+    NORI_INTEGRATOR_SIMPLE = 2,
+    NORI_INTEGRATOR_WHITTED = 3,
+    NORI_INTEGRATOR_PATH_MATS = 4,
+    NORI_INTEGRATOR_PATH_EMS = 5,
+    NORI_INTEGRATOR_PATH_MIS = 6
+} nori_integrator_type;
+
+/* src/rfilter.cpp:110-113 */
+typedef enum nori_rfilter_type {
+    NORI_RFILTER_GAUSSIAN = 0,
+    NORI_RFILTER_MITCHELL = 1,
+    NORI_RFILTER_TENT = 2,
+    NORI_RFILTER_BOX = 3
+} nori_rfilter_type;
+
+/* include/nori/common.h:179-183 (EMeasure) */
+typedef enum nori_measure {
+    NORI_MEASURE_UNKNOWN = 0,
+    NORI_MEASURE_SOLID_ANGLE = 1,
+    NORI_MEASURE_DISCRETE = 2
+} nori_measure;
+
+/* include/nori/warp.h:18-57; numbering follows src/warptest.cpp:79-82 */
+typedef enum nori_warp_type {
+    NORI_WARP_SQUARE = 0,
+    NORI_WARP_TENT = 1,
+    NORI_WARP_DISK = 2,
+    NORI_WARP_UNIFORM_SPHERE = 3,
+    NORI_WARP_UNIFORM_HEMISPHERE = 4,
+    NORI_WARP_COSINE_HEMISPHERE = 5,
+    NORI_WARP_BECKMANN = 6
+} nori_warp_type;
+
+/* How the pcg32 stream of a camera sample is seeded.
+ *  PER_SAMPLE : seed(initstate = y*width + x, initseq = sample index) before
+ *               every camera sample -- order independent, what a GPU can
+ *               reproduce; the mode in which device and oracle images are
+ *               compared sample for sample.
+ *  NORI_BLOCK : the reference's scheme, src/independent.cpp:36-41 -- one
+ *               stream per 32x32 block seeded with (offset.x, offset.y) and
+ *               consumed serially over y, x, sample.  Oracle only. */
+typedef enum nori_seed_mode {
+    NORI_SEED_PER_SAMPLE = 0,
+    NORI_SEED_NORI_BLOCK = 1
+} nori_seed_mode;
+
+typedef enum nori_accel_builder {
+    NORI_ACCEL_HOST_SAH = 0,   /* binned SAH on the host, uploaded            */
+    NORI_ACCEL_GPU_LBVH = 1    /* Morton/LBVH built on the device             */
+} nori_accel_builder;
+
+/* ------------------------------------------------------ scene description */
+
+/* BSDF parameters; defaults as in the reference constructors
+ * (src/diffuse.cpp:18-20, src/dielectric.cpp:17-23, src/microfacet.cpp:17-36).
+ * `albedo` holds Diffuse::m_albedo or Microfacet::m_kd. */
+typedef struct nori_bsdf_desc {
+    int32_t type;       /* nori_bsdf_type */
+    float albedo[3];
+    float alpha;
+    float int_ior;
+    float ext_ior;
+    float ks;           /* 1 - max(kd), src/microfacet.cpp:35 */
+} nori_bsdf_desc;
+
+/* One <mesh>: the buffers of include/nori/mesh.h:160-163 (m_V, m_N, m_UV, m_F;
+ * column-major 3xN == xyz interleaved per vertex), already in world space
+ * (src/obj.cpp:52,62 applies toWorld at load), plus its BSDF and optional
+ * area emitter (mesh.h:128-134). */
+typedef struct nori_mesh_desc {
+    uint32_t n_vertices;
+    uint32_t n_triangles;
+    const float *positions;    /* 3 * n_vertices                           */
+    const float *normals;      /* 3 * n_vertices or NULL                   */
+    const float *texcoords;    /* 2 * n_vertices or NULL                   */
+    const uint32_t *indices;   /* 3 * n_triangles                          */
+    nori_bsdf_desc bsdf;
+    int32_t is_emitter;        /* <emitter type="area">                    */
+    float radiance[3];
+} nori_mesh_desc;
+
+/* src/perspective.cpp:22-39; to_world is row-major 4x4 (camera -> world). */
+typedef struct nori_camera_desc {
+    int32_t width, height;
+    float fov;                 /* horizontal, degrees */
+    float near_clip, far_clip;
+    float to_world[16];
+} nori_camera_desc;
+
+/* src/rfilter.cpp constructors. radius is ignored for tent (1) and box (.5) */
+typedef struct nori_rfilter_desc {
+    int32_t type;              /* nori_rfilter_type */
+    float radius;
+    float stddev;              /* gaussian */
+    float B, C;                /* mitchell */
+} nori_rfilter_desc;
+
+typedef struct nori_integrator_desc {
+    int32_t type;              /* nori_integrator_type */
+    float position[3];         /* simple: point light position             */
+    float energy[3];           /* simple: point light power                */
+} nori_integrator_desc;
+
+typedef struct nori_scene_desc {
+    uint32_t n_meshes;
+    const nori_mesh_desc *meshes;
+    nori_camera_desc camera;
+    nori_rfilter_desc rfilter;
+    nori_integrator_desc integrator;
+    int32_t sample_count;      /* Independent::m_sampleCount               */
+} nori_scene_desc;
+
+/* ------------------------------------------------------- per-query records */
+
+/* include/nori/ray.h:30-34 without dRcp (recomputed on the device). 32 B. */
+typedef struct nori_ray {
+    float o[3];
+    float d[3];
+    float mint, maxt;
+} nori_ray;
+
+/* include/nori/mesh.h:23-35.  mesh = index into nori_scene_desc::meshes,
+ * 0xFFFFFFFF when nothing was hit (Intersection::mesh == nullptr).
+ * `tri` is the triangle index inside that mesh (the `f` of accel.cpp:25). */
+typedef struct nori_intersection {
+    float p[3];
+    float t;
+    float uv[2];
+    float sh_s[3], sh_t[3], sh_n[3];
+    float geo_s[3], geo_t[3], geo_n[3];
+    uint32_t mesh;
+    uint32_t tri;
+} nori_intersection;
+
+#define NORI_NO_HIT 0xFFFFFFFFu
+
+/* What to render: the frame is cut into fixed tiles (NORI_TILE_SIZE^2 px,
+ * the device analogue of NORI_BLOCK_SIZE, include/nori/block.h:17).  A call
+ * renders the tiles whose raster index i satisfies i % tile_mod == tile_rem,
+ * with camera samples [spp_begin, spp_begin+spp_count) per pixel, and ADDS the
+ * weighted samples into the caller's RGBW accumulation buffer, laid out like
+ * the full-frame ImageBlock of src/main.cpp:67: (height+2b) rows x
+ * (width+2b) columns x 4 floats, b = nori_hip_border_size().  Summing the
+ * buffers of several calls / ranks is exactly ImageBlock::put(ImageBlock&)
+ * (src/block.cpp:93-102). */
+typedef struct nori_render_params {
+    uint32_t spp_begin;
+    uint32_t spp_count;
+    uint32_t tile_mod;      /* >= 1 */
+    uint32_t tile_rem;      /* <  tile_mod */
+    int32_t seed_mode;      /* nori_seed_mode; the device supports PER_SAMPLE */
+    int32_t count_traversal;/* != 0: also count node/triangle tests (slower) */
+    void *stream;           /* hipStream_t or NULL for the default stream   */
+} nori_render_params;
+
+#define NORI_TILE_SIZE 16
+
+/* Work counters of one render call.  Ray queries are counted where the
+ * reference would pass through Scene::rayIntersect (include/nori/scene.h:63
+ * closest hit, :82 shadow). */
+typedef struct nori_render_stats {
+    uint64_t n_camera_samples;
+    uint64_t n_closest_rays;
+    uint64_t n_shadow_rays;
+    uint64_t n_node_tests;   /* only when count_traversal != 0 */
+    uint64_t n_tri_tests;    /* only when count_traversal != 0 */
+    uint64_t n_invalid;      /* samples dropped by the isValid() guard,
+                                src/block.cpp:63-67 */
+    float kernel_ms;         /* HIP-event time of the render kernel on the
+                                stream it was launched on */
+} nori_render_stats;
+
+typedef struct nori_accel_info {
+    uint32_t n_triangles;
+    uint32_t n_nodes;
+    uint32_t n_leaves;
+    uint32_t max_depth;
+    uint32_t node_bytes;     /* size of one node record as laid out */
+    uint32_t tri_bytes;      /* size of one leaf triangle record     */
+    uint64_t total_bytes;    /* nodes + leaf triangles in HBM        */
+    float build_ms;
+    float sah_cost;
+} nori_accel_info;
+
+typedef struct nori_hip_ctx nori_hip_ctx;
+
+/* ------------------------------------------------------------ life cycle */
+
+/* Bind a context to HIP device `device`. */
+int nori_hip_create(int device, nori_hip_ctx **out);
+void nori_hip_destroy(nori_hip_ctx *ctx);
+/* Message of the last failing call on this context (or on creation when
+ * ctx == NULL).  Stands in for NoriException::what(), common.h:135-140. */
+const char *nori_hip_last_error(const nori_hip_ctx *ctx);
+
+/* Copy the scene into HBM (SoA vertex/index buffers, material and emitter
+ * tables, camera, filter table).  Replaces the load-time half of
+ * Scene::addChild / Accel::addMesh (src/scene.cpp:48-52, src/accel.cpp:12-17),
+ * the ImageBlock filter tabulation (src/block.cpp:18-27) and
+ * PerspectiveCamera::activate (src/perspective.cpp:41-74). */
+int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene);
+
+/* Accel::build (src/accel.cpp:19-21 -- a no-op in the reference, a BVH here) */
+int nori_hip_build_accel(nori_hip_ctx *ctx, int builder /* nori_accel_builder */);
+int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out);
+
+/* ImageBlock::m_borderSize for the uploaded filter (src/block.cpp:20). */
+int nori_hip_border_size(const nori_hip_ctx *ctx);
+
+/* --------------------------------------------------- operator-level twins */
+
+/* Accel::rayIntersect(ray, its, shadowRay) (src/accel.cpp:23-99) for a batch
+ * of n rays held in HOST memory.  shadow_ray != 0: only `mesh` is meaningful
+ * (0 = some occluder, NORI_NO_HIT = none), as the reference returns early. */
+int nori_hip_intersect(nori_hip_ctx *ctx, const nori_ray *rays,
+                       nori_intersection *its, size_t n, int shadow_ray);
+
+/* Same on DEVICE buffers (rays: n x nori_ray, its: n x nori_intersection),
+ * asynchronous on `stream`. */
+int nori_hip_intersect_device(nori_hip_ctx *ctx, const void *d_rays,
+                              void *d_its, size_t n, int shadow_ray,
+                              void *stream);
+
+/* PerspectiveCamera::sampleRay (src/perspective.cpp:76-97) for n film
+ * positions (pixel_samples: 2n floats, fractional pixel coordinates). */
+int nori_hip_sample_rays(nori_hip_ctx *ctx, const float *pixel_samples,
+                         size_t n, nori_ray *rays);
+
+/* Integrator::Li (include/nori/integrator.h:42) for n rays; path k draws its
+ * random numbers from pcg32.seed(seed_state[k], seed_seq[k]).  rgb: 3n. */
+int nori_hip_li(nori_hip_ctx *ctx, const nori_ray *rays, size_t n,
+                const uint64_t *seed_state, const uint64_t *seed_seq,
+                float *rgb);
+
+/* BSDF::sample / eval / pdf (include/nori/bsdf.h:59,70,87) in the local
+ * frame.  wi, wo: 3n floats; sample: 2n; weight, value: 3n; eta, pdf: n. */
+int nori_hip_bsdf_sample(nori_hip_ctx *ctx, const nori_bsdf_desc *bsdf,
+                         const float *wi, const float *sample, size_t n,
+                         float *wo, float *weight, float *eta,
+                         int32_t *measure);
+int nori_hip_bsdf_eval(nori_hip_ctx *ctx, const nori_bsdf_desc *bsdf,
+                       const float *wi, const float *wo, size_t n,
+                       float *value);
+int nori_hip_bsdf_pdf(nori_hip_ctx *ctx, const nori_bsdf_desc *bsdf,
+                      const float *wi, const float *wo, size_t n, float *pdf);
+
+/* Warp::squareToX / squareToXPdf (include/nori/warp.h:18-57).  sample: 2n.
+ * out: 3n (2D warps leave z = 0).  pdf takes points in the same 3n layout. */
+int nori_hip_warp(nori_hip_ctx *ctx, int warp /* nori_warp_type */,
+                  float param, const float *sample, size_t n, float *out);
+int nori_hip_warp_pdf(nori_hip_ctx *ctx, int warp, float param,
+                      const float *points, size_t n, float *pdf);
+
+/* pcg32::nextFloat stream (Independent::next1D, src/independent.cpp:46-48):
+ * out[k*count + j] = j-th float of pcg32.seed(seed_state[k], seed_seq[k]). */
+int nori_hip_pcg32_floats(nori_hip_ctx *ctx, const uint64_t *seed_state,
+                          const uint64_t *seed_seq, size_t n, uint32_t count,
+                          float *out);
+
+/* ImageBlock::put(pos, value) (src/block.cpp:62-91) of n samples into the
+ * full-frame RGBW buffer `rgbw` (HOST memory, layout as in
+ * nori_render_params; accumulated into). positions: 2n, values: 3n. */
+int nori_hip_splat(nori_hip_ctx *ctx, const float *positions,
+                   const float *values, size_t n, float *rgbw);
+
+/* ----------------------------------------------------------- the hot path */
+
+/* renderBlock + render (src/main.cpp:27-119) for the tiles / samples named in
+ * `params`, accumulating into the DEVICE buffer d_rgbw (see
+ * nori_render_params).  Asynchronous on params->stream unless `stats` is
+ * non-NULL, in which case the call synchronises the stream and fills it. */
+int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params,
+                    void *d_rgbw, nori_render_stats *stats);
+
+/* Convenience: zero a host RGBW buffer, render into a scratch device buffer
+ * and copy back (synchronous). */
+int nori_hip_render_host(nori_hip_ctx *ctx, const nori_render_params *params,
+                         float *rgbw, nori_render_stats *stats);
+
+/* ImageBlock::toBitmap (src/block.cpp:45-51): rgb = rgbw.rgb / w (0 if w==0)
+ * without the border, on the device.  d_rgb: height*width*3 floats. */
+int nori_hip_develop(nori_hip_ctx *ctx, const void *d_rgbw, void *d_rgb,
+                     void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NORI_HIP_H */

@@ -1,0 +1,766 @@
+/*
+ * nori_hip.hip -- gfx950 kernels and the C ABI of include/nori_hip.h.
+ *
+ * Kernel shapes (wave64, 256-thread workgroups = 4 waves):
+ *
+ *  render_kernel   one workgroup per (16x16 pixel tile, spp chunk); thread <->
+ *                  pixel, each wave an 8x8 quad of the tile.  Every lane runs
+ *                  the path state machine of rt_path.h persistently: one ray
+ *                  query per loop trip, a finished path is splatted and the lane
+ *                  regenerates the next camera sample of its pixel in place.
+ *                  LDS holds (a) the per-lane traversal stacks, [depth][thread]
+ *                  so that bank = lane (conflict free), (b) the RGBW
+ *                  accumulation tile incl. filter border -- ImageBlock::put
+ *                  (src/block.cpp:62-91) becomes ds_add_f32 into this tile --
+ *                  and (c) the 33-entry filter table.  The tile is merged into
+ *                  the frame buffer once per workgroup with global float
+ *                  atomics: ImageBlock::put(ImageBlock&) (src/block.cpp:93-102).
+ *  intersect_kernel / li_kernel / bsdf_* / warp_* / camera / pcg32 / splat
+ *                  batch twins of the reference's virtual calls for parity tests
+ *                  and for the host-side plugin classes.
+ *
+ * No MFMA anywhere: there is no dense contraction on this path.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/nori_hip.h"
+#include "rt_film.h"
+#include "rt_path.h"
+#include "scene_prep.h"
+
+using namespace nrt;
+
+/* ------------------------------------------------------------ LDS stack */
+template <int DEPTH, int STRIDE>
+struct LdsStack {
+    int *base;      /* &lds[threadIdx.x] */
+    int sp;
+    __device__ __forceinline__ void reset() { sp = 0; }
+    __device__ __forceinline__ bool empty() const { return sp == 0; }
+    __device__ __forceinline__ void push(int v) {
+        if (sp < DEPTH) base[sp * STRIDE] = v;
+        sp++;
+    }
+    __device__ __forceinline__ int pop() {
+        sp--;
+        return sp < DEPTH ? base[sp * STRIDE] : 0;
+    }
+};
+
+constexpr int kBlock = 256;
+
+/* ----------------------------------------------------------- render kernel */
+struct RenderArgs {
+    uint32_t spp_begin, spp_count;
+    uint32_t tile_mod, tile_rem;
+    uint32_t tiles_x, tiles_y;
+    uint32_t n_sel_tiles;       /* tiles handled by this launch            */
+    uint32_t n_chunks;          /* spp chunks per tile                     */
+    uint32_t chunk_spp;
+    int32_t tile_w;             /* kTile + 2 * border                      */
+};
+
+struct LdsAdd {
+    __device__ __forceinline__ void operator()(float *p, float v) const { atomicAdd(p, v); }
+};
+
+template <int INTEG, int STACK, bool COUNT>
+__global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, RenderArgs args, const float *__restrict__ filter_table,
+                                                        float *rgbw, unsigned long long *stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *lds_stack = reinterpret_cast<int *>(smem);
+    float *tile = reinterpret_cast<float *>(smem + sizeof(int) * STACK * kBlock);
+    const int tile_w = args.tile_w;
+    const int tile_floats = tile_w * tile_w * 4;
+    float *ftab = tile + tile_floats;
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(ftab + 48);
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < tile_floats; i += kBlock) tile[i] = 0.0f;
+    if (tid <= kFilterRes) ftab[tid] = filter_table[tid];
+    if (tid < 8) cnt[tid] = 0u;
+    __syncthreads();
+
+    /* which tile / which samples */
+    const uint32_t sel = blockIdx.x / args.n_chunks, chunk = blockIdx.x % args.n_chunks;
+    const uint32_t tile_id = args.tile_rem + sel * args.tile_mod;
+    const int x0 = (int) (tile_id % args.tiles_x) * kTile, y0 = (int) (tile_id / args.tiles_x) * kTile;
+    const uint32_t s0 = args.spp_begin + chunk * args.chunk_spp;
+    const uint32_t s1 = min(s0 + args.chunk_spp, args.spp_begin + args.spp_count);
+
+    /* wave w covers the 8x8 quad (w&1, w>>1) of the tile; lane l the pixel (l&7, l>>3) */
+    const int wave = tid >> 6, lane = tid & 63;
+    const int px = x0 + ((wave & 1) << 3) + (lane & 7);
+    const int py = y0 + ((wave >> 1) << 3) + (lane >> 3);
+    const bool live = px < sc.camera.width && py < sc.camera.height;
+
+    LdsStack<STACK, kBlock> stack;
+    stack.base = lds_stack + tid; stack.sp = 0;
+
+    PathState st;
+    st.phase = PH_NEW;
+    f2 pixelSample = mk2(0.0f, 0.0f);
+    uint32_t s = s0;
+    uint32_t nCam = 0, nClosest = 0, nShadow = 0, nInvalid = 0;
+    TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
+    const float radius = sc.filter.radius, lookup = sc.filter.lookup_factor;
+    const int border = sc.filter.border;
+
+    if (live) {
+        while (true) {
+            if (st.phase == PH_NEW) {
+                if (s >= s1) break;
+                /* renderBlock, src/main.cpp:41-46: jitter, aperture draw, sampleRay */
+                rng_seed(st.rng, (uint64_t) py * (uint64_t) sc.camera.width + (uint64_t) px, (uint64_t) s);
+                const f2 j = rng_next_2d(st.rng);
+                pixelSample = mk2((float) px + j.x, (float) py + j.y);
+                (void) rng_next_2d(st.rng);            /* apertureSample: drawn, unused (perspective.cpp:78) */
+                RayIn cam;
+                camera_sample_ray(sc.camera, pixelSample, cam);
+                path_begin(st, cam);
+                ++s; ++nCam;
+            }
+            const bool any = st.phase == PH_SHADOW;
+            Hit hit;
+            const bool found = traverse<COUNT>(sc, st.ray, any, stack, hit, tc);
+            bool done;
+            if (any) { ++nShadow; done = path_on_shadow(st, found); }
+            else { ++nClosest; done = path_on_closest<INTEG>(sc, st, hit, found); }
+            if (done) {
+                if (color_valid(st.L)) splat_tile(tile, tile_w, x0, y0, ftab, radius, lookup, border, pixelSample, st.L, LdsAdd());
+                else ++nInvalid;
+                st.phase = PH_NEW;
+            }
+        }
+    }
+
+    atomicAdd(&cnt[0], nCam); atomicAdd(&cnt[1], nClosest); atomicAdd(&cnt[2], nShadow);
+    atomicAdd(&cnt[5], nInvalid);
+    if (COUNT) { atomicAdd(&cnt[3], tc.nodes); atomicAdd(&cnt[4], tc.tris); }
+    __syncthreads();
+
+    /* ImageBlock::put(ImageBlock&): merge tile + border into the frame */
+    const int cols = sc.camera.width + 2 * border, rows = sc.camera.height + 2 * border;
+    for (int i = tid; i < tile_w * tile_w; i += kBlock) {
+        const int ty = i / tile_w, tx = i - ty * tile_w;
+        const int gx = x0 + tx, gy = y0 + ty;           /* frame coords incl. border */
+        if (gx >= cols || gy >= rows) continue;
+        const float *p = tile + (i << 2);
+        if (p[3] == 0.0f && p[0] == 0.0f && p[1] == 0.0f && p[2] == 0.0f) continue;
+        float *dst = rgbw + (((size_t) gy * cols + gx) << 2);
+        unsafeAtomicAdd(dst + 0, p[0]); unsafeAtomicAdd(dst + 1, p[1]);
+        unsafeAtomicAdd(dst + 2, p[2]); unsafeAtomicAdd(dst + 3, p[3]);
+    }
+    if (tid < 6 && cnt[tid] != 0u) atomicAdd(&stats[tid], (unsigned long long) cnt[tid]);
+}
+
+/* ------------------------------------------------------- batch operators */
+template <int STACK>
+__global__ __launch_bounds__(kBlock) void intersect_kernel(DevScene sc, const nori_ray *rays, nori_intersection *out,
+                                                           size_t n, int shadow) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LdsStack<STACK, kBlock> stack;
+    stack.base = reinterpret_cast<int *>(smem) + threadIdx.x; stack.sp = 0;
+    TraversalCounters tc; tc.nodes = tc.tris = 0;
+    for (size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t) gridDim.x * kBlock) {
+        const nori_ray r = rays[i];
+        RayIn ray; ray.o = mk3(r.o[0], r.o[1], r.o[2]); ray.d = mk3(r.d[0], r.d[1], r.d[2]);
+        ray.mint = r.mint; ray.maxt = r.maxt;
+        Hit hit;
+        const bool found = traverse<false>(sc, ray, shadow != 0, stack, hit, tc);
+        nori_intersection o;
+        memset(&o, 0, sizeof(o));
+        o.mesh = NORI_NO_HIT; o.tri = NORI_NO_HIT;
+        if (found && shadow) {
+            o.mesh = 0;
+        } else if (found) {
+            Surface sf; f3 ng; f2 uv;
+            surface_fill(sc, hit, sf, &ng, &uv);
+            const Frame sh = make_frame(sf.ns), geo = make_frame(ng);
+            o.p[0] = sf.p.x; o.p[1] = sf.p.y; o.p[2] = sf.p.z; o.t = hit.t; o.uv[0] = uv.x; o.uv[1] = uv.y;
+            o.sh_s[0] = sh.s.x; o.sh_s[1] = sh.s.y; o.sh_s[2] = sh.s.z;
+            o.sh_t[0] = sh.t.x; o.sh_t[1] = sh.t.y; o.sh_t[2] = sh.t.z;
+            o.sh_n[0] = sh.n.x; o.sh_n[1] = sh.n.y; o.sh_n[2] = sh.n.z;
+            o.geo_s[0] = geo.s.x; o.geo_s[1] = geo.s.y; o.geo_s[2] = geo.s.z;
+            o.geo_t[0] = geo.t.x; o.geo_t[1] = geo.t.y; o.geo_t[2] = geo.t.z;
+            o.geo_n[0] = geo.n.x; o.geo_n[1] = geo.n.y; o.geo_n[2] = geo.n.z;
+            o.mesh = hit.mesh; o.tri = hit.tri - sc.meshes[hit.mesh].tri_offset;
+        }
+        out[i] = o;
+    }
+}
+
+template <int INTEG, int STACK>
+__global__ __launch_bounds__(kBlock) void li_kernel(DevScene sc, const nori_ray *rays, size_t n,
+                                                    const uint64_t *seed_state, const uint64_t *seed_seq, float *rgb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LdsStack<STACK, kBlock> stack;
+    stack.base = reinterpret_cast<int *>(smem) + threadIdx.x; stack.sp = 0;
+    TraversalCounters tc; tc.nodes = tc.tris = 0;
+    for (size_t i = (size_t) blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t) gridDim.x * kBlock) {
+        const nori_ray r = rays[i];
+        RayIn ray; ray.o = mk3(r.o[0], r.o[1], r.o[2]); ray.d = mk3(r.d[0], r.d[1], r.d[2]);
+        ray.mint = r.mint; ray.maxt = r.maxt;
+        PathState st;
+        rng_seed(st.rng, seed_state[i], seed_seq[i]);
+        path_begin(st, ray);
+        while (true) {
+            const bool any = st.phase == PH_SHADOW;
+            Hit hit;
+            const bool found = traverse<false>(sc, st.ray, any, stack, hit, tc);
+            const bool done = any ? path_on_shadow(st, found) : path_on_closest<INTEG>(sc, st, hit, found);
+            if (done) break;
+        }
+        rgb[3 * i] = st.L.x; rgb[3 * i + 1] = st.L.y; rgb[3 * i + 2] = st.L.z;
+    }
+}
+
+__global__ void sample_rays_kernel(CameraRec cam, const float *ps, size_t n, nori_ray *rays) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    RayIn r;
+    camera_sample_ray(cam, mk2(ps[2 * i], ps[2 * i + 1]), r);
+    nori_ray o;
+    o.o[0] = r.o.x; o.o[1] = r.o.y; o.o[2] = r.o.z; o.d[0] = r.d.x; o.d[1] = r.d.y; o.d[2] = r.d.z;
+    o.mint = r.mint; o.maxt = r.maxt;
+    rays[i] = o;
+}
+
+__global__ void bsdf_kernel(Bsdf b, int op, const float *wi, const float *wo_in, const float *sample, size_t n,
+                            float *wo_out, float *value, float *eta, int32_t *measure) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 a = mk3(wi[3 * i], wi[3 * i + 1], wi[3 * i + 2]);
+    if (op == 0) {
+        f3 wo; float e; int m;
+        const f3 w = bsdf_sample(b, a, mk2(sample[2 * i], sample[2 * i + 1]), wo, e, m);
+        wo_out[3 * i] = wo.x; wo_out[3 * i + 1] = wo.y; wo_out[3 * i + 2] = wo.z;
+        value[3 * i] = w.x; value[3 * i + 1] = w.y; value[3 * i + 2] = w.z;
+        if (eta) eta[i] = e;
+        if (measure) measure[i] = m;
+    } else {
+        const f3 o = mk3(wo_in[3 * i], wo_in[3 * i + 1], wo_in[3 * i + 2]);
+        if (op == 1) { const f3 v = bsdf_eval(b, a, o); value[3 * i] = v.x; value[3 * i + 1] = v.y; value[3 * i + 2] = v.z; }
+        else value[i] = bsdf_pdf(b, a, o);
+    }
+}
+
+__global__ void warp_kernel(int warp, float param, int pdf, const float *in, size_t n, float *out) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!pdf) {
+        const f3 r = warp_dispatch(warp, param, mk2(in[2 * i], in[2 * i + 1]));
+        out[3 * i] = r.x; out[3 * i + 1] = r.y; out[3 * i + 2] = r.z;
+    } else {
+        out[i] = warp_pdf_dispatch(warp, param, mk3(in[3 * i], in[3 * i + 1], in[3 * i + 2]));
+    }
+}
+
+__global__ void pcg32_kernel(const uint64_t *state, const uint64_t *seq, size_t n, uint32_t count, float *out) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r; rng_seed(r, state[i], seq[i]);
+    for (uint32_t j = 0; j < count; ++j) out[i * count + j] = rng_next_float(r);
+}
+
+/* ImageBlock::put(pos, value) straight into the global frame (parity twin;
+ * the render kernel splats into LDS instead). */
+__global__ void splat_kernel(FilterRec fl, const float *ftab, int width, int height, const float *pos, const float *val,
+                             size_t n, float *rgbw) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const f3 value = mk3(val[3 * i], val[3 * i + 1], val[3 * i + 2]);
+    if (!color_valid(value)) return;
+    const int border = fl.border, cols = width + 2 * border, rows = height + 2 * border;
+    const float px = pos[2 * i] - 0.5f - (float) (0 - border), py = pos[2 * i + 1] - 0.5f - (float) (0 - border);
+    int minX = max((int) ceilf(px - fl.radius), 0), maxX = min((int) floorf(px + fl.radius), cols - 1);
+    int minY = max((int) ceilf(py - fl.radius), 0), maxY = min((int) floorf(py + fl.radius), rows - 1);
+    for (int y = minY; y <= maxY; ++y) {
+        const float wy = ftab[(int) (fabsf((float) y - py) * fl.lookup_factor)];
+        for (int x = minX; x <= maxX; ++x) {
+            const float wx = ftab[(int) (fabsf((float) x - px) * fl.lookup_factor)];
+            float *p = rgbw + (((size_t) y * cols + x) << 2);
+            unsafeAtomicAdd(p + 0, value.x * wx * wy); unsafeAtomicAdd(p + 1, value.y * wx * wy);
+            unsafeAtomicAdd(p + 2, value.z * wx * wy); unsafeAtomicAdd(p + 3, 1.0f * wx * wy);
+        }
+    }
+}
+
+/* ImageBlock::toBitmap, src/block.cpp:45-51 */
+__global__ void develop_kernel(const float4 *rgbw, float *rgb, int width, int height, int border) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= width) return;
+    const float4 p = rgbw[(size_t) (y + border) * (width + 2 * border) + (x + border)];
+    float *o = rgb + ((size_t) y * width + x) * 3;
+    if (p.w != 0.0f) { o[0] = p.x / p.w; o[1] = p.y / p.w; o[2] = p.z / p.w; }
+    else { o[0] = o[1] = o[2] = 0.0f; }
+}
+
+/* ---------------------------------------------------------------- context */
+struct nori_hip_ctx {
+    int device = 0;
+    std::string error;
+    bool have_scene = false, have_accel = false;
+    HostScene host;
+    HostBvh bvh;
+    DevScene dev;
+    std::vector<void *> allocs_scene, allocs_accel;
+    float *d_filter = nullptr;
+    unsigned long long *d_stats = nullptr;
+    nori_accel_info info;
+    int stack_depth = 32;
+};
+
+static std::string g_create_error;
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess) {                                                                   \
+            (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e__);                     \
+            return e__ == hipErrorOutOfMemory ? NORI_ERR_OUT_OF_MEMORY : NORI_ERR_NO_DEVICE;       \
+        }                                                                                          \
+    } while (0)
+
+template <class T>
+static int upload(nori_hip_ctx *ctx, std::vector<void *> &pool, const std::vector<T> &v, const T **out) {
+    void *d = nullptr;
+    const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIP_TRY(ctx, hipMalloc(&d, bytes));
+    pool.push_back(d);
+    if (!v.empty()) HIP_TRY(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<const T *>(d);
+    return NORI_OK;
+}
+
+static void free_pool(std::vector<void *> &pool) {
+    for (void *p : pool) (void) hipFree(p);
+    pool.clear();
+}
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; (void) hipSetDevice(dev); }
+    ~DeviceGuard() { if (prev >= 0) (void) hipSetDevice(prev); }
+};
+
+extern "C" {
+
+int nori_hip_create(int device, nori_hip_ctx **out) {
+    if (!out) return NORI_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        g_create_error = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return NORI_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= count) { g_create_error = "device index out of range"; return NORI_ERR_INVALID_ARGUMENT; }
+    nori_hip_ctx *ctx = new nori_hip_ctx();
+    ctx->device = device;
+    memset(&ctx->dev, 0, sizeof(ctx->dev));
+    memset(&ctx->info, 0, sizeof(ctx->info));
+    DeviceGuard g(device);
+    e = hipMalloc((void **) &ctx->d_stats, 8 * sizeof(unsigned long long));
+    if (e != hipSuccess) { g_create_error = std::string("hipMalloc: ") + hipGetErrorString(e); delete ctx; return NORI_ERR_NO_DEVICE; }
+    *out = ctx;
+    return NORI_OK;
+}
+
+void nori_hip_destroy(nori_hip_ctx *ctx) {
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    free_pool(ctx->allocs_scene); free_pool(ctx->allocs_accel);
+    if (ctx->d_stats) (void) hipFree(ctx->d_stats);
+    delete ctx;
+}
+
+const char *nori_hip_last_error(const nori_hip_ctx *ctx) {
+    return ctx ? ctx->error.c_str() : g_create_error.c_str();
+}
+
+int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
+    if (!ctx || !scene) return NORI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    free_pool(ctx->allocs_scene); free_pool(ctx->allocs_accel);
+    ctx->have_scene = ctx->have_accel = false;
+    std::string err = prepare_scene(*scene, ctx->host);
+    if (!err.empty()) { ctx->error = err; return NORI_ERR_INVALID_ARGUMENT; }
+    HostScene &h = ctx->host;
+    DevScene &d = ctx->dev;
+    memset(&d, 0, sizeof(d));
+    int rc;
+    if ((rc = upload(ctx, ctx->allocs_scene, h.positions, &d.positions))) return rc;
+    if ((rc = upload(ctx, ctx->allocs_scene, h.normals, &d.normals))) return rc;
+    if ((rc = upload(ctx, ctx->allocs_scene, h.texcoords, &d.texcoords))) return rc;
+    if ((rc = upload(ctx, ctx->allocs_scene, h.indices, &d.indices))) return rc;
+    if ((rc = upload(ctx, ctx->allocs_scene, h.meshes, &d.meshes))) return rc;
+    if ((rc = upload(ctx, ctx->allocs_scene, h.emitter_cdf, &d.emitter_cdf))) return rc;
+    if ((rc = upload(ctx, ctx->allocs_scene, h.emitters, &d.emitters))) return rc;
+    std::vector<float> ft(h.filter.table, h.filter.table + kFilterRes + 1);
+    const float *dft = nullptr;
+    if ((rc = upload(ctx, ctx->allocs_scene, ft, &dft))) return rc;
+    ctx->d_filter = const_cast<float *>(dft);
+    d.n_emitters = (uint32_t) h.emitters.size();
+    d.n_meshes = (uint32_t) h.meshes.size();
+    d.n_triangles = (uint32_t) h.tri_mesh.size();
+    d.camera = h.camera; d.filter = h.filter; d.integrator = h.integrator;
+    ctx->have_scene = true;
+    return NORI_OK;
+}
+
+int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
+    if (!ctx) return NORI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_scene) { ctx->error = "build_accel: no scene uploaded"; return NORI_ERR_NOT_READY; }
+    if (builder != NORI_ACCEL_HOST_SAH) { ctx->error = "build_accel: only NORI_ACCEL_HOST_SAH is implemented"; return NORI_ERR_UNSUPPORTED; }
+    DeviceGuard g(ctx->device);
+    free_pool(ctx->allocs_accel);
+    ctx->have_accel = false;
+    std::string err = build_bvh_sah(ctx->host, 64, ctx->bvh);
+    if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
+    int rc;
+    if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.nodes, &ctx->dev.nodes))) return rc;
+    if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.tris, &ctx->dev.tris))) return rc;
+    ctx->dev.root = ctx->bvh.root;
+    ctx->stack_depth = ctx->bvh.max_depth + 1 <= 32 ? 32 : 64;
+    nori_accel_info &in = ctx->info;
+    in.n_triangles = ctx->dev.n_triangles; in.n_nodes = ctx->bvh.n_nodes; in.n_leaves = ctx->bvh.n_leaves;
+    in.max_depth = ctx->bvh.max_depth; in.node_bytes = kNodeQuads * 16; in.tri_bytes = kTriQuads * 16;
+    in.total_bytes = (uint64_t) ctx->bvh.nodes.size() * 16 + (uint64_t) ctx->bvh.tris.size() * 16;
+    in.build_ms = ctx->bvh.build_ms; in.sah_cost = ctx->bvh.sah_cost;
+    ctx->have_accel = true;
+    return NORI_OK;
+}
+
+int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out) {
+    if (!ctx || !out) return NORI_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_accel) return NORI_ERR_NOT_READY;
+    *out = ctx->info;
+    return NORI_OK;
+}
+
+int nori_hip_border_size(const nori_hip_ctx *ctx) {
+    if (!ctx || !ctx->have_scene) return NORI_ERR_NOT_READY;
+    return ctx->host.filter.border;
+}
+
+#define REQUIRE_ACCEL(ctx)                                                                 \
+    do {                                                                                   \
+        if (!(ctx)) return NORI_ERR_INVALID_ARGUMENT;                                      \
+        if (!(ctx)->have_accel) { (ctx)->error = "no acceleration structure built"; return NORI_ERR_NOT_READY; } \
+    } while (0)
+
+static int grid_for(size_t n) { return (int) std::min<size_t>((n + kBlock - 1) / kBlock, 8192); }
+
+int nori_hip_intersect_device(nori_hip_ctx *ctx, const void *d_rays, void *d_its, size_t n, int shadow_ray, void *stream) {
+    REQUIRE_ACCEL(ctx);
+    if (n == 0) return NORI_OK;
+    DeviceGuard g(ctx->device);
+    hipStream_t s = (hipStream_t) stream;
+    if (ctx->stack_depth <= 32)
+        hipLaunchKernelGGL(intersect_kernel<32>, dim3(grid_for(n)), dim3(kBlock), 32 * kBlock * sizeof(int), s, ctx->dev,
+                           (const nori_ray *) d_rays, (nori_intersection *) d_its, n, shadow_ray);
+    else
+        hipLaunchKernelGGL(intersect_kernel<64>, dim3(grid_for(n)), dim3(kBlock), 64 * kBlock * sizeof(int), s, ctx->dev,
+                           (const nori_ray *) d_rays, (nori_intersection *) d_its, n, shadow_ray);
+    HIP_TRY(ctx, hipGetLastError());
+    return NORI_OK;
+}
+
+/* small RAII device buffer for the host-buffer convenience entry points */
+struct Scratch {
+    void *p = nullptr;
+    ~Scratch() { if (p) (void) hipFree(p); }
+};
+#define SCRATCH_IN(ctx, var, host, bytes)                                           \
+    Scratch var;                                                                    \
+    HIP_TRY(ctx, hipMalloc(&var.p, std::max<size_t>((bytes), 16)));                 \
+    if (host) HIP_TRY(ctx, hipMemcpy(var.p, host, (bytes), hipMemcpyHostToDevice))
+#define SCRATCH_OUT(ctx, var, bytes)                                                \
+    Scratch var;                                                                    \
+    HIP_TRY(ctx, hipMalloc(&var.p, std::max<size_t>((bytes), 16)))
+
+int nori_hip_intersect(nori_hip_ctx *ctx, const nori_ray *rays, nori_intersection *its, size_t n, int shadow_ray) {
+    REQUIRE_ACCEL(ctx);
+    if (n == 0) return NORI_OK;
+    if (!rays || !its) return NORI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    SCRATCH_IN(ctx, dr, rays, n * sizeof(nori_ray));
+    SCRATCH_OUT(ctx, di, n * sizeof(nori_intersection));
+    int rc = nori_hip_intersect_device(ctx, dr.p, di.p, n, shadow_ray, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(its, di.p, n * sizeof(nori_intersection), hipMemcpyDeviceToHost));
+    return NORI_OK;
+}
+
+int nori_hip_sample_rays(nori_hip_ctx *ctx, const float *pixel_samples, size_t n, nori_ray *rays) {
+    if (!ctx || !ctx->have_scene) return NORI_ERR_NOT_READY;
+    if (n == 0) return NORI_OK;
+    DeviceGuard g(ctx->device);
+    SCRATCH_IN(ctx, dp, pixel_samples, n * 2 * sizeof(float));
+    SCRATCH_OUT(ctx, dr, n * sizeof(nori_ray));
+    hipLaunchKernelGGL(sample_rays_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, ctx->dev.camera,
+                       (const float *) dp.p, n, (nori_ray *) dr.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpy(rays, dr.p, n * sizeof(nori_ray), hipMemcpyDeviceToHost));
+    return NORI_OK;
+}
+
+} // extern "C"
+
+template <int STACK>
+static void launch_li(nori_hip_ctx *ctx, const nori_ray *r, size_t n, const uint64_t *ss, const uint64_t *sq, float *rgb) {
+    const dim3 grid(grid_for(n)), block(kBlock);
+    const size_t lds = STACK * kBlock * sizeof(int);
+    switch (ctx->dev.integrator.type) {
+#define LI_CASE(I) case I: hipLaunchKernelGGL((li_kernel<I, STACK>), grid, block, lds, 0, ctx->dev, r, n, ss, sq, rgb); break;
+        LI_CASE(0) LI_CASE(1) LI_CASE(2) LI_CASE(3) LI_CASE(4) LI_CASE(5) LI_CASE(6)
+#undef LI_CASE
+    }
+}
+
+extern "C" {
+
+int nori_hip_li(nori_hip_ctx *ctx, const nori_ray *rays, size_t n, const uint64_t *seed_state, const uint64_t *seed_seq, float *rgb) {
+    REQUIRE_ACCEL(ctx);
+    if (n == 0) return NORI_OK;
+    if (!rays || !seed_state || !seed_seq || !rgb) return NORI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    SCRATCH_IN(ctx, dr, rays, n * sizeof(nori_ray));
+    SCRATCH_IN(ctx, ds, seed_state, n * sizeof(uint64_t));
+    SCRATCH_IN(ctx, dq, seed_seq, n * sizeof(uint64_t));
+    SCRATCH_OUT(ctx, dc, n * 3 * sizeof(float));
+    if (ctx->stack_depth <= 32) launch_li<32>(ctx, (const nori_ray *) dr.p, n, (const uint64_t *) ds.p, (const uint64_t *) dq.p, (float *) dc.p);
+    else launch_li<64>(ctx, (const nori_ray *) dr.p, n, (const uint64_t *) ds.p, (const uint64_t *) dq.p, (float *) dc.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpy(rgb, dc.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return NORI_OK;
+}
+
+static Bsdf bsdf_from_desc(const nori_bsdf_desc &d) {
+    Bsdf b;
+    b.type = d.type; b.albedo = mk3(d.albedo[0], d.albedo[1], d.albedo[2]);
+    b.alpha = d.alpha; b.int_ior = d.int_ior; b.ext_ior = d.ext_ior; b.ks = d.ks;
+    return b;
+}
+
+static int bsdf_call(nori_hip_ctx *ctx, const nori_bsdf_desc *bsdf, int op, const float *wi, const float *wo_in,
+                     const float *sample, size_t n, float *wo_out, float *value, float *eta, int32_t *measure) {
+    if (!ctx || !bsdf || !wi) return NORI_ERR_INVALID_ARGUMENT;
+    if (bsdf->type < 0 || bsdf->type > 3) { ctx->error = "unknown BSDF type"; return NORI_ERR_INVALID_ARGUMENT; }
+    if (n == 0) return NORI_OK;
+    DeviceGuard g(ctx->device);
+    SCRATCH_IN(ctx, dwi, wi, n * 3 * sizeof(float));
+    SCRATCH_IN(ctx, dwo, wo_in, n * 3 * sizeof(float));
+    SCRATCH_IN(ctx, dsm, sample, n * 2 * sizeof(float));
+    SCRATCH_OUT(ctx, dout_wo, n * 3 * sizeof(float));
+    SCRATCH_OUT(ctx, dval, n * 3 * sizeof(float));
+    SCRATCH_OUT(ctx, deta, n * sizeof(float));
+    SCRATCH_OUT(ctx, dmeas, n * sizeof(int32_t));
+    hipLaunchKernelGGL(bsdf_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, bsdf_from_desc(*bsdf), op,
+                       (const float *) dwi.p, (const float *) dwo.p, (const float *) dsm.p, n, (float *) dout_wo.p,
+                       (float *) dval.p, (float *) deta.p, (int32_t *) dmeas.p);
+    HIP_TRY(ctx, hipGetLastError());
+    if (op == 0) {
+        HIP_TRY(ctx, hipMemcpy(wo_out, dout_wo.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipMemcpy(value, dval.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        if (eta) HIP_TRY(ctx, hipMemcpy(eta, deta.p, n * sizeof(float), hipMemcpyDeviceToHost));
+        if (measure) HIP_TRY(ctx, hipMemcpy(measure, dmeas.p, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    } else {
+        HIP_TRY(ctx, hipMemcpy(value, dval.p, n * (op == 1 ? 3 : 1) * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return NORI_OK;
+}
+
+int nori_hip_bsdf_sample(nori_hip_ctx *ctx, const nori_bsdf_desc *bsdf, const float *wi, const float *sample, size_t n,
+                         float *wo, float *weight, float *eta, int32_t *measure) {
+    if (!sample || !wo || !weight) return NORI_ERR_INVALID_ARGUMENT;
+    return bsdf_call(ctx, bsdf, 0, wi, nullptr, sample, n, wo, weight, eta, measure);
+}
+int nori_hip_bsdf_eval(nori_hip_ctx *ctx, const nori_bsdf_desc *bsdf, const float *wi, const float *wo, size_t n, float *value) {
+    if (!wo || !value) return NORI_ERR_INVALID_ARGUMENT;
+    return bsdf_call(ctx, bsdf, 1, wi, wo, nullptr, n, nullptr, value, nullptr, nullptr);
+}
+int nori_hip_bsdf_pdf(nori_hip_ctx *ctx, const nori_bsdf_desc *bsdf, const float *wi, const float *wo, size_t n, float *pdf) {
+    if (!wo || !pdf) return NORI_ERR_INVALID_ARGUMENT;
+    return bsdf_call(ctx, bsdf, 2, wi, wo, nullptr, n, nullptr, pdf, nullptr, nullptr);
+}
+
+int nori_hip_warp(nori_hip_ctx *ctx, int warp, float param, const float *sample, size_t n, float *out) {
+    if (!ctx || !sample || !out || warp < 0 || warp > 6) return NORI_ERR_INVALID_ARGUMENT;
+    if (n == 0) return NORI_OK;
+    DeviceGuard g(ctx->device);
+    SCRATCH_IN(ctx, din, sample, n * 2 * sizeof(float));
+    SCRATCH_OUT(ctx, dout, n * 3 * sizeof(float));
+    hipLaunchKernelGGL(warp_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, warp, param, 0, (const float *) din.p, n, (float *) dout.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpy(out, dout.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return NORI_OK;
+}
+
+int nori_hip_warp_pdf(nori_hip_ctx *ctx, int warp, float param, const float *points, size_t n, float *pdf) {
+    if (!ctx || !points || !pdf || warp < 0 || warp > 6) return NORI_ERR_INVALID_ARGUMENT;
+    if (n == 0) return NORI_OK;
+    DeviceGuard g(ctx->device);
+    SCRATCH_IN(ctx, din, points, n * 3 * sizeof(float));
+    SCRATCH_OUT(ctx, dout, n * sizeof(float));
+    hipLaunchKernelGGL(warp_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, warp, param, 1, (const float *) din.p, n, (float *) dout.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpy(pdf, dout.p, n * sizeof(float), hipMemcpyDeviceToHost));
+    return NORI_OK;
+}
+
+int nori_hip_pcg32_floats(nori_hip_ctx *ctx, const uint64_t *seed_state, const uint64_t *seed_seq, size_t n, uint32_t count, float *out) {
+    if (!ctx || !seed_state || !seed_seq || !out) return NORI_ERR_INVALID_ARGUMENT;
+    if (n == 0 || count == 0) return NORI_OK;
+    DeviceGuard g(ctx->device);
+    SCRATCH_IN(ctx, ds, seed_state, n * sizeof(uint64_t));
+    SCRATCH_IN(ctx, dq, seed_seq, n * sizeof(uint64_t));
+    SCRATCH_OUT(ctx, dout, n * count * sizeof(float));
+    hipLaunchKernelGGL(pcg32_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, (const uint64_t *) ds.p, (const uint64_t *) dq.p, n, count, (float *) dout.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpy(out, dout.p, n * count * sizeof(float), hipMemcpyDeviceToHost));
+    return NORI_OK;
+}
+
+static size_t frame_floats(const nori_hip_ctx *ctx) {
+    const int b = ctx->host.filter.border;
+    return (size_t) (ctx->host.camera.width + 2 * b) * (size_t) (ctx->host.camera.height + 2 * b) * 4;
+}
+
+int nori_hip_splat(nori_hip_ctx *ctx, const float *positions, const float *values, size_t n, float *rgbw) {
+    if (!ctx || !ctx->have_scene) return NORI_ERR_NOT_READY;
+    if (!positions || !values || !rgbw) return NORI_ERR_INVALID_ARGUMENT;
+    if (n == 0) return NORI_OK;
+    DeviceGuard g(ctx->device);
+    const size_t fb = frame_floats(ctx) * sizeof(float);
+    SCRATCH_IN(ctx, dp, positions, n * 2 * sizeof(float));
+    SCRATCH_IN(ctx, dv, values, n * 3 * sizeof(float));
+    SCRATCH_IN(ctx, df, rgbw, fb);
+    hipLaunchKernelGGL(splat_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, ctx->dev.filter, ctx->d_filter,
+                       ctx->host.camera.width, ctx->host.camera.height, (const float *) dp.p, (const float *) dv.p, n, (float *) df.p);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpy(rgbw, df.p, fb, hipMemcpyDeviceToHost));
+    return NORI_OK;
+}
+
+} // extern "C"
+
+/* ---------------------------------------------------------------- render */
+template <int INTEG, int STACK, bool COUNT>
+static hipError_t launch_render_one(nori_hip_ctx *ctx, const RenderArgs &a, float *d_rgbw, hipStream_t s) {
+    const size_t lds = sizeof(int) * STACK * kBlock + sizeof(float) * ((size_t) a.tile_w * a.tile_w * 4 + 48 + 8);
+    auto kern = render_kernel<INTEG, STACK, COUNT>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_sel_tiles * a.n_chunks), dim3(kBlock), lds, s, ctx->dev, a,
+                       (const float *) ctx->d_filter, d_rgbw, ctx->d_stats);
+    return hipGetLastError();
+}
+
+template <int STACK, bool COUNT>
+static hipError_t launch_render(nori_hip_ctx *ctx, const RenderArgs &a, float *d_rgbw, hipStream_t s) {
+    switch (ctx->dev.integrator.type) {
+    case 0: return launch_render_one<0, STACK, COUNT>(ctx, a, d_rgbw, s);
+    case 1: return launch_render_one<1, STACK, COUNT>(ctx, a, d_rgbw, s);
+    case 2: return launch_render_one<2, STACK, COUNT>(ctx, a, d_rgbw, s);
+    case 3: return launch_render_one<3, STACK, COUNT>(ctx, a, d_rgbw, s);
+    case 4: return launch_render_one<4, STACK, COUNT>(ctx, a, d_rgbw, s);
+    case 5: return launch_render_one<5, STACK, COUNT>(ctx, a, d_rgbw, s);
+    default: return launch_render_one<6, STACK, COUNT>(ctx, a, d_rgbw, s);
+    }
+}
+
+extern "C" {
+
+int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d_rgbw, nori_render_stats *stats) {
+    REQUIRE_ACCEL(ctx);
+    if (!params || !d_rgbw) return NORI_ERR_INVALID_ARGUMENT;
+    if (params->tile_mod == 0 || params->tile_rem >= params->tile_mod) { ctx->error = "render: bad tile_mod/tile_rem"; return NORI_ERR_INVALID_ARGUMENT; }
+    if (params->seed_mode != NORI_SEED_PER_SAMPLE) { ctx->error = "render: the device implements NORI_SEED_PER_SAMPLE only"; return NORI_ERR_UNSUPPORTED; }
+    if (ctx->host.filter.border > 8) { ctx->error = "render: reconstruction filter radius too large for the LDS tile"; return NORI_ERR_UNSUPPORTED; }
+    DeviceGuard g(ctx->device);
+    hipStream_t s = (hipStream_t) params->stream;
+
+    RenderArgs a;
+    a.spp_begin = params->spp_begin; a.spp_count = params->spp_count;
+    a.tile_mod = params->tile_mod; a.tile_rem = params->tile_rem;
+    a.tiles_x = (uint32_t) ((ctx->host.camera.width + kTile - 1) / kTile);
+    a.tiles_y = (uint32_t) ((ctx->host.camera.height + kTile - 1) / kTile);
+    const uint32_t n_tiles = a.tiles_x * a.tiles_y;
+    a.n_sel_tiles = n_tiles > a.tile_rem ? (n_tiles - a.tile_rem + a.tile_mod - 1) / a.tile_mod : 0;
+    a.tile_w = kTile + 2 * ctx->host.filter.border;
+    /* spp chunking: aim for >= ~8 workgroups per CU slot-round, >= 8 spp per chunk */
+    uint32_t target_wgs = 8192;
+    if (const char *e = getenv("NORI_HIP_TARGET_WGS")) target_wgs = (uint32_t) std::max(1, atoi(e));
+    uint32_t n_chunks = 1;
+    if (a.n_sel_tiles > 0 && a.n_sel_tiles < target_wgs) n_chunks = (target_wgs + a.n_sel_tiles - 1) / a.n_sel_tiles;
+    n_chunks = std::max(1u, std::min(n_chunks, std::max(1u, a.spp_count / 8)));
+    a.chunk_spp = (a.spp_count + n_chunks - 1) / std::max(1u, n_chunks);
+    if (a.chunk_spp == 0) a.chunk_spp = 1;
+    a.n_chunks = std::max(1u, (a.spp_count + a.chunk_spp - 1) / a.chunk_spp);
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (stats) {
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), s));
+        HIP_TRY(ctx, hipEventCreate(&ev0)); HIP_TRY(ctx, hipEventCreate(&ev1));
+        HIP_TRY(ctx, hipEventRecord(ev0, s));
+    }
+    if (a.n_sel_tiles > 0 && a.spp_count > 0) {
+        hipError_t e;
+        const bool count = params->count_traversal != 0;
+        if (ctx->stack_depth <= 32) e = count ? launch_render<32, true>(ctx, a, (float *) d_rgbw, s) : launch_render<32, false>(ctx, a, (float *) d_rgbw, s);
+        else e = count ? launch_render<64, true>(ctx, a, (float *) d_rgbw, s) : launch_render<64, false>(ctx, a, (float *) d_rgbw, s);
+        HIP_TRY(ctx, e);
+    }
+    if (stats) {
+        HIP_TRY(ctx, hipEventRecord(ev1, s));
+        HIP_TRY(ctx, hipEventSynchronize(ev1));
+        float ms = 0.0f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ev0, ev1));
+        (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1);
+        unsigned long long h[8];
+        HIP_TRY(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
+        memset(stats, 0, sizeof(*stats));
+        stats->n_camera_samples = h[0]; stats->n_closest_rays = h[1]; stats->n_shadow_rays = h[2];
+        stats->n_node_tests = h[3]; stats->n_tri_tests = h[4]; stats->n_invalid = h[5];
+        stats->kernel_ms = ms;
+    }
+    return NORI_OK;
+}
+
+int nori_hip_render_host(nori_hip_ctx *ctx, const nori_render_params *params, float *rgbw, nori_render_stats *stats) {
+    REQUIRE_ACCEL(ctx);
+    if (!params || !rgbw) return NORI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    const size_t fb = frame_floats(ctx) * sizeof(float);
+    SCRATCH_OUT(ctx, df, fb);
+    HIP_TRY(ctx, hipMemset(df.p, 0, fb));
+    nori_render_stats local;
+    int rc = nori_hip_render(ctx, params, df.p, stats ? stats : &local);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpy(rgbw, df.p, fb, hipMemcpyDeviceToHost));
+    return NORI_OK;
+}
+
+int nori_hip_develop(nori_hip_ctx *ctx, const void *d_rgbw, void *d_rgb, void *stream) {
+    if (!ctx || !ctx->have_scene) return NORI_ERR_NOT_READY;
+    if (!d_rgbw || !d_rgb) return NORI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    const int w = ctx->host.camera.width, h = ctx->host.camera.height;
+    hipLaunchKernelGGL(develop_kernel, dim3((w + 255) / 256, h), dim3(256), 0, (hipStream_t) stream, (const float4 *) d_rgbw,
+                       (float *) d_rgb, w, h, ctx->host.filter.border);
+    HIP_TRY(ctx, hipGetLastError());
+    return NORI_OK;
+}
+
+} // extern "C"

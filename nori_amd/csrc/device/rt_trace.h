@@ -1,0 +1,180 @@
+/*
+ * rt_trace.h -- per-lane BVH traversal, Moeller-Trumbore, intersection record.
+ *
+ * Replaces Accel::rayIntersect (src/accel.cpp:23-99): the O(#triangles) scan of
+ * accel.cpp:30-40 becomes a BVH2 walk whose leaf test is Mesh::rayIntersect
+ * (src/mesh.cpp:39-76) in the same operation order, and whose tie rule
+ * reproduces the scan (a later triangle with equal t wins, because mesh.cpp:75
+ * accepts t <= maxt after accel.cpp:37 shrank maxt to t).  Node test: the
+ * slab test of include/nori/bbox.h:323-350, made conservative (far side
+ * widened by 2 ulp-ish) so no leaf whose triangle test would accept is culled.
+ *
+ * `Stack` is a policy with push(int)/pop()->int/empty(): in the HIP kernels it
+ * is an LDS column ([depth][lane], bank = lane -> conflict free); the CPU
+ * emulation harness passes a plain array.
+ */
+#pragma once
+#include "rt_types.h"
+
+namespace nrt {
+
+struct RayIn {
+    f3 o, d;
+    float mint, maxt;
+};
+
+/* Reciprocal direction for the slab test.  A zero component maps to a huge
+ * finite value so that (plane - o) * rcp is +-inf off the plane and exactly 0
+ * on it -- the containment rule of bbox.h:331-333 (boundary inclusive) without
+ * producing 0 * inf = NaN. */
+NORI_HD float slab_rcp(float d) {
+    float r = 1.0f / d;
+    if (!(fabsf(r) <= 3.0e38f)) r = (f2u(d) >> 31) ? -3.0e38f : 3.0e38f;
+    return r;
+}
+
+/* Moeller-Trumbore on a pre-gathered leaf record; src/mesh.cpp:39-76 */
+NORI_HD bool tri_test(f3 p0, f3 edge1, f3 edge2, f3 o, f3 d, float &u, float &v, float &t) {
+    f3 pvec = cross(d, edge2);
+    float det = dot(edge1, pvec);
+    if (det > -1e-8f && det < 1e-8f) return false;
+    float inv_det = 1.0f / det;
+    f3 tvec = o - p0;
+    u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 qvec = cross(tvec, edge1);
+    v = dot(d, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    t = dot(edge2, qvec) * inv_det;
+    return true;
+}
+
+NORI_HD void slab_pair(float bmin, float bmax, float o, float rcp, float &tnear, float &tfar) {
+    float t1 = (bmin - o) * rcp;
+    float t2 = (bmax - o) * rcp;
+    tnear = fmaxf(tnear, fminf(t1, t2));
+    tfar = fminf(tfar, fmaxf(t1, t2));
+}
+
+/* Closest-hit (any = false) or any-hit / shadow (any = true) traversal; `any`
+ * is a run-time flag so that lanes tracing shadow rays and lanes tracing
+ * closest-hit rays share one instruction stream.
+ * Returns true if something was hit; for closest-hit `hit` holds t,u,v,tri,mesh. */
+template <bool COUNT, class Stack>
+NORI_HD bool traverse(const DevScene &sc, const RayIn &ray, bool any, Stack &stack, Hit &hit, TraversalCounters &cnt) {
+    const f3 o = ray.o, d = ray.d;
+    const f3 rcp = mk3(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+    const float mint = ray.mint;
+    float best_t = ray.maxt;
+    hit.tri = kNoHit; hit.mesh = kNoHit; hit.t = ray.maxt; hit.u = 0.0f; hit.v = 0.0f;
+
+    int node = sc.root;
+    stack.reset();
+    if (sc.n_triangles == 0) return false;
+    while (true) {
+        if (node >= 0) {
+            const f4 *nq = sc.nodes + (size_t) node * kNodeQuads;
+            const f4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+            if (COUNT) cnt.nodes++;
+            float nl = -kInf, fl = kInf, nr = -kInf, fr = kInf;
+            slab_pair(q0.x, q0.w, o.x, rcp.x, nl, fl);
+            slab_pair(q0.y, q1.x, o.y, rcp.y, nl, fl);
+            slab_pair(q0.z, q1.y, o.z, rcp.z, nl, fl);
+            slab_pair(q1.z, q2.y, o.x, rcp.x, nr, fr);
+            slab_pair(q1.w, q2.z, o.y, rcp.y, nr, fr);
+            slab_pair(q2.x, q2.w, o.z, rcp.z, nr, fr);
+            fl *= 1.0000004f; fr *= 1.0000004f;
+            const bool hl = (nl <= fl) && (fl >= mint) && (nl <= best_t);
+            const bool hr = (nr <= fr) && (fr >= mint) && (nr <= best_t);
+            const int cl = (int) f2u(q3.x), cr = (int) f2u(q3.y);
+            if (hl && hr) {
+                const bool leftFirst = nl <= nr;
+                stack.push(leftFirst ? cr : cl);
+                node = leftFirst ? cl : cr;
+                continue;
+            } else if (hl) {
+                node = cl; continue;
+            } else if (hr) {
+                node = cr; continue;
+            }
+        } else {
+            const uint32_t code = ~(uint32_t) node;
+            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t i = 0; i < count; ++i) {
+                const f4 *tq = sc.tris + (size_t) (first + i) * kTriQuads;
+                const f4 a = tq[0], b = tq[1], c = tq[2];
+                if (COUNT) cnt.tris++;
+                float u, v, t;
+                if (!tri_test(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, u, v, t))
+                    continue;
+                if (!(t >= mint && t <= best_t)) continue;
+                const uint32_t gid = f2u(c.y);
+                if (any) { hit.tri = gid; hit.t = t; return true; }
+                if (t == best_t && hit.tri != kNoHit && gid < hit.tri) continue;
+                best_t = t;
+                hit.t = t; hit.u = u; hit.v = v; hit.tri = gid; hit.mesh = f2u(c.z);
+            }
+        }
+        if (stack.empty()) break;
+        node = stack.pop();
+    }
+    return hit.tri != kNoHit;
+}
+
+/* The part of the intersection record the integrators consume. */
+struct Surface {
+    f3 p;        /* its.p, accel.cpp:71 */
+    f3 ns;       /* its.shFrame.n, accel.cpp:82-95 */
+};
+
+/* src/accel.cpp:45-96 -- barycentric position and shading normal */
+NORI_HD void surface_fill(const DevScene &sc, const Hit &h, Surface &s, f3 *geo_n, f2 *uv_out) {
+    const MeshRec &m = sc.meshes[h.mesh];
+    const uint32_t *idx = sc.indices + 3 * (size_t) h.tri;
+    const uint32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
+    const f3 p0 = xyz(sc.positions[i0]), p1 = xyz(sc.positions[i1]), p2 = xyz(sc.positions[i2]);
+    const float b0 = 1.0f - (h.u + h.v), b1 = h.u, b2 = h.v;
+    s.p = (b0 * p0 + b1 * p1) + b2 * p2;
+    const bool needGeo = geo_n != nullptr || !(m.flags & kMeshHasNormals);
+    f3 ng = mk3(0.0f);
+    if (needGeo) ng = normalized(cross(p1 - p0, p2 - p0));
+    if (geo_n) *geo_n = ng;
+    if (m.flags & kMeshHasNormals) {
+        const f3 n0 = xyz(sc.normals[i0]), n1 = xyz(sc.normals[i1]), n2 = xyz(sc.normals[i2]);
+        s.ns = normalized((b0 * n0 + b1 * n1) + b2 * n2);
+    } else {
+        s.ns = ng;
+    }
+    if (uv_out) {
+        if (m.flags & kMeshHasUV) {
+            const f2 a = sc.texcoords[i0], b = sc.texcoords[i1], c = sc.texcoords[i2];
+            *uv_out = mk2((b0 * a.x + b1 * b.x) + b2 * c.x, (b0 * a.y + b1 * b.y) + b2 * c.y);
+        } else {
+            *uv_out = mk2(h.u, h.v);
+        }
+    }
+}
+
+/* PerspectiveCamera::sampleRay, src/perspective.cpp:76-97 */
+NORI_HD f3 mat_point(const float *m, f3 p) {
+    float r[4];
+    for (int i = 0; i < 4; ++i)
+        r[i] = ((m[4 * i] * p.x + m[4 * i + 1] * p.y) + m[4 * i + 2] * p.z) + m[4 * i + 3] * 1.0f;
+    return mk3(r[0] / r[3], r[1] / r[3], r[2] / r[3]);
+}
+NORI_HD f3 mat_vector(const float *m, f3 v) {
+    return mk3(m[0] * v.x + (m[1] * v.y + m[2] * v.z),
+               m[4] * v.x + (m[5] * v.y + m[6] * v.z),
+               m[8] * v.x + (m[9] * v.y + m[10] * v.z));
+}
+NORI_HD void camera_sample_ray(const CameraRec &cam, f2 samplePosition, RayIn &ray) {
+    f3 nearP = mat_point(cam.sample_to_camera, mk3(samplePosition.x * cam.inv_w, samplePosition.y * cam.inv_h, 0.0f));
+    f3 d = normalized(nearP);
+    float invZ = 1.0f / d.z;
+    ray.o = mat_point(cam.camera_to_world, mk3(0.0f, 0.0f, 0.0f));
+    ray.d = mat_vector(cam.camera_to_world, d);
+    ray.mint = cam.near_clip * invZ;
+    ray.maxt = cam.far_clip * invZ;
+}
+
+} // namespace nrt

@@ -1,0 +1,178 @@
+/*
+ * rt_types.h -- POD value types and device scene layout of the gfx950 path
+ * tracer.  Per-lane code in rt_*.h is plain scalar C++ annotated NORI_HD; the
+ * kernels that drive it (LDS stacks, tile accumulation, wave reductions) are
+ * HIP-only and live in nori_hip.hip.
+ *
+ * All arithmetic is IEEE float32 without FMA contraction (build flag
+ * -ffp-contract=off) in the reference's evaluation order, so that triangle
+ * hits are bit-identical to Mesh::rayIntersect (src/mesh.cpp:39-76).
+ *   dot(a,b)  = a.x*b.x + (a.y*b.y + a.z*b.z)      (Eigen's unrolled redux)
+ *   cross     = (a.y*b.z - a.z*b.y, a.z*b.x - a.x*b.z, a.x*b.y - a.y*b.x)
+ */
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NORI_HD __host__ __device__ __forceinline__
+#else
+#define NORI_HD inline
+#endif
+
+namespace nrt {
+
+constexpr float kEpsilon = 1e-4f;              /* include/nori/common.h:38 */
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kInvPi = 0.31830988618379067154f;
+constexpr float kInvTwoPi = 0.15915494309189533577f;
+constexpr float kInvFourPi = 0.07957747154594766788f;
+constexpr float kInf = __builtin_huge_valf();
+constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+constexpr int kFilterRes = 32;                 /* include/nori/rfilter.h:12 */
+constexpr int kTile = 16;                      /* NORI_TILE_SIZE */
+
+struct f2 { float x, y; };
+struct f3 { float x, y, z; };
+struct alignas(16) f4 { float x, y, z, w; };
+
+NORI_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+NORI_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+
+NORI_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+NORI_HD f3 mk3(float v) { return mk3(v, v, v); }
+NORI_HD f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
+NORI_HD f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+NORI_HD f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+NORI_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+NORI_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+NORI_HD f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+NORI_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+NORI_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+NORI_HD float dot(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+NORI_HD f3 cross(f3 a, f3 b) {
+    return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+NORI_HD f3 normalized(f3 a) {
+    float z = dot(a, a);
+    if (z > 0.0f) return a / sqrtf(z);
+    return a;
+}
+NORI_HD float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
+NORI_HD bool is_zero(f3 a) { return a.x == 0.0f && a.y == 0.0f && a.z == 0.0f; }
+NORI_HD f3 xyz(f4 a) { return mk3(a.x, a.y, a.z); }
+
+/* src/common.cpp:198-205 */
+NORI_HD bool color_valid(f3 c) {
+    return c.x >= 0.0f && c.y >= 0.0f && c.z >= 0.0f &&
+           c.x < kInf && c.y < kInf && c.z < kInf;    /* NaN fails every compare */
+}
+
+/* src/common.cpp:248-257 */
+NORI_HD void coordinate_system(f3 a, f3 &b, f3 &c) {
+    if (fabsf(a.x) > fabsf(a.y)) {
+        float invLen = 1.0f / sqrtf(a.x * a.x + a.z * a.z);
+        c = mk3(a.z * invLen, 0.0f, -a.x * invLen);
+    } else {
+        float invLen = 1.0f / sqrtf(a.y * a.y + a.z * a.z);
+        c = mk3(0.0f, a.z * invLen, -a.y * invLen);
+    }
+    b = cross(c, a);
+}
+
+/* include/nori/frame.h:20-50 */
+struct Frame {
+    f3 s, t, n;
+};
+NORI_HD Frame make_frame(f3 n) { Frame f; f.n = n; coordinate_system(n, f.s, f.t); return f; }
+NORI_HD f3 to_local(const Frame &f, f3 v) { return mk3(dot(v, f.s), dot(v, f.t), dot(v, f.n)); }
+NORI_HD f3 to_world(const Frame &f, f3 v) { return (f.s * v.x + f.t * v.y) + f.n * v.z; }
+
+/* ------------------------------------------------------------ scene in HBM */
+
+/* One BVH2 node = 64 B = 4 x dwordx4: both child boxes + both child links, so
+ * one fetch decides both children.
+ *   q0 = (lmin.x, lmin.y, lmin.z, lmax.x)
+ *   q1 = (lmax.y, lmax.z, rmin.x, rmin.y)
+ *   q2 = (rmin.z, rmax.x, rmax.y, rmax.z)
+ *   q3 = (bits left, bits right, 0, 0)
+ * child link >= 0: inner node index; < 0: leaf, ~link = (first_tri << 3) | (count - 1)
+ */
+constexpr int kNodeQuads = 4;
+constexpr int kMaxLeafTris = 8;
+
+/* One leaf triangle = 48 B = 3 x dwordx4, de-indexed and pre-gathered in leaf
+ * order so a leaf test is one contiguous read:
+ *   q0 = (p0.x, p0.y, p0.z, e1.x)   e1 = p1 - p0, e2 = p2 - p0 (same IEEE
+ *   q1 = (e1.y, e1.z, e2.x, e2.y)   subtraction mesh.cpp:43 performs per ray)
+ *   q2 = (e2.z, bits global_tri, bits mesh, 0)
+ */
+constexpr int kTriQuads = 3;
+
+struct MeshRec {
+    uint32_t tri_offset;      /* first global triangle                */
+    uint32_t vtx_offset;      /* first global vertex                  */
+    uint32_t n_triangles;
+    uint32_t flags;           /* bit0 normals, bit1 uv, bit2 emitter  */
+    int32_t bsdf_type;
+    float albedo[3];          /* diffuse albedo / microfacet kd       */
+    float alpha, int_ior, ext_ior, ks;
+    float radiance[3];
+    float inv_area;           /* DiscretePDF::getNormalization()      */
+    uint32_t cdf_offset;      /* into emitter_cdf (n_triangles+1)     */
+    uint32_t pad[3];
+};
+constexpr uint32_t kMeshHasNormals = 1u, kMeshHasUV = 2u, kMeshEmitter = 4u;
+
+struct CameraRec {
+    float sample_to_camera[16];   /* row-major */
+    float camera_to_world[16];
+    float inv_w, inv_h;
+    float near_clip, far_clip;
+    int32_t width, height;
+};
+
+struct FilterRec {
+    float table[kFilterRes + 1];  /* src/block.cpp:23-26 */
+    float radius;
+    float lookup_factor;          /* src/block.cpp:27 */
+    int32_t border;               /* src/block.cpp:20 */
+};
+
+struct IntegratorRec {
+    int32_t type;
+    float position[3];
+    float energy[3];
+};
+
+struct DevScene {
+    const f4 *nodes;
+    const f4 *tris;
+    const f4 *positions;        /* global vertex arrays, xyz_ */
+    const f4 *normals;          /* valid where the mesh has normals */
+    const f2 *texcoords;
+    const uint32_t *indices;    /* 3 per global triangle, GLOBAL vertex ids */
+    const MeshRec *meshes;
+    const float *emitter_cdf;
+    const uint32_t *emitters;   /* mesh ids of emitters */
+    uint32_t n_emitters;
+    uint32_t n_meshes;
+    uint32_t n_triangles;
+    int32_t root;               /* child-link code of the root */
+    CameraRec camera;
+    FilterRec filter;
+    IntegratorRec integrator;
+};
+
+struct Hit {
+    float t, u, v;
+    uint32_t tri;     /* global triangle id or kNoHit */
+    uint32_t mesh;
+};
+
+struct TraversalCounters {
+    uint32_t nodes, tris;
+};
+
+} // namespace nrt

@@ -1,0 +1,392 @@
+/*
+ * scene_prep.cpp -- load-time host code of libnori_hip (see scene_prep.h).
+ *
+ * Reference behaviour reproduced here (all load-time, float, no FMA):
+ *   ImageBlock filter tabulation     src/block.cpp:18-27
+ *   PerspectiveCamera::activate      src/perspective.cpp:41-74
+ *   Mesh::surfaceArea + DiscretePDF  src/mesh.cpp:31-37, include/nori/dpdf.h:42-97
+ *   per-triangle bbox / centroid     src/mesh.cpp:78-90 (inputs of the BVH build)
+ */
+#include "scene_prep.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace nrt {
+
+float rfilter_eval(const nori_rfilter_desc &d, float radius, float x) {
+    switch (d.type) {
+    case NORI_RFILTER_GAUSSIAN: {
+        float alpha = -1.0f / (2.0f * d.stddev * d.stddev);
+        return std::max(0.0f, std::exp(alpha * x * x) - std::exp(alpha * radius * radius));
+    }
+    case NORI_RFILTER_MITCHELL: {
+        const float B = d.B, C = d.C;
+        x = std::abs(2.0f * x / radius);
+        float x2 = x * x, x3 = x2 * x;
+        if (x < 1)
+            return 1.0f / 6.0f * ((12 - 9 * B - 6 * C) * x3 + (-18 + 12 * B + 6 * C) * x2 + (6 - 2 * B));
+        else if (x < 2)
+            return 1.0f / 6.0f * ((-B - 6 * C) * x3 + (6 * B + 30 * C) * x2 + (-12 * B - 48 * C) * x + (8 * B + 24 * C));
+        return 0.0f;
+    }
+    case NORI_RFILTER_TENT:
+        return std::max(0.0f, 1.0f - std::abs(x));
+    default:
+        return 1.0f;
+    }
+}
+
+static void mat4_mul(const float *a, const float *b, float *r) {
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            r[4 * i + j] = ((a[4 * i] * b[j] + a[4 * i + 1] * b[4 + j]) + a[4 * i + 2] * b[8 + j]) + a[4 * i + 3] * b[12 + j];
+}
+
+static bool mat4_inverse(const float *a, float *out) {
+    double w[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) { w[i][j] = a[4 * i + j]; w[i][j + 4] = i == j ? 1.0 : 0.0; }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 4; ++r) if (std::fabs(w[r][c]) > std::fabs(w[piv][c])) piv = r;
+        if (w[piv][c] == 0.0) return false;
+        if (piv != c) for (int j = 0; j < 8; ++j) std::swap(w[c][j], w[piv][j]);
+        const double dv = w[c][c];
+        for (int j = 0; j < 8; ++j) w[c][j] /= dv;
+        for (int r = 0; r < 4; ++r) {
+            if (r == c) continue;
+            const double f = w[r][c];
+            if (f != 0.0) for (int j = 0; j < 8; ++j) w[r][j] -= f * w[c][j];
+        }
+    }
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) out[4 * i + j] = (float) w[i][j + 4];
+    return true;
+}
+
+std::string prepare_scene(const nori_scene_desc &desc, HostScene &out) {
+    out = HostScene();
+    if (desc.n_meshes > 0 && !desc.meshes) return "scene has meshes == NULL";
+    if (desc.camera.width <= 0 || desc.camera.height <= 0) return "camera has a non-positive output size";
+    if (desc.sample_count < 0) return "negative sample count";
+    out.sample_count = desc.sample_count;
+
+    uint64_t nV = 0, nT = 0;
+    for (uint32_t i = 0; i < desc.n_meshes; ++i) { nV += desc.meshes[i].n_vertices; nT += desc.meshes[i].n_triangles; }
+    if (nT >= (1ull << 28)) return "too many triangles (limit 2^28)";
+    out.positions.resize(nV); out.normals.resize(nV); out.texcoords.resize(nV);
+    out.indices.resize(3 * nT); out.tri_mesh.resize(nT);
+
+    uint32_t vOff = 0, tOff = 0;
+    for (uint32_t mi = 0; mi < desc.n_meshes; ++mi) {
+        const nori_mesh_desc &m = desc.meshes[mi];
+        if ((m.n_vertices && !m.positions) || (m.n_triangles && !m.indices)) return "mesh with NULL buffers";
+        MeshRec rec; std::memset(&rec, 0, sizeof(rec));
+        rec.tri_offset = tOff; rec.vtx_offset = vOff; rec.n_triangles = m.n_triangles;
+        rec.flags = (m.normals ? kMeshHasNormals : 0u) | (m.texcoords ? kMeshHasUV : 0u) | (m.is_emitter ? kMeshEmitter : 0u);
+        if (m.texcoords) out.has_uv = true;
+        rec.bsdf_type = m.bsdf.type;
+        if (rec.bsdf_type < 0 || rec.bsdf_type > 3) return "unknown BSDF type";
+        for (int k = 0; k < 3; ++k) { rec.albedo[k] = m.bsdf.albedo[k]; rec.radiance[k] = m.radiance[k]; }
+        rec.alpha = m.bsdf.alpha; rec.int_ior = m.bsdf.int_ior; rec.ext_ior = m.bsdf.ext_ior; rec.ks = m.bsdf.ks;
+        for (uint32_t v = 0; v < m.n_vertices; ++v) {
+            f4 p; p.x = m.positions[3 * v]; p.y = m.positions[3 * v + 1]; p.z = m.positions[3 * v + 2]; p.w = 0.0f;
+            out.positions[vOff + v] = p;
+            f4 n; n.x = n.y = n.z = n.w = 0.0f;
+            if (m.normals) { n.x = m.normals[3 * v]; n.y = m.normals[3 * v + 1]; n.z = m.normals[3 * v + 2]; }
+            out.normals[vOff + v] = n;
+            f2 t; t.x = t.y = 0.0f;
+            if (m.texcoords) { t.x = m.texcoords[2 * v]; t.y = m.texcoords[2 * v + 1]; }
+            out.texcoords[vOff + v] = t;
+        }
+        for (uint32_t t = 0; t < m.n_triangles; ++t) {
+            for (int k = 0; k < 3; ++k) {
+                uint32_t id = m.indices[3 * t + k];
+                if (id >= m.n_vertices) return "triangle index out of range";
+                out.indices[3 * (size_t) (tOff + t) + k] = vOff + id;
+            }
+            out.tri_mesh[tOff + t] = mi;
+        }
+        if (m.is_emitter) {
+            if (m.n_triangles == 0) return "area emitter attached to an empty mesh";
+            /* DiscretePDF over Mesh::surfaceArea: append, then normalize */
+            rec.cdf_offset = (uint32_t) out.emitter_cdf.size();
+            out.emitter_cdf.push_back(0.0f);
+            for (uint32_t t = 0; t < m.n_triangles; ++t) {
+                const uint32_t *id = &out.indices[3 * (size_t) (tOff + t)];
+                const f3 p0 = xyz(out.positions[id[0]]), p1 = xyz(out.positions[id[1]]), p2 = xyz(out.positions[id[2]]);
+                const f3 c = cross(p1 - p0, p2 - p0);
+                const float area = 0.5f * sqrtf(dot(c, c));
+                out.emitter_cdf.push_back(out.emitter_cdf.back() + area);
+            }
+            const float sum = out.emitter_cdf.back();
+            float normalization = 0.0f;
+            if (sum > 0) {
+                normalization = 1.0f / sum;
+                for (uint32_t t = 1; t <= m.n_triangles; ++t) out.emitter_cdf[rec.cdf_offset + t] *= normalization;
+                out.emitter_cdf[rec.cdf_offset + m.n_triangles] = 1.0f;
+            }
+            rec.inv_area = normalization;
+            out.emitters.push_back(mi);
+        }
+        out.meshes.push_back(rec);
+        vOff += m.n_vertices; tOff += m.n_triangles;
+    }
+
+    /* camera, src/perspective.cpp:41-74 */
+    const nori_camera_desc &c = desc.camera;
+    CameraRec &cam = out.camera;
+    cam.width = c.width; cam.height = c.height;
+    cam.inv_w = 1.0f / (float) c.width; cam.inv_h = 1.0f / (float) c.height;
+    cam.near_clip = c.near_clip; cam.far_clip = c.far_clip;
+    std::memcpy(cam.camera_to_world, c.to_world, sizeof(float) * 16);
+    {
+        const float aspect = c.width / (float) c.height;
+        const float recip = 1.0f / (c.far_clip - c.near_clip);
+        const float cot = 1.0f / std::tan((c.fov / 2.0f) * (kPi / 180.0f));
+        float persp[16] = {0};
+        persp[0] = cot; persp[5] = cot;
+        persp[10] = c.far_clip * recip; persp[11] = -c.near_clip * c.far_clip * recip;
+        persp[14] = 1.0f;
+        /* DiagonalMatrix(-0.5, -0.5 aspect, 1) * Translation(-1, -1/aspect, 0) */
+        const float sx = -0.5f, sy = -0.5f * aspect, sz = 1.0f;
+        const float tx = -1.0f, ty = -1.0f / aspect, tz = 0.0f;
+        float A[16] = {0};
+        A[0] = sx; A[5] = sy; A[10] = sz; A[15] = 1.0f;
+        A[3] = sx * tx; A[7] = sy * ty; A[11] = sz * tz;
+        float M[16];
+        mat4_mul(A, persp, M);
+        if (!mat4_inverse(M, cam.sample_to_camera)) return "singular camera projection";
+    }
+
+    /* filter, src/block.cpp:18-27 */
+    const nori_rfilter_desc &rf = desc.rfilter;
+    if (rf.type < 0 || rf.type > 3) return "unknown reconstruction filter";
+    FilterRec &fl = out.filter;
+    fl.radius = rf.type == NORI_RFILTER_TENT ? 1.0f : (rf.type == NORI_RFILTER_BOX ? 0.5f : rf.radius);
+    if (!(fl.radius > 0.0f)) return "reconstruction filter radius must be positive";
+    fl.border = (int) std::ceil(fl.radius - 0.5f);
+    for (int i = 0; i < kFilterRes; ++i) {
+        const float pos = (fl.radius * i) / kFilterRes;
+        fl.table[i] = rfilter_eval(rf, fl.radius, pos);
+    }
+    fl.table[kFilterRes] = 0.0f;
+    fl.lookup_factor = kFilterRes / fl.radius;
+
+    out.integrator.type = desc.integrator.type;
+    if (out.integrator.type < 0 || out.integrator.type > 6) return "unknown integrator type";
+    for (int k = 0; k < 3; ++k) { out.integrator.position[k] = desc.integrator.position[k]; out.integrator.energy[k] = desc.integrator.energy[k]; }
+    return std::string();
+}
+
+/* ------------------------------------------------------------- SAH builder */
+namespace {
+
+struct Box {
+    float mn[3], mx[3];
+    void reset() { for (int i = 0; i < 3; ++i) { mn[i] = std::numeric_limits<float>::infinity(); mx[i] = -std::numeric_limits<float>::infinity(); } }
+    void grow(const Box &b) { for (int i = 0; i < 3; ++i) { mn[i] = std::min(mn[i], b.mn[i]); mx[i] = std::max(mx[i], b.mx[i]); } }
+    void grow(const float *p) { for (int i = 0; i < 3; ++i) { mn[i] = std::min(mn[i], p[i]); mx[i] = std::max(mx[i], p[i]); } }
+    float area() const {
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        if (!(dx >= 0.0f)) return 0.0f;
+        return 2.0f * (dx * dy + dy * dz + dz * dx);
+    }
+};
+
+struct BuildNode {
+    Box box;
+    int32_t left = -1, right = -1;     /* build-node ids; -1 for leaves */
+    uint32_t first = 0, count = 0;
+    uint32_t depth = 0;
+};
+
+constexpr int kBins = 32;
+constexpr uint32_t kLeafTarget = 4;
+constexpr float kCostNode = 1.0f, kCostTri = 1.0f;
+
+} // namespace
+
+std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh &out) {
+    const auto t0 = std::chrono::steady_clock::now();
+    out = HostBvh();
+    const uint32_t n = (uint32_t) sc.tri_mesh.size();
+    if (n == 0) {
+        /* traversal returns before touching nodes when there are no triangles */
+        out.nodes.resize(kNodeQuads); out.tris.resize(kTriQuads);
+        std::memset(out.nodes.data(), 0, sizeof(f4) * kNodeQuads);
+        std::memset(out.tris.data(), 0, sizeof(f4) * kTriQuads);
+        out.root = 0; out.n_nodes = 1;
+        return std::string();
+    }
+
+    std::vector<Box> boxes(n);
+    std::vector<float> cent(3 * (size_t) n);
+    Box sceneBox; sceneBox.reset();
+    for (uint32_t t = 0; t < n; ++t) {
+        Box b; b.reset();
+        for (int k = 0; k < 3; ++k) { const f4 &p = sc.positions[sc.indices[3 * (size_t) t + k]]; const float q[3] = {p.x, p.y, p.z}; b.grow(q); }
+        boxes[t] = b; sceneBox.grow(b);
+    }
+    /* Pad every triangle box: the slab test must never cull a leaf whose
+       Moeller-Trumbore test (rounded differently) accepts the ray. */
+    {
+        const float dx = sceneBox.mx[0] - sceneBox.mn[0], dy = sceneBox.mx[1] - sceneBox.mn[1], dz = sceneBox.mx[2] - sceneBox.mn[2];
+        const float pad = 2e-5f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f;
+        for (uint32_t t = 0; t < n; ++t)
+            for (int k = 0; k < 3; ++k) {
+                boxes[t].mn[k] -= pad; boxes[t].mx[k] += pad;
+                cent[3 * (size_t) t + k] = 0.5f * (boxes[t].mn[k] + boxes[t].mx[k]);
+            }
+    }
+
+    std::vector<uint32_t> prim(n);
+    for (uint32_t t = 0; t < n; ++t) prim[t] = t;
+    std::vector<BuildNode> bn;
+    bn.reserve(2 * (size_t) n / 2 + 16);
+    bn.emplace_back();
+    bn[0].first = 0; bn[0].count = n; bn[0].depth = 0;
+    std::vector<uint32_t> todo; todo.push_back(0);
+
+    auto log2ceil = [](uint32_t v) { uint32_t r = 0; while ((1u << r) < v) ++r; return r; };
+
+    while (!todo.empty()) {
+        const uint32_t id = todo.back(); todo.pop_back();
+        const uint32_t first = bn[id].first, count = bn[id].count, depth = bn[id].depth;
+        Box nb, cb; nb.reset(); cb.reset();
+        for (uint32_t i = first; i < first + count; ++i) { nb.grow(boxes[prim[i]]); cb.grow(&cent[3 * (size_t) prim[i]]); }
+        bn[id].box = nb;
+        if (count <= 1) continue;
+
+        /* depth budget: once the remaining levels only just suffice for a
+           balanced split, stop using SAH */
+        const uint32_t needBalanced = log2ceil((count + kLeafTarget - 1) / kLeafTarget) + 1;
+        const bool forceMedian = depth + needBalanced + 1 >= max_depth_limit;
+
+        int axis = 0;
+        { float e0 = cb.mx[0] - cb.mn[0], e1 = cb.mx[1] - cb.mn[1], e2 = cb.mx[2] - cb.mn[2];
+          axis = (e0 >= e1 && e0 >= e2) ? 0 : (e1 >= e2 ? 1 : 2); }
+        uint32_t mid = first;
+        bool split = false;
+
+        if (!forceMedian) {
+            float bestCost = std::numeric_limits<float>::infinity(); int bestAxis = -1, bestBin = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+                const float cmin = cb.mn[ax], cmax = cb.mx[ax];
+                if (!(cmax > cmin)) continue;
+                Box bb[kBins]; uint32_t bc[kBins];
+                for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
+                const float scale = kBins / (cmax - cmin);
+                for (uint32_t i = first; i < first + count; ++i) {
+                    int b = (int) ((cent[3 * (size_t) prim[i] + ax] - cmin) * scale);
+                    b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+                    bb[b].grow(boxes[prim[i]]); bc[b]++;
+                }
+                float ra[kBins]; uint32_t rc[kBins]; Box acc; acc.reset(); uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); c += bc[b]; ra[b] = acc.area(); rc[b] = c; }
+                Box la; la.reset(); uint32_t lc = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    la.grow(bb[b]); lc += bc[b];
+                    if (lc == 0 || rc[b + 1] == 0) continue;
+                    const float cost = la.area() * (float) lc + ra[b + 1] * (float) rc[b + 1];
+                    if (cost < bestCost) { bestCost = cost; bestAxis = ax; bestBin = b; }
+                }
+            }
+            if (bestAxis >= 0) {
+                const float area = nb.area();
+                const float splitCost = kCostNode * area + kCostTri * bestCost;
+                const float leafCost = kCostTri * area * (float) count;
+                if (count > kLeafTarget || splitCost < leafCost) {
+                    const float cmin = cb.mn[bestAxis], scale = kBins / (cb.mx[bestAxis] - cmin);
+                    auto it = std::partition(prim.begin() + first, prim.begin() + first + count, [&](uint32_t g) {
+                        int b = (int) ((cent[3 * (size_t) g + bestAxis] - cmin) * scale);
+                        b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+                        return b <= bestBin;
+                    });
+                    mid = (uint32_t) (it - prim.begin());
+                    split = mid > first && mid < first + count;
+                }
+            }
+        }
+        if (!split) {
+            if (count <= kLeafTarget) continue;            /* stays a leaf */
+            mid = first + count / 2;
+            std::nth_element(prim.begin() + first, prim.begin() + mid, prim.begin() + first + count,
+                             [&](uint32_t a, uint32_t b) { return cent[3 * (size_t) a + axis] < cent[3 * (size_t) b + axis]; });
+        }
+        const int32_t l = (int32_t) bn.size(); bn.emplace_back();
+        const int32_t r = (int32_t) bn.size(); bn.emplace_back();
+        bn[id].left = l; bn[id].right = r;
+        bn[l].first = first; bn[l].count = mid - first; bn[l].depth = depth + 1;
+        bn[r].first = mid; bn[r].count = first + count - mid; bn[r].depth = depth + 1;
+        todo.push_back((uint32_t) r); todo.push_back((uint32_t) l);
+    }
+
+    /* leaf triangle records, in prim order */
+    out.tris.resize((size_t) n * kTriQuads);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t g = prim[i];
+        const uint32_t *id = &sc.indices[3 * (size_t) g];
+        const f3 p0 = xyz(sc.positions[id[0]]), p1 = xyz(sc.positions[id[1]]), p2 = xyz(sc.positions[id[2]]);
+        const f3 e1 = p1 - p0, e2 = p2 - p0;
+        f4 *q = &out.tris[(size_t) i * kTriQuads];
+        q[0].x = p0.x; q[0].y = p0.y; q[0].z = p0.z; q[0].w = e1.x;
+        q[1].x = e1.y; q[1].y = e1.z; q[1].z = e2.x; q[1].w = e2.y;
+        q[2].x = e2.z; q[2].y = u2f(g); q[2].z = u2f(sc.tri_mesh[g]); q[2].w = 0.0f;
+    }
+
+    /* flatten: one device node per inner build node, DFS pre-order */
+    auto isLeaf = [&](int32_t b) { return bn[b].left < 0; };
+    auto leafCode = [&](int32_t b) -> int32_t {
+        return (int32_t) ~((bn[b].first << 3) | (bn[b].count - 1));
+    };
+    for (size_t b = 0; b < bn.size(); ++b)
+        if (isLeaf((int32_t) b) && bn[b].count > (uint32_t) kMaxLeafTris) return "internal: leaf exceeds kMaxLeafTris";
+
+    const float rootArea = std::max(bn[0].box.area(), 1e-30f);
+    double sah = 0.0;
+    uint32_t maxDepth = 0, nLeaves = 0;
+    if (isLeaf(0)) {
+        out.root = leafCode(0);
+        out.nodes.resize(kNodeQuads);
+        std::memset(out.nodes.data(), 0, sizeof(f4) * kNodeQuads);
+        out.n_nodes = 0; nLeaves = 1;
+        sah = kCostTri * bn[0].count;
+    } else {
+        std::vector<int32_t> devId(bn.size(), -1);
+        uint32_t nInner = 0;
+        { std::vector<int32_t> st; st.push_back(0);
+          while (!st.empty()) { int32_t b = st.back(); st.pop_back(); if (isLeaf(b)) continue; devId[b] = (int32_t) nInner++; st.push_back(bn[b].right); st.push_back(bn[b].left); } }
+        out.nodes.resize((size_t) nInner * kNodeQuads);
+        for (size_t b = 0; b < bn.size(); ++b) {
+            const float rel = bn[b].box.area() / rootArea;
+            if (isLeaf((int32_t) b)) {
+                nLeaves++; maxDepth = std::max(maxDepth, bn[b].depth);
+                sah += kCostTri * rel * bn[b].count;
+                continue;
+            }
+            sah += kCostNode * rel;
+            const Box &L = bn[bn[b].left].box, &R = bn[bn[b].right].box;
+            const int32_t cl = isLeaf(bn[b].left) ? leafCode(bn[b].left) : devId[bn[b].left];
+            const int32_t cr = isLeaf(bn[b].right) ? leafCode(bn[b].right) : devId[bn[b].right];
+            f4 *q = &out.nodes[(size_t) devId[b] * kNodeQuads];
+            q[0].x = L.mn[0]; q[0].y = L.mn[1]; q[0].z = L.mn[2]; q[0].w = L.mx[0];
+            q[1].x = L.mx[1]; q[1].y = L.mx[2]; q[1].z = R.mn[0]; q[1].w = R.mn[1];
+            q[2].x = R.mn[2]; q[2].y = R.mx[0]; q[2].z = R.mx[1]; q[2].w = R.mx[2];
+            q[3].x = u2f((uint32_t) cl); q[3].y = u2f((uint32_t) cr); q[3].z = 0.0f; q[3].w = 0.0f;
+        }
+        out.root = 0;
+        out.n_nodes = nInner;
+    }
+    out.n_leaves = nLeaves;
+    out.max_depth = maxDepth;
+    out.sah_cost = (float) sah;
+    if (maxDepth + 1 > max_depth_limit) return "internal: BVH deeper than the traversal stack";
+    out.build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return std::string();
+}
+
+} // namespace nrt

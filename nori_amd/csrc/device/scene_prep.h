@@ -1,0 +1,49 @@
+/*
+ * scene_prep.h -- load-time host code of libnori_hip: flattens a
+ * nori_scene_desc into the arrays the kernels read (rt_types.h layouts) and
+ * builds the SAH BVH.  Runs once per scene; not on the per-sample path.
+ */
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../../include/nori_hip.h"
+#include "rt_types.h"
+
+namespace nrt {
+
+struct HostScene {
+    std::vector<f4> positions, normals;
+    std::vector<f2> texcoords;
+    std::vector<uint32_t> indices;      /* 3 per triangle, global vertex ids */
+    std::vector<uint32_t> tri_mesh;     /* mesh id per global triangle       */
+    std::vector<MeshRec> meshes;
+    std::vector<float> emitter_cdf;
+    std::vector<uint32_t> emitters;
+    CameraRec camera;
+    FilterRec filter;
+    IntegratorRec integrator;
+    int32_t sample_count = 1;
+    bool has_uv = false;
+};
+
+struct HostBvh {
+    std::vector<f4> nodes;              /* kNodeQuads per node   */
+    std::vector<f4> tris;               /* kTriQuads per triangle, leaf order */
+    int32_t root = 0;
+    uint32_t n_nodes = 0, n_leaves = 0, max_depth = 0;
+    float sah_cost = 0.0f;
+    float build_ms = 0.0f;
+};
+
+/* Returns an empty string on success, else the error message. */
+std::string prepare_scene(const nori_scene_desc &desc, HostScene &out);
+
+/* Binned-SAH BVH2 over all triangles of the scene (Accel::build,
+ * src/accel.cpp:19-21).  max_depth_limit bounds the traversal stack. */
+std::string build_bvh_sah(const HostScene &scene, uint32_t max_depth_limit, HostBvh &out);
+
+/* Filter evaluation, src/rfilter.cpp:25-29,56-70,85-103 */
+float rfilter_eval(const nori_rfilter_desc &d, float radius, float x);
+
+} // namespace nrt

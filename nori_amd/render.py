@@ -1,0 +1,222 @@
+"""`Renderer`: Python handle on a libnori_hip context (one GPU).
+
+Thin glue over the C ABI of include/nori_hip.h: numpy in / numpy out for the
+operator-level twins, torch CUDA tensors (device memory, streams) for the
+frame buffer of the hot path.  No compute happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import NoriError, ptr
+from .scene import Bsdf, Scene
+
+
+def _f32(a, shape_last=None):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if shape_last is not None:
+        a = a.reshape(-1, shape_last)
+    return a
+
+
+class Renderer:
+    """Owns a `nori_hip_ctx`.  Mirrors Scene/Accel/Integrator of the reference:
+    `upload` = Scene::addChild + activate, `build_accel` = Accel::build,
+    `intersect` = Accel::rayIntersect, `li` = Integrator::Li, `render` =
+    render() of src/main.cpp:58-119."""
+
+    def __init__(self, device: int = 0):
+        self._lib = capi.load_hip()
+        h = C.c_void_p()
+        rc = self._lib.nori_hip_create(int(device), C.byref(h))
+        if rc != 0:
+            msg = self._lib.nori_hip_last_error(None)
+            raise NoriError(f"nori_hip_create({device}) failed: {capi.STATUS.get(rc, rc)}: "
+                            f"{msg.decode() if msg else ''}")
+        self._h = h
+        self.device = int(device)
+        self.scene: Optional[Scene] = None
+
+    # -------------------------------------------------------------- plumbing
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nori_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.nori_hip_last_error(self._h)
+            raise NoriError(f"{what}: {capi.STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    # ------------------------------------------------------------ load time
+    def upload(self, scene: Scene, build: bool = True, builder: int = 0):
+        desc, keep = scene.c_desc()
+        self._check(self._lib.nori_hip_upload_scene(self._h, C.byref(desc)), "upload_scene")
+        del keep
+        self.scene = scene
+        if build:
+            self.build_accel(builder)
+        return self
+
+    def build_accel(self, builder: int = 0):
+        self._check(self._lib.nori_hip_build_accel(self._h, int(builder)), "build_accel")
+
+    def accel_info(self) -> dict:
+        info = capi.AccelInfo()
+        self._check(self._lib.nori_hip_accel_info(self._h, C.byref(info)), "accel_info")
+        return info.as_dict()
+
+    @property
+    def border(self) -> int:
+        b = self._lib.nori_hip_border_size(self._h)
+        if b < 0:
+            self._check(b, "border_size")
+        return b
+
+    def frame_shape(self):
+        b = self.border
+        c = self.scene.camera
+        return (c.height + 2 * b, c.width + 2 * b, 4)
+
+    # ---------------------------------------------------- operator-level twins
+    def intersect(self, rays: np.ndarray, shadow: bool = False) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=capi.RAY_DTYPE)
+        its = np.zeros(rays.shape[0], dtype=capi.ITS_DTYPE)
+        self._check(self._lib.nori_hip_intersect(self._h, ptr(rays), ptr(its), rays.shape[0], int(shadow)), "intersect")
+        return its
+
+    def sample_rays(self, pixel_samples) -> np.ndarray:
+        ps = _f32(pixel_samples, 2)
+        rays = np.zeros(ps.shape[0], dtype=capi.RAY_DTYPE)
+        self._check(self._lib.nori_hip_sample_rays(self._h, ptr(ps), ps.shape[0], ptr(rays)), "sample_rays")
+        return rays
+
+    def li(self, rays, seed_state, seed_seq) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, dtype=capi.RAY_DTYPE)
+        ss = np.ascontiguousarray(seed_state, dtype=np.uint64)
+        sq = np.ascontiguousarray(seed_seq, dtype=np.uint64)
+        out = np.zeros((rays.shape[0], 3), dtype=np.float32)
+        self._check(self._lib.nori_hip_li(self._h, ptr(rays), rays.shape[0], ptr(ss), ptr(sq), ptr(out)), "li")
+        return out
+
+    def bsdf_sample(self, bsdf: Bsdf, wi, sample):
+        wi, sample = _f32(wi, 3), _f32(sample, 2)
+        n = wi.shape[0]
+        wo, w = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+        eta, meas = np.zeros(n, np.float32), np.zeros(n, np.int32)
+        d = bsdf.desc()
+        self._check(self._lib.nori_hip_bsdf_sample(self._h, C.byref(d), ptr(wi), ptr(sample), n, ptr(wo), ptr(w),
+                                                   ptr(eta), ptr(meas)), "bsdf_sample")
+        return wo, w, eta, meas
+
+    def bsdf_eval(self, bsdf: Bsdf, wi, wo):
+        wi, wo = _f32(wi, 3), _f32(wo, 3)
+        out = np.zeros((wi.shape[0], 3), np.float32)
+        d = bsdf.desc()
+        self._check(self._lib.nori_hip_bsdf_eval(self._h, C.byref(d), ptr(wi), ptr(wo), wi.shape[0], ptr(out)), "bsdf_eval")
+        return out
+
+    def bsdf_pdf(self, bsdf: Bsdf, wi, wo):
+        wi, wo = _f32(wi, 3), _f32(wo, 3)
+        out = np.zeros(wi.shape[0], np.float32)
+        d = bsdf.desc()
+        self._check(self._lib.nori_hip_bsdf_pdf(self._h, C.byref(d), ptr(wi), ptr(wo), wi.shape[0], ptr(out)), "bsdf_pdf")
+        return out
+
+    def warp(self, name: str, sample, param: float = 0.0):
+        s = _f32(sample, 2)
+        out = np.zeros((s.shape[0], 3), np.float32)
+        self._check(self._lib.nori_hip_warp(self._h, capi.WARP_NAMES[name], float(param), ptr(s), s.shape[0], ptr(out)), "warp")
+        return out
+
+    def warp_pdf(self, name: str, points, param: float = 0.0):
+        p = _f32(points, 3)
+        out = np.zeros(p.shape[0], np.float32)
+        self._check(self._lib.nori_hip_warp_pdf(self._h, capi.WARP_NAMES[name], float(param), ptr(p), p.shape[0], ptr(out)), "warp_pdf")
+        return out
+
+    def pcg32_floats(self, seed_state, seed_seq, count: int):
+        ss = np.ascontiguousarray(seed_state, dtype=np.uint64)
+        sq = np.ascontiguousarray(seed_seq, dtype=np.uint64)
+        out = np.zeros((ss.shape[0], count), np.float32)
+        self._check(self._lib.nori_hip_pcg32_floats(self._h, ptr(ss), ptr(sq), ss.shape[0], count, ptr(out)), "pcg32_floats")
+        return out
+
+    def splat(self, positions, values, rgbw: Optional[np.ndarray] = None):
+        p, v = _f32(positions, 2), _f32(values, 3)
+        if rgbw is None:
+            rgbw = np.zeros(self.frame_shape(), np.float32)
+        rgbw = np.ascontiguousarray(rgbw, dtype=np.float32)
+        self._check(self._lib.nori_hip_splat(self._h, ptr(p), ptr(v), p.shape[0], ptr(rgbw)), "splat")
+        return rgbw
+
+    # ------------------------------------------------------------ hot path
+    @staticmethod
+    def _params(spp_begin, spp_count, tile_mod, tile_rem, count_traversal, stream):
+        p = capi.RenderParams()
+        p.spp_begin, p.spp_count = int(spp_begin), int(spp_count)
+        p.tile_mod, p.tile_rem = int(tile_mod), int(tile_rem)
+        p.seed_mode = capi.SEED_PER_SAMPLE
+        p.count_traversal = int(bool(count_traversal))
+        p.stream = stream
+        return p
+
+    def render_host(self, spp_count=None, spp_begin=0, tile_mod=1, tile_rem=0, count_traversal=False):
+        """Render into a fresh host RGBW frame; returns (rgbw, stats dict)."""
+        spp = self.scene.sample_count if spp_count is None else spp_count
+        p = self._params(spp_begin, spp, tile_mod, tile_rem, count_traversal, None)
+        rgbw = np.zeros(self.frame_shape(), np.float32)
+        st = capi.RenderStats()
+        self._check(self._lib.nori_hip_render_host(self._h, C.byref(p), ptr(rgbw), C.byref(st)), "render_host")
+        return rgbw, st.as_dict()
+
+    def render_into(self, rgbw_tensor, spp_count=None, spp_begin=0, tile_mod=1, tile_rem=0,
+                    count_traversal=False, stream=None, want_stats=True):
+        """Accumulate into a torch CUDA float32 tensor of shape frame_shape().
+
+        `stream`: a torch.cuda.Stream (its raw hipStream_t is handed to the
+        library) or None for the legacy default stream."""
+        assert rgbw_tensor.is_cuda and rgbw_tensor.is_contiguous() and tuple(rgbw_tensor.shape) == tuple(self.frame_shape())
+        spp = self.scene.sample_count if spp_count is None else spp_count
+        raw = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        p = self._params(spp_begin, spp, tile_mod, tile_rem, count_traversal, raw)
+        st = capi.RenderStats() if want_stats else None
+        self._check(self._lib.nori_hip_render(self._h, C.byref(p), C.c_void_p(rgbw_tensor.data_ptr()),
+                                              C.byref(st) if st is not None else None), "render")
+        return st.as_dict() if st is not None else None
+
+    def develop(self, rgbw_tensor, stream=None):
+        """ImageBlock::toBitmap on the device: (H, W, 3) torch tensor."""
+        import torch
+        c = self.scene.camera
+        rgb = torch.empty((c.height, c.width, 3), dtype=torch.float32, device=rgbw_tensor.device)
+        raw = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._check(self._lib.nori_hip_develop(self._h, C.c_void_p(rgbw_tensor.data_ptr()), C.c_void_p(rgb.data_ptr()), raw), "develop")
+        return rgb
+
+
+def develop_host(rgbw: np.ndarray, border: int) -> np.ndarray:
+    """ImageBlock::toBitmap (src/block.cpp:45-51) for a host RGBW frame.  Pure
+    reshaping/division of an already rendered frame (output side, not the hot path)."""
+    h, w = rgbw.shape[0] - 2 * border, rgbw.shape[1] - 2 * border
+    core = rgbw[border:border + h, border:border + w]
+    wgt = core[..., 3:4]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rgb = np.where(wgt != 0, core[..., :3] / wgt, np.float32(0))
+    return rgb.astype(np.float32)

@@ -1,0 +1,136 @@
+"""CPU checks of the DEVICE code's per-lane logic (tests/emu: the same rt_*.h
+headers the HIP kernels are built from, compiled with g++) against the oracle.
+The real kernels are checked by tests/test_gpu_parity.py on the GPU box."""
+import numpy as np
+import pytest
+
+from nori_amd.scene import Bsdf
+from tests import scenes
+from tests.backends import Emu, Oracle
+
+ITS_FIELDS = ["p", "t", "uv", "sh_s", "sh_t", "sh_n", "geo_s", "geo_t", "geo_n", "mesh", "tri"]
+
+
+def _assert_its_equal(a, b):
+    for k in ITS_FIELDS:
+        assert np.array_equal(a[k], b[k]), f"intersection field {k} differs"
+
+
+@pytest.mark.parametrize("n_tris,seed", [(1, 3), (7, 4), (300, 5), (5000, 6)])
+def test_bvh_traversal_equals_brute_force_soup(n_tris, seed):
+    sc = scenes.soup_scene(n_tris, seed)
+    rays = scenes.random_rays(20000 if n_tris < 1000 else 4000, seed=seed + 10)
+    o, e = Oracle(sc), Emu(sc)
+    _assert_its_equal(o.intersect(rays), e.intersect(rays))
+    assert np.array_equal(o.intersect(rays, True)["mesh"], e.intersect(rays, True)["mesh"])
+
+
+def test_bvh_traversal_cornell_axis_aligned_and_ties():
+    """Axis-aligned walls (flat boxes), shared edges and bounded segments."""
+    sc = scenes.cornell_box(16, 16, 1)
+    rays = scenes.random_rays(30000, seed=7, extent=0.9)
+    rays["o"] += np.float32([0, 1, 0])
+    # axis-aligned directions incl. exact zeros, and rays lying in wall planes
+    rays["d"][:3000] = np.float32([0, -1, 0])
+    rays["d"][3000:6000] = np.float32([1, 0, 0])
+    rays["o"][6000:7000, 1] = 0.0
+    rays["d"][6000:7000, 1] = 0.0
+    rays["d"][6000:7000] /= np.linalg.norm(rays["d"][6000:7000], axis=1, keepdims=True)
+    rays["maxt"][7000:9000] = np.random.default_rng(1).uniform(0.1, 2.0, 2000).astype(np.float32)
+    o, e = Oracle(sc), Emu(sc)
+    _assert_its_equal(o.intersect(rays), e.intersect(rays))
+    assert np.array_equal(o.intersect(rays, True)["mesh"], e.intersect(rays, True)["mesh"])
+
+
+def test_duplicate_triangles_tie_rule():
+    """Coincident triangles: the linear scan keeps the LAST one (mesh.cpp:75 accepts t <= maxt)."""
+    from nori_amd.scene import Mesh, Scene
+    v = np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]])
+    f = np.uint32([[0, 1, 2]])
+    sc = scenes.soup_scene(1)
+    sc.meshes = [Mesh(v, f), Mesh(v, np.uint32([[0, 1, 2], [0, 1, 2]])), Mesh(v + np.float32([0, 0, 1]), f)]
+    rays = scenes.random_rays(2000, seed=3, extent=3.0, target_extent=0.6)
+    o, e = Oracle(sc), Emu(sc)
+    a, b = o.intersect(rays), e.intersect(rays)
+    _assert_its_equal(a, b)
+    hit0 = a["mesh"] != 0xFFFFFFFF
+    assert hit0.any() and set(np.unique(a["mesh"][hit0])) <= {1, 2}
+    assert (a["tri"][a["mesh"] == 1] == 1).all()
+
+
+def test_empty_scene():
+    from nori_amd.scene import Scene
+    sc = scenes.soup_scene(1)
+    sc.meshes = []
+    rays = scenes.random_rays(64)
+    assert (Emu(sc).intersect(rays)["mesh"] == 0xFFFFFFFF).all()
+    assert (Oracle(sc).intersect(rays)["mesh"] == 0xFFFFFFFF).all()
+
+
+@pytest.mark.parametrize("integ", ["normals", "ao", "simple", "whitted", "path_mats", "path_ems", "path_mis"])
+def test_li_bitwise(integ):
+    """Same seeds -> same radiance, bit for bit (both sides use glibc libm here)."""
+    sb = [Bsdf("mirror"), Bsdf("dielectric")] if integ in ("whitted", "path_mis") else \
+        [Bsdf("microfacet", (0.2, 0.3, 0.1), 0.2), Bsdf("diffuse")]
+    sc = scenes.cornell_box(16, 16, 1, integ, sphere_bsdfs=sb)
+    sc.integrator.position, sc.integrator.energy = (0, 1.5, 0.5), (30, 30, 30)
+    o, e = Oracle(sc, use_bvh=True), Emu(sc)
+    rng = np.random.default_rng(11)
+    ps = rng.uniform(0, 16, (4000, 2)).astype(np.float32)
+    rays = o.sample_rays(ps)
+    assert np.array_equal(rays, e.sample_rays(ps))
+    ss = rng.integers(0, 2 ** 62, 4000, dtype=np.uint64)
+    sq = rng.integers(0, 2 ** 62, 4000, dtype=np.uint64)
+    a, b = o.li(rays, ss, sq), e.li(rays, ss, sq)
+    assert np.array_equal(a, b)
+    assert np.isfinite(a).all() and a.max() > 0
+
+
+@pytest.mark.parametrize("integ,rf", [("path_mis", "gaussian"), ("path_ems", "mitchell"), ("whitted", "tent"), ("normals", "box")])
+def test_render_matches_oracle(integ, rf):
+    from nori_amd.scene import RFilter
+    sc = scenes.cornell_box(40, 24, 4, integ, rfilter=RFilter(rf))   # 40x24: ragged 16-px tiles and 32-px blocks
+    o, e = Oracle(sc, use_bvh=True), Emu(sc)
+    A, sa = o.render_host()
+    B, sb = e.render_host()
+    for k in ("n_camera_samples", "n_closest_rays", "n_shadow_rays", "n_invalid"):
+        assert sa[k] == sb[k], k
+    assert sa["n_camera_samples"] == 40 * 24 * 4
+    # identical per-sample weights and radiance; only the float summation order differs
+    np.testing.assert_allclose(B, A, rtol=2e-5, atol=1e-6)
+
+
+def test_render_tile_and_sample_split_sum_to_whole():
+    sc = scenes.cornell_box(40, 24, 6, "path_mis")
+    e = Emu(sc)
+    whole, _ = e.render_host()
+    parts = sum(e.render_host(tile_mod=3, tile_rem=r)[0] for r in range(3))
+    np.testing.assert_allclose(parts, whole, rtol=1e-5, atol=1e-6)
+    parts = e.render_host(spp_count=2, spp_begin=0)[0] + e.render_host(spp_count=4, spp_begin=2)[0]
+    np.testing.assert_allclose(parts, whole, rtol=1e-5, atol=1e-6)
+    o = Oracle(sc, use_bvh=True)
+    oparts = sum(o.render_host(tile_mod=3, tile_rem=r)[0] for r in range(3))
+    np.testing.assert_allclose(oparts, whole, rtol=2e-5, atol=1e-6)
+
+
+def test_bsdf_and_warp_twins_bitwise():
+    rng = np.random.default_rng(5)
+    n = 20000
+    s = rng.uniform(0, 1, (n, 2)).astype(np.float32)
+    for name, param in [("square", 0), ("tent", 0), ("disk", 0), ("uniform_sphere", 0), ("uniform_hemisphere", 0),
+                        ("cosine_hemisphere", 0), ("beckmann", 0.3)]:
+        a, b = Oracle.warp(name, s, param), Emu.warp(name, s, param)
+        assert np.array_equal(a, b), name
+        assert np.array_equal(Oracle.warp_pdf(name, a, param), Emu.warp_pdf(name, a, param)), name
+    wi = rng.normal(size=(n, 3)).astype(np.float32)
+    wi /= np.linalg.norm(wi, axis=1, keepdims=True)
+    wo = rng.normal(size=(n, 3)).astype(np.float32)
+    wo /= np.linalg.norm(wo, axis=1, keepdims=True)
+    for b in [Bsdf("diffuse", (0.2, 0.5, 0.7)), Bsdf("mirror"), Bsdf("dielectric"), Bsdf("dielectric", int_ior=1.33, ext_ior=1.0),
+              Bsdf("microfacet", (0.1, 0.2, 0.15), 0.1, 1.5), Bsdf("microfacet", (0.4, 0.2, 0.3), 0.6, 1.8, 1.3)]:
+        for x, y in zip(Oracle.bsdf_sample(b, wi, s), Emu.bsdf_sample(b, wi, s)):
+            assert np.array_equal(x, y, equal_nan=True), b
+        assert np.array_equal(Oracle.bsdf_eval(b, wi, wo), Emu.bsdf_eval(b, wi, wo), equal_nan=True)
+        assert np.array_equal(Oracle.bsdf_pdf(b, wi, wo), Emu.bsdf_pdf(b, wi, wo), equal_nan=True)
+    st = rng.integers(0, 2 ** 63, 100, dtype=np.uint64)
+    assert np.array_equal(Oracle.pcg32_floats(st, st[::-1].copy(), 64), Emu.pcg32_floats(st, st[::-1].copy(), 64))
