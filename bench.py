@@ -1,0 +1,177 @@
+#!/usr/bin/env python
+"""bench.py -- Mrays/s of the hot path (BVH traversal + Li path loop + tile splat).
+
+One "step" = one complete render pass of the workload (every pixel, every
+sample) through libnori_hip.  N GPUs (one process per GPU under
+torch.distributed.run) split the 16x16 tiles of the frame round-robin and rank 0
+receives the RCCL sum-reduce of the RGBW frame (ImageBlock::put(ImageBlock&)
+across GPUs).  Total work is fixed as N grows -> "scaling": "strong".
+
+Prints ONE JSON line on rank 0 (contract in the task statement) extended with
+`roofline` (dominant kernel: render_kernel) and `cpu_baseline` (the oracle,
+timed on the host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def load_workload(name: str, width: int, height: int, spp: int):
+    from nori_amd.scene import Scene
+    from tests import scenes
+    golden = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
+    if os.path.exists(golden):
+        sc = Scene.load_npz(golden)
+    elif name == "procedural-cornell":
+        sc = scenes.cornell_box(width, height, spp, "path_mis", sphere_subdiv=4)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    sc.camera.width, sc.camera.height, sc.sample_count = width, height, spp
+    return sc
+
+
+def algorithmic_bytes(stats: dict, info: dict, tile_w: int, n_workgroups: int, frame_px: int) -> float:
+    """per ray N_node*S_node + N_tri*S_tri; S_io = 0 (register-resident
+    megakernel); per closest hit the surface fetch (3 indices + 3 positions + 3 normals,
+    de-indexed as 16-B records); per workgroup one LDS-tile flush (read-modify-write
+    of (16+2b)^2 RGBW pixels)."""
+    b = stats["n_node_tests"] * info["node_bytes"] + stats["n_tri_tests"] * info["tri_bytes"]
+    b += stats["n_closest_rays"] * (12 + 48 + 48)
+    b += n_workgroups * 2 * 16 * tile_w * tile_w
+    return float(b)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("NORI_BENCH_WORKLOAD", "pa4-cbox-path_mis"))
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    if not os.path.exists(os.path.join(ROOT, "tests", "golden", f"{args.workload}.npz")):
+        args.workload = "procedural-cornell"
+    sc = load_workload(args.workload, args.width, args.height, args.spp)
+
+    from nori_amd.render import Renderer
+    r = Renderer(local_rank).upload(sc)
+    info = r.accel_info()
+    frame = torch.zeros(r.frame_shape(), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step(want_stats=False, count=False):
+        frame.zero_()
+        st = r.render_into(frame, tile_mod=world, tile_rem=rank, stream=stream, want_stats=want_stats,
+                           count_traversal=count)
+        if world > 1:
+            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
+        return st
+
+    # one instrumented pass: traversal counters for the roofline (untimed)
+    counted = step(want_stats=True, count=True)
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    last = None
+    for _ in range(args.steps):
+        last = step(want_stats=True)        # stats: HIP-event kernel time on the launch stream
+        kernel_ms.append(last["kernel_ms"])
+    barrier()
+    dt = time.perf_counter() - t0
+
+    rays_local = float(last["n_closest_rays"] + last["n_shadow_rays"])
+    t = torch.tensor([dt, rays_local], dtype=torch.float64, device=dev)
+    if world > 1:
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, rays_total = float(tmax[0]), float(tsum[1])
+    else:
+        rays_total = rays_local
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        mrays = rays_total / (ms_per_step * 1e-3) / 1e6
+        # roofline of the dominant kernel on this rank
+        tile_w = 16 + 2 * r.border
+        alg = algorithmic_bytes(counted, info, tile_w, last["n_workgroups"], args.width * args.height)
+        k_ms = float(np.mean(kernel_ms))
+        achieved = alg / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "Mrays/sec (primary+secondary) at 1024x1024 256spp",
+            "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.workload, "integrator": sc.integrator.type, "width": args.width,
+                       "height": args.height, "spp": args.spp, "triangles": info["n_triangles"],
+                       "parallelism": f"tile-split x{world} + RCCL reduce" if world > 1 else "single GPU",
+                       "rays_per_step": int(rays_total), "seed_mode": "per_sample"},
+            "roofline": {"bound": "hbm", "kernel": "render_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "kernel_ms": round(k_ms, 3), "algorithmic_bytes": int(alg),
+                         "workgroups": int(last["n_workgroups"]), "lds_bytes": int(last["lds_bytes"]),
+                         "node_tests": int(counted["n_node_tests"]), "tri_tests": int(counted["n_tri_tests"])},
+            "accel": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in info.items()},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(sc, args)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(sc, args):
+    """The oracle (kind 'port': CPU restatement with a SAH BVH) on all host cores,
+    on a bounded sample: the same frame at reduced spp, sized for ~cpu_seconds."""
+    from tests.backends import Oracle
+    o = Oracle(sc, use_bvh=True)
+    cores = os.cpu_count() or 1
+    _, st = o.render_host(spp_count=1, threads=cores)
+    per_spp = max(st["kernel_ms"] * 1e-3, 1e-3)
+    spp = int(max(1, min(args.spp, args.cpu_seconds / per_spp)))
+    _, st = o.render_host(spp_count=spp, threads=cores)
+    rays = st["n_closest_rays"] + st["n_shadow_rays"]
+    sec = st["kernel_ms"] * 1e-3
+    return {"value": round(rays / sec / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": f"{args.width}x{args.height} at {spp} spp of {args.spp} ({rays} rays in {sec:.1f} s, "
+                      f"std::thread x{cores}, SAH BVH, per-sample seeding)"}
+
+
+if __name__ == "__main__":
+    main()

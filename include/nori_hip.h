@@ -223,6 +223,9 @@ typedef struct nori_render_stats {
                                 src/block.cpp:63-67 */
     float kernel_ms;         /* HIP-event time of the render kernel on the
                                 stream it was launched on */
+    uint32_t n_workgroups;   /* launch geometry of the render kernel: one
+                                workgroup per (tile, spp chunk)              */
+    uint32_t lds_bytes;      /* dynamic LDS per workgroup                    */
 } nori_render_stats;
 
 typedef struct nori_accel_info {

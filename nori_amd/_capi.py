@@ -79,7 +79,7 @@ class RenderStats(C.Structure):
     _fields_ = [("n_camera_samples", C.c_uint64), ("n_closest_rays", C.c_uint64),
                 ("n_shadow_rays", C.c_uint64), ("n_node_tests", C.c_uint64),
                 ("n_tri_tests", C.c_uint64), ("n_invalid", C.c_uint64),
-                ("kernel_ms", C.c_float)]
+                ("kernel_ms", C.c_float), ("n_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -654,9 +654,14 @@ int nori_hip_splat(nori_hip_ctx *ctx, const float *positions, const float *value
 } // extern "C"
 
 /* ---------------------------------------------------------------- render */
+template <int STACK>
+static size_t render_lds_bytes(const RenderArgs &a) {
+    return sizeof(int) * STACK * kBlock + sizeof(float) * ((size_t) a.tile_w * a.tile_w * 4 + 48 + 8);
+}
+
 template <int INTEG, int STACK, bool COUNT>
 static hipError_t launch_render_one(nori_hip_ctx *ctx, const RenderArgs &a, float *d_rgbw, hipStream_t s) {
-    const size_t lds = sizeof(int) * STACK * kBlock + sizeof(float) * ((size_t) a.tile_w * a.tile_w * 4 + 48 + 8);
+    const size_t lds = render_lds_bytes<STACK>(a);
     auto kern = render_kernel<INTEG, STACK, COUNT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
@@ -734,6 +739,8 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         stats->n_camera_samples = h[0]; stats->n_closest_rays = h[1]; stats->n_shadow_rays = h[2];
         stats->n_node_tests = h[3]; stats->n_tri_tests = h[4]; stats->n_invalid = h[5];
         stats->kernel_ms = ms;
+        stats->n_workgroups = a.n_sel_tiles * a.n_chunks;
+        stats->lds_bytes = (uint32_t) (ctx->stack_depth <= 32 ? render_lds_bytes<32>(a) : render_lds_bytes<64>(a));
     }
     return NORI_OK;
 }
