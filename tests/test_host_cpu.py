@@ -1,0 +1,182 @@
+"""CPU-side checks of the C++ host (XML / OBJ / plugin parameters / EXR) and of
+the C-ABI library: it loads and exports every symbol include/*.h declares
+(no compute calls without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from nori_amd import NoriError, _capi, host
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/scenes"
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present (GPU box)")
+
+
+def _declared(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    return sorted(set(re.findall(r"\b(nori_(?:hip|host)_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_hip_library_exports_every_declared_symbol():
+    lib = _capi.load_hip()
+    names = _declared("nori_hip.h")
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(_capi.HIP_PROTOTYPES)
+
+
+def test_host_library_exports_every_declared_symbol():
+    lib = host.load_host()
+    names = _declared("nori_host.h")
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) == set(host.HOST_PROTOTYPES)
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nori_amd.render import Renderer
+    with pytest.raises(NoriError, match="NO_DEVICE"):
+        Renderer(0)
+
+
+def _write_scene(tmp_path, body, obj=True):
+    if obj:
+        (tmp_path / "tri.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 0 1\nvt 1 1\n"
+                                          "f 1/1/1 2/2/1 4/4/1 3/3/1\n")
+    p = tmp_path / "s.xml"
+    p.write_text(body)
+    return str(p)
+
+
+def test_parser_defaults_quads_transforms(tmp_path):
+    path = _write_scene(tmp_path, """<?xml version='1.0' encoding='utf-8'?>
+<!-- a comment -->
+<scene>
+  <integrator type="simple"><point name="position" value="1, 2, 3"/><color name="energy" value="4 5 6"/></integrator>
+  <camera type="perspective">
+    <transform name="toWorld"><scale value="-1,1,1"/><lookat target="0, 0, 1" origin="0, 0, 0" up="0, 1, 0"/></transform>
+  </camera>
+  <mesh type="obj"><string name="filename" value="tri.obj"/>
+    <transform name="toWorld"><scale value="2,2,2"/><translate value="1,0,0"/></transform></mesh>
+  <mesh type="obj"><string name="filename" value="tri.obj"/><bsdf type="microfacet"><color name="kd" value="0.1,0.2,0.3"/></bsdf>
+    <emitter type="area"><color name="radiance" value="1,2,3"/></emitter></mesh>
+</scene>""")
+    sc = host.load_xml(path)
+    # defaults: 1280x720, fov 30, gaussian r=2 sd=.5, independent 1 spp, diffuse 0.5 (perspective.cpp:24-36, mesh.cpp:23-29)
+    assert (sc.camera.width, sc.camera.height, sc.camera.fov) == (1280, 720, 30.0)
+    assert sc.rfilter.type == "gaussian" and sc.rfilter.radius == 2.0 and sc.sample_count == 1
+    assert sc.integrator.type == "simple" and sc.integrator.position == (1.0, 2.0, 3.0) and sc.integrator.energy == (4.0, 5.0, 6.0)
+    m0, m1 = sc.meshes
+    assert m0.bsdf.type == "diffuse" and m0.bsdf.albedo == (0.5, 0.5, 0.5) and m0.radiance is None
+    # quad -> 2 triangles (0,1,2) (3,0,2) over de-duplicated vertices (obj.cpp:63-91)
+    assert m0.indices.tolist() == [[0, 1, 2], [3, 0, 2]]
+    # toWorld = translate * scale (each op left-multiplies, parser.cpp:238-262)
+    np.testing.assert_allclose(m0.positions, [[1, 0, 0], [3, 0, 0], [3, 2, 0], [1, 2, 0]])
+    np.testing.assert_allclose(m0.normals, [[0, 0, 1]] * 4)
+    assert m0.texcoords.shape == (4, 2)
+    assert m1.bsdf.type == "microfacet" and m1.radiance == (1.0, 2.0, 3.0)
+    assert abs(m1.bsdf.ks - 0.7) < 1e-6 and m1.bsdf.alpha == pytest.approx(0.1)
+    # lookat then scale(-1,1,1): left = up x dir = (1,0,0) -> mirrored
+    np.testing.assert_allclose(sc.camera.to_world, np.diag([-1, 1, 1, 1]), atol=1e-7)
+
+
+@pytest.mark.parametrize("body,msg", [
+    ("<scene><integrator type='normals'/></scene>", "No camera was specified"),
+    ("<scene><camera type='perspective'/></scene>", "No integrator was specified"),
+    ("<scene><integrator type='nope'/></scene>", "could not be found"),
+    ("<scene><integrator type='normals' foo='1'/></scene>", "unexpected attribute"),
+    ("<scene><float name='x'/></scene>", "missing attribute"),
+    ("<scene><bogus/></scene>", "unexpected tag"),
+    ("<float name='x' value='1'/>", "must be a Nori object"),
+    ("<scene><translate value='1,1,1'/></scene>", "transform nodes can only contain"),
+    ("<scene><integrator type='diffuse'/></scene>", "Unexpectedly constructed an object"),
+    ("<scene><integrator type='normals'><float name='a' value='1x'/></integrator></scene>", "Could not parse floating point"),
+    ("<scene><integrator type='simple'/></scene>", "Property 'position' is missing"),
+    ("<scene><integrator type='simple'><float name='position' value='1'/></integrator></scene>", "wrong type"),
+    ("<scene><mesh type='obj'><string name='filename' value='missing.obj'/></mesh></scene>", "Unable to open OBJ file"),
+    ("<scene><integrator type='normals'/><integrator type='ao'/></scene>", "only be one integrator"),
+    ("<scene><mesh type='obj'><string name='filename' value='tri.obj'/><bsdf type='diffuse'/><bsdf type='mirror'/></mesh></scene>", "multiple BSDF"),
+    ("<scene><integrator type='normals'></scene>", "closing tag"),
+])
+def test_parser_errors(tmp_path, body, msg):
+    path = _write_scene(tmp_path, body)
+    with pytest.raises(NoriError, match=msg):
+        host.load_xml(path)
+
+
+def test_exr_png_roundtrip(tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 4, (17, 23, 3)).astype(np.float32)
+    host.save_images(str(tmp_path / "a"), img)
+    back = host.load_exr(str(tmp_path / "a.exr"))
+    assert np.array_equal(back, img)
+    raw = open(tmp_path / "a.exr", "rb").read()
+    assert raw[:4] == b"\x76\x2f\x31\x01" and b"Generated by Nori" in raw
+    png = open(tmp_path / "a.png", "rb").read()
+    assert png[:8] == b"\x89PNG\r\n\x1a\n"
+    # decode the PNG (zlib) and check the sRGB curve of common.cpp:166-180
+    import struct, zlib
+    pos, idat = 8, b""
+    while pos < len(png):
+        ln, tp = struct.unpack(">I4s", png[pos:pos + 8])
+        if tp == b"IDAT":
+            idat += png[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+    px = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(17, 1 + 23 * 3)[:, 1:].reshape(17, 23, 3)
+    v = img.astype(np.float64)
+    srgb = np.where(v <= 0.0031308, 12.92 * v, 1.055 * v ** (1 / 2.4) - 0.055)
+    assert np.abs(px.astype(int) - np.clip(255 * srgb, 0, 255).astype(int)).max() <= 1
+
+
+@needs_ref
+def test_shipped_scenes_load_unchanged():
+    import glob
+    ok = 0
+    for f in sorted(glob.glob(REF + "/**/*.xml", recursive=True)):
+        if "ajax" in f:       # ajax.obj is not shipped with the reference
+            with pytest.raises(NoriError, match="Unable to open OBJ file"):
+                host.HostRoot(f)
+            continue
+        r = host.HostRoot(f)
+        assert r.class_type in (0, 9)
+        (r.scene() if r.class_type == 0 else r.test())
+        r.close()
+        ok += 1
+    assert ok >= 19
+
+
+@needs_ref
+def test_golden_fixtures_are_current():
+    """tests/golden/*.npz equal what the host produces from the reference files now."""
+    from nori_amd.scene import Scene
+    sc = host.load_xml(REF + "/pa5/cbox/cbox_mis.xml")
+    g = Scene.load_npz(os.path.join(ROOT, "tests", "golden", "pa5-cbox_mis.npz"))
+    assert len(sc.meshes) == len(g.meshes) == 6
+    for a, b in zip(sc.meshes, g.meshes):
+        assert np.array_equal(a.positions, b.positions) and np.array_equal(a.indices, b.indices)
+        assert a.bsdf.type == b.bsdf.type and a.radiance == b.radiance
+    assert np.array_equal(sc.camera.to_world, g.camera.to_world) and sc.sample_count == g.sample_count == 256
+
+
+def test_statistics_match_scipy():
+    """nori/hypothesis.h CDFs (C++) vs scipy, via a tiny compiled probe."""
+    import subprocess, tempfile
+    from scipy import stats
+    src = r'''#include <nori/hypothesis.h>
+#include <cstdio>
+int main(){ for (double t : {-3.0,-0.5,0.0,1.2,4.0}) for (int d : {3,30,99999}) printf("%.12g\n", hypothesis::students_t_cdf(t,d));
+for (double x : {0.5,5.0,50.0,300.0}) for (int d : {1,10,199}) printf("%.12g\n", hypothesis::chi2_cdf(x,d)); }'''
+    with tempfile.TemporaryDirectory() as td:
+        open(td + "/p.cpp", "w").write(src)
+        subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "nori_amd/csrc/host"), td + "/p.cpp", "-o", td + "/p"], check=True)
+        got = [float(x) for x in subprocess.run([td + "/p"], capture_output=True, text=True, check=True).stdout.split()]
+    want = [stats.t.cdf(t, d) for t in (-3.0, -0.5, 0.0, 1.2, 4.0) for d in (3, 30, 99999)]
+    want += [stats.chi2.cdf(x, d) for x in (0.5, 5.0, 50.0, 300.0) for d in (1, 10, 199)]
+    np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-12)
