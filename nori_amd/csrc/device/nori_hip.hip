@@ -55,6 +55,9 @@ struct LdsStack {
 };
 
 constexpr int kBlock = 256;
+#ifndef NORI_RENDER_MIN_WAVES
+#define NORI_RENDER_MIN_WAVES 4   /* waves per SIMD the render kernel is register-budgeted for */
+#endif
 
 /* ----------------------------------------------------------- render kernel */
 struct RenderArgs {
@@ -65,6 +68,7 @@ struct RenderArgs {
     uint32_t n_chunks;          /* spp chunks per tile                     */
     uint32_t chunk_spp;
     int32_t tile_w;             /* kTile + 2 * border                      */
+    uint32_t th_shade, th_inner, th_leaf;   /* lanes of a wave that must want a kind of work for it to run */
 };
 
 struct LdsAdd {
@@ -72,7 +76,7 @@ struct LdsAdd {
 };
 
 template <int INTEG, int STACK, bool COUNT>
-__global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, RenderArgs args, const float *__restrict__ filter_table,
+__global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(DevScene sc, RenderArgs args, const float *__restrict__ filter_table,
                                                         float *rgbw, unsigned long long *stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *lds_stack = reinterpret_cast<int *>(smem);
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, RenderArgs 
     const int tid = threadIdx.x;
     for (int i = tid; i < tile_floats; i += kBlock) tile[i] = 0.0f;
     if (tid <= kFilterRes) ftab[tid] = filter_table[tid];
-    if (tid < 8) cnt[tid] = 0u;
+    if (tid < 16) cnt[tid] = 0u;
     __syncthreads();
 
     /* which tile / which samples */
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, RenderArgs 
 
     PathState st;
     st.phase = PH_NEW;
+    st.ray.o = st.ray.d = mk3(0.0f); st.ray.mint = st.ray.maxt = 0.0f;
     f2 pixelSample = mk2(0.0f, 0.0f);
     uint32_t s = s0;
     uint32_t nCam = 0, nClosest = 0, nShadow = 0, nInvalid = 0;
@@ -113,32 +118,69 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, RenderArgs 
     const float radius = sc.filter.radius, lookup = sc.filter.lookup_factor;
     const int border = sc.filter.border;
 
-    if (live) {
-        while (true) {
-            if (st.phase == PH_NEW) {
-                if (s >= s1) break;
-                /* renderBlock, src/main.cpp:41-46: jitter, aperture draw, sampleRay */
-                rng_seed(st.rng, (uint64_t) py * (uint64_t) sc.camera.width + (uint64_t) px, (uint64_t) s);
-                const f2 j = rng_next_2d(st.rng);
-                pixelSample = mk2((float) px + j.x, (float) py + j.y);
-                (void) rng_next_2d(st.rng);            /* apertureSample: drawn, unused (perspective.cpp:78) */
-                RayIn cam;
-                camera_sample_ray(sc.camera, pixelSample, cam);
-                path_begin(st, cam);
-                ++s; ++nCam;
+    /* Persistent loop.  At any time a lane wants exactly one of three kinds of
+       work: SHADE (its query finished: consume the result, splat, regenerate a
+       camera sample, start the next query), INNER (test a BVH node) or LEAF (test
+       one triangle).  Each trip the wave votes (__ballot) and runs a kind only
+       if enough lanes want it -- thresholds from RenderArgs -- so that no block
+       of code executes for a handful of the 64 lanes; if no kind reaches its
+       threshold the most wanted one runs, which guarantees progress. */
+    Trav tv;
+    tv.active = false; tv.node = 0;
+    bool finished = !live;
+    const int thS = (int) args.th_shade, thI = (int) args.th_inner, thL = (int) args.th_leaf;
+    while (true) {
+        const bool wantS = !tv.active && !finished;
+        const bool wantI = tv.active && tv.node >= 0;
+        const bool wantL = tv.active && tv.node < 0;
+        const int cS = __popcll(__ballot(wantS)), cI = __popcll(__ballot(wantI)), cL = __popcll(__ballot(wantL));
+        if ((cS | cI | cL) == 0) break;
+        bool runS = cS >= thS, runI = cI >= thI, runL = cL >= thL;
+        if (!(runS | runI | runL)) {
+            runS = cS >= cI && cS >= cL;
+            runI = !runS && cI >= cL;
+            runL = !runS && !runI;
+        }
+        if (COUNT && lane == 0) {       /* scheduler census: wave-level runs and participating lanes per kind */
+            if (runS) { atomicAdd(&cnt[8], 1u); atomicAdd(&cnt[9], (unsigned) cS); }
+            if (runI) { atomicAdd(&cnt[10], 1u); atomicAdd(&cnt[11], (unsigned) cI); }
+            if (runL) { atomicAdd(&cnt[12], 1u); atomicAdd(&cnt[13], (unsigned) cL); }
+        }
+        if (runS && wantS) {
+            bool gen = st.phase == PH_NEW;
+            if (!gen) {
+                bool done;
+                if (st.phase == PH_SHADOW) done = path_on_shadow(st, tv.hit.tri != kNoHit, tv.o);
+                else done = path_on_closest<INTEG>(sc, st, tv.hit, tv.hit.tri != kNoHit, tv.d);
+                if (done) {
+                    if (color_valid(st.L)) splat_tile(tile, tile_w, x0, y0, ftab, radius, lookup, border, pixelSample, st.L, LdsAdd());
+                    else ++nInvalid;
+                    gen = true;
+                }
             }
-            const bool any = st.phase == PH_SHADOW;
-            Hit hit;
-            const bool found = traverse<COUNT>(sc, st.ray, any, stack, hit, tc);
-            bool done;
-            if (any) { ++nShadow; done = path_on_shadow(st, found); }
-            else { ++nClosest; done = path_on_closest<INTEG>(sc, st, hit, found); }
-            if (done) {
-                if (color_valid(st.L)) splat_tile(tile, tile_w, x0, y0, ftab, radius, lookup, border, pixelSample, st.L, LdsAdd());
-                else ++nInvalid;
-                st.phase = PH_NEW;
+            if (gen) {
+                if (s >= s1) {
+                    finished = true;
+                } else {
+                    /* renderBlock, src/main.cpp:41-46: jitter, aperture draw, sampleRay */
+                    rng_seed(st.rng, (uint64_t) py * (uint64_t) sc.camera.width + (uint64_t) px, (uint64_t) s);
+                    const f2 j = rng_next_2d(st.rng);
+                    pixelSample = mk2((float) px + j.x, (float) py + j.y);
+                    (void) rng_next_2d(st.rng);        /* apertureSample: drawn, unused (perspective.cpp:78) */
+                    RayIn cam;
+                    camera_sample_ray(sc.camera, pixelSample, cam);
+                    path_begin(st, cam);
+                    ++s; ++nCam;
+                }
+            }
+            if (!finished) {
+                const bool any = st.phase == PH_SHADOW;
+                if (any) ++nShadow; else ++nClosest;
+                trav_begin(sc, st.ray, any, stack, tv);
             }
         }
+        if (runI && tv.active && tv.node >= 0) trav_inner_step<COUNT>(sc, stack, tv, tc);
+        if (runL && tv.active && tv.node < 0) trav_leaf_step<COUNT>(sc, stack, tv, tc);
     }
 
     atomicAdd(&cnt[0], nCam); atomicAdd(&cnt[1], nClosest); atomicAdd(&cnt[2], nShadow);
@@ -158,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void render_kernel(DevScene sc, RenderArgs 
         unsafeAtomicAdd(dst + 0, p[0]); unsafeAtomicAdd(dst + 1, p[1]);
         unsafeAtomicAdd(dst + 2, p[2]); unsafeAtomicAdd(dst + 3, p[3]);
     }
-    if (tid < 6 && cnt[tid] != 0u) atomicAdd(&stats[tid], (unsigned long long) cnt[tid]);
+    if (tid < 16 && cnt[tid] != 0u) atomicAdd(&stats[tid], (unsigned long long) cnt[tid]);
 }
 
 /* ------------------------------------------------------- batch operators */
@@ -214,8 +256,9 @@ __global__ __launch_bounds__(kBlock) void li_kernel(DevScene sc, const nori_ray 
         while (true) {
             const bool any = st.phase == PH_SHADOW;
             Hit hit;
+            const f3 qo = st.ray.o, qd = st.ray.d;
             const bool found = traverse<false>(sc, st.ray, any, stack, hit, tc);
-            const bool done = any ? path_on_shadow(st, found) : path_on_closest<INTEG>(sc, st, hit, found);
+            const bool done = any ? path_on_shadow(st, found, qo) : path_on_closest<INTEG>(sc, st, hit, found, qd);
             if (done) break;
         }
         rgb[3 * i] = st.L.x; rgb[3 * i + 1] = st.L.y; rgb[3 * i + 2] = st.L.z;
@@ -368,7 +411,7 @@ int nori_hip_create(int device, nori_hip_ctx **out) {
     memset(&ctx->dev, 0, sizeof(ctx->dev));
     memset(&ctx->info, 0, sizeof(ctx->info));
     DeviceGuard g(device);
-    e = hipMalloc((void **) &ctx->d_stats, 8 * sizeof(unsigned long long));
+    e = hipMalloc((void **) &ctx->d_stats, 16 * sizeof(unsigned long long));
     if (e != hipSuccess) { g_create_error = std::string("hipMalloc: ") + hipGetErrorString(e); delete ctx; return NORI_ERR_NO_DEVICE; }
     *out = ctx;
     return NORI_OK;
@@ -656,7 +699,7 @@ int nori_hip_splat(nori_hip_ctx *ctx, const float *positions, const float *value
 /* ---------------------------------------------------------------- render */
 template <int STACK>
 static size_t render_lds_bytes(const RenderArgs &a) {
-    return sizeof(int) * STACK * kBlock + sizeof(float) * ((size_t) a.tile_w * a.tile_w * 4 + 48 + 8);
+    return sizeof(int) * STACK * kBlock + sizeof(float) * ((size_t) a.tile_w * a.tile_w * 4 + 48 + 16);
 }
 
 template <int INTEG, int STACK, bool COUNT>
@@ -704,6 +747,10 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
     const uint32_t n_tiles = a.tiles_x * a.tiles_y;
     a.n_sel_tiles = n_tiles > a.tile_rem ? (n_tiles - a.tile_rem + a.tile_mod - 1) / a.tile_mod : 0;
     a.tile_w = kTile + 2 * ctx->host.filter.border;
+    a.th_shade = 44; a.th_inner = 1; a.th_leaf = 1;
+    if (const char *e = getenv("NORI_HIP_TH_SHADE")) a.th_shade = (uint32_t) std::min(64, std::max(1, atoi(e)));
+    if (const char *e = getenv("NORI_HIP_TH_INNER")) a.th_inner = (uint32_t) std::min(64, std::max(1, atoi(e)));
+    if (const char *e = getenv("NORI_HIP_TH_LEAF")) a.th_leaf = (uint32_t) std::min(64, std::max(1, atoi(e)));
     /* spp chunking: aim for >= ~8 workgroups per CU slot-round, >= 8 spp per chunk */
     uint32_t target_wgs = 8192;
     if (const char *e = getenv("NORI_HIP_TARGET_WGS")) target_wgs = (uint32_t) std::max(1, atoi(e));
@@ -716,14 +763,18 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) {
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 8 * sizeof(unsigned long long), s));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 16 * sizeof(unsigned long long), s));
         HIP_TRY(ctx, hipEventCreate(&ev0)); HIP_TRY(ctx, hipEventCreate(&ev1));
         HIP_TRY(ctx, hipEventRecord(ev0, s));
     }
     if (a.n_sel_tiles > 0 && a.spp_count > 0) {
         hipError_t e;
         const bool count = params->count_traversal != 0;
-        if (ctx->stack_depth <= 32) e = count ? launch_render<32, true>(ctx, a, (float *) d_rgbw, s) : launch_render<32, false>(ctx, a, (float *) d_rgbw, s);
+        const uint32_t need = ctx->bvh.max_depth + 1;
+        /* the LDS stack is sized to the tree: fewer entries -> more workgroups per CU */
+        if (need <= 16) e = count ? launch_render<16, true>(ctx, a, (float *) d_rgbw, s) : launch_render<16, false>(ctx, a, (float *) d_rgbw, s);
+        else if (need <= 24) e = count ? launch_render<24, true>(ctx, a, (float *) d_rgbw, s) : launch_render<24, false>(ctx, a, (float *) d_rgbw, s);
+        else if (need <= 32) e = count ? launch_render<32, true>(ctx, a, (float *) d_rgbw, s) : launch_render<32, false>(ctx, a, (float *) d_rgbw, s);
         else e = count ? launch_render<64, true>(ctx, a, (float *) d_rgbw, s) : launch_render<64, false>(ctx, a, (float *) d_rgbw, s);
         HIP_TRY(ctx, e);
     }
@@ -733,14 +784,17 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         float ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev0, ev1));
         (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1);
-        unsigned long long h[8];
+        unsigned long long h[16];
         HIP_TRY(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
         memset(stats, 0, sizeof(*stats));
         stats->n_camera_samples = h[0]; stats->n_closest_rays = h[1]; stats->n_shadow_rays = h[2];
         stats->n_node_tests = h[3]; stats->n_tri_tests = h[4]; stats->n_invalid = h[5];
         stats->kernel_ms = ms;
+        if (getenv("NORI_HIP_CENSUS") && h[8])
+            fprintf(stderr, "[census] shade runs %llu lanes %.1f | inner runs %llu lanes %.1f | leaf runs %llu lanes %.1f\n", h[8], (double) h[9] / h[8], h[10], (double) h[11] / std::max(1ull, h[10]), h[12], (double) h[13] / std::max(1ull, h[12]));
         stats->n_workgroups = a.n_sel_tiles * a.n_chunks;
-        stats->lds_bytes = (uint32_t) (ctx->stack_depth <= 32 ? render_lds_bytes<32>(a) : render_lds_bytes<64>(a));
+        const uint32_t need = ctx->bvh.max_depth + 1;
+        stats->lds_bytes = (uint32_t) (need <= 16 ? render_lds_bytes<16>(a) : need <= 24 ? render_lds_bytes<24>(a) : need <= 32 ? render_lds_bytes<32>(a) : render_lds_bytes<64>(a));
     }
     return NORI_OK;
 }

@@ -115,12 +115,11 @@ NORI_HD bool sample_direct(const DevScene &sc, Rng &rng, const Surface &s, const
  * complete (st.L is the radiance estimate); otherwise st.ray / st.phase name
  * the next query. */
 template <int INTEG>
-NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, bool found) {
+NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, bool found, const f3 d) {
     if (!found) return true;
     Surface sf;
     surface_fill(sc, hit, sf, nullptr, nullptr);
     const MeshRec &m = sc.meshes[hit.mesh];
-    const f3 d = st.ray.d;
 
     if (INTEG == INT_NORMALS) {
         st.L = mk3(fabsf(sf.ns.x), fabsf(sf.ns.y), fabsf(sf.ns.z));
@@ -235,11 +234,12 @@ NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, 
     return false;
 }
 
-/* Consume the result of a shadow query. */
-NORI_HD bool path_on_shadow(PathState &st, bool occluded) {
+/* Consume the result of a shadow query (`o` = origin of the shadow ray, which
+ * is also the origin of the continuation). */
+NORI_HD bool path_on_shadow(PathState &st, bool occluded, const f3 o) {
     if (!occluded) st.L = st.L + st.Ld;
     if (st.end_after_shadow) return true;
-    st.ray.d = st.cont_d; st.ray.mint = kEpsilon; st.ray.maxt = kInf;
+    st.ray.o = o; st.ray.d = st.cont_d; st.ray.mint = kEpsilon; st.ray.maxt = kInf;
     st.phase = PH_CLOSEST;
     return false;
 }

@@ -56,68 +56,117 @@ NORI_HD void slab_pair(float bmin, float bmax, float o, float rcp, float &tnear,
     tfar = fminf(tfar, fmaxf(t1, t2));
 }
 
-/* Closest-hit (any = false) or any-hit / shadow (any = true) traversal; `any`
- * is a run-time flag so that lanes tracing shadow rays and lanes tracing
- * closest-hit rays share one instruction stream.
+/* Traversal state of one ray, advanced ONE step at a time so that a kernel can
+ * interleave traversal with other work (regenerating finished lanes) instead of
+ * letting 63 lanes wait for the longest walk of the wave.
+ *   node >= 0           : next step tests an inner node
+ *   node <  0, tri_cur < tri_end : next step tests ONE leaf triangle
+ *   active == false     : traversal finished; `hit` is the answer
+ * Closest-hit (any = false) or any-hit / shadow (any = true); `any` is run-time
+ * state so both kinds of query share one instruction stream. */
+struct Trav {
+    f3 o, d, rcp;
+    float mint, best_t;
+    int node;
+    uint32_t tri_cur, tri_end;
+    Hit hit;
+    bool any, active;
+};
+
+template <class Stack>
+NORI_HD void trav_begin(const DevScene &sc, const RayIn &ray, bool any, Stack &stack, Trav &tv) {
+    tv.o = ray.o; tv.d = ray.d;
+    tv.rcp = mk3(slab_rcp(ray.d.x), slab_rcp(ray.d.y), slab_rcp(ray.d.z));
+    tv.mint = ray.mint; tv.best_t = ray.maxt;
+    tv.hit.tri = kNoHit; tv.hit.mesh = kNoHit; tv.hit.t = ray.maxt; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
+    tv.any = any;
+    tv.tri_cur = tv.tri_end = 0;
+    stack.reset();
+    tv.active = sc.n_triangles != 0;
+    tv.node = sc.root;
+    if (tv.active && tv.node < 0) {          /* the whole scene is one leaf */
+        const uint32_t code = ~(uint32_t) tv.node;
+        tv.tri_cur = code >> 3; tv.tri_end = tv.tri_cur + (code & 7u) + 1u;
+    }
+}
+
+/* pop the next subtree or finish */
+template <class Stack>
+NORI_HD void trav_pop(Stack &stack, Trav &tv) {
+    if (stack.empty()) { tv.active = false; return; }
+    tv.node = stack.pop();
+    if (tv.node < 0) {
+        const uint32_t code = ~(uint32_t) tv.node;
+        tv.tri_cur = code >> 3; tv.tri_end = tv.tri_cur + (code & 7u) + 1u;
+    }
+}
+
+/* one inner-node step: both child boxes from one 64-B record */
+template <bool COUNT, class Stack>
+NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt) {
+    const f4 *nq = sc.nodes + (size_t) tv.node * kNodeQuads;
+    const f4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+    if (COUNT) cnt.nodes++;
+    float nl = -kInf, fl = kInf, nr = -kInf, fr = kInf;
+    slab_pair(q0.x, q0.w, tv.o.x, tv.rcp.x, nl, fl);
+    slab_pair(q0.y, q1.x, tv.o.y, tv.rcp.y, nl, fl);
+    slab_pair(q0.z, q1.y, tv.o.z, tv.rcp.z, nl, fl);
+    slab_pair(q1.z, q2.y, tv.o.x, tv.rcp.x, nr, fr);
+    slab_pair(q1.w, q2.z, tv.o.y, tv.rcp.y, nr, fr);
+    slab_pair(q2.x, q2.w, tv.o.z, tv.rcp.z, nr, fr);
+    fl *= 1.0000004f; fr *= 1.0000004f;
+    const bool hl = (nl <= fl) && (fl >= tv.mint) && (nl <= tv.best_t);
+    const bool hr = (nr <= fr) && (fr >= tv.mint) && (nr <= tv.best_t);
+    const int cl = (int) f2u(q3.x), cr = (int) f2u(q3.y);
+    if (hl && hr) {
+        const bool leftFirst = nl <= nr;
+        stack.push(leftFirst ? cr : cl);
+        tv.node = leftFirst ? cl : cr;
+    } else if (hl) {
+        tv.node = cl;
+    } else if (hr) {
+        tv.node = cr;
+    } else {
+        trav_pop(stack, tv);
+        return;
+    }
+    if (tv.node < 0) {
+        const uint32_t code = ~(uint32_t) tv.node;
+        tv.tri_cur = code >> 3; tv.tri_end = tv.tri_cur + (code & 7u) + 1u;
+    }
+}
+
+/* one leaf step: ONE triangle (mesh.cpp:39-76), then advance within the leaf */
+template <bool COUNT, class Stack>
+NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt) {
+    const f4 *tq = sc.tris + (size_t) tv.tri_cur * kTriQuads;
+    const f4 a = tq[0], b = tq[1], c = tq[2];
+    if (COUNT) cnt.tris++;
+    float u, v, t;
+    if (tri_test(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tv.o, tv.d, u, v, t) &&
+        t >= tv.mint && t <= tv.best_t) {
+        const uint32_t gid = f2u(c.y);
+        if (tv.any) { tv.hit.tri = gid; tv.hit.t = t; tv.active = false; return; }
+        /* tie rule of the linear scan: a later triangle with equal t replaces an earlier one */
+        if (!(t == tv.best_t && tv.hit.tri != kNoHit && gid < tv.hit.tri)) {
+            tv.best_t = t;
+            tv.hit.t = t; tv.hit.u = u; tv.hit.v = v; tv.hit.tri = gid; tv.hit.mesh = f2u(c.z);
+        }
+    }
+    if (++tv.tri_cur >= tv.tri_end) trav_pop(stack, tv);
+}
+
+/* Run a traversal to completion (batch kernels, tests).
  * Returns true if something was hit; for closest-hit `hit` holds t,u,v,tri,mesh. */
 template <bool COUNT, class Stack>
 NORI_HD bool traverse(const DevScene &sc, const RayIn &ray, bool any, Stack &stack, Hit &hit, TraversalCounters &cnt) {
-    const f3 o = ray.o, d = ray.d;
-    const f3 rcp = mk3(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
-    const float mint = ray.mint;
-    float best_t = ray.maxt;
-    hit.tri = kNoHit; hit.mesh = kNoHit; hit.t = ray.maxt; hit.u = 0.0f; hit.v = 0.0f;
-
-    int node = sc.root;
-    stack.reset();
-    if (sc.n_triangles == 0) return false;
-    while (true) {
-        if (node >= 0) {
-            const f4 *nq = sc.nodes + (size_t) node * kNodeQuads;
-            const f4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
-            if (COUNT) cnt.nodes++;
-            float nl = -kInf, fl = kInf, nr = -kInf, fr = kInf;
-            slab_pair(q0.x, q0.w, o.x, rcp.x, nl, fl);
-            slab_pair(q0.y, q1.x, o.y, rcp.y, nl, fl);
-            slab_pair(q0.z, q1.y, o.z, rcp.z, nl, fl);
-            slab_pair(q1.z, q2.y, o.x, rcp.x, nr, fr);
-            slab_pair(q1.w, q2.z, o.y, rcp.y, nr, fr);
-            slab_pair(q2.x, q2.w, o.z, rcp.z, nr, fr);
-            fl *= 1.0000004f; fr *= 1.0000004f;
-            const bool hl = (nl <= fl) && (fl >= mint) && (nl <= best_t);
-            const bool hr = (nr <= fr) && (fr >= mint) && (nr <= best_t);
-            const int cl = (int) f2u(q3.x), cr = (int) f2u(q3.y);
-            if (hl && hr) {
-                const bool leftFirst = nl <= nr;
-                stack.push(leftFirst ? cr : cl);
-                node = leftFirst ? cl : cr;
-                continue;
-            } else if (hl) {
-                node = cl; continue;
-            } else if (hr) {
-                node = cr; continue;
-            }
-        } else {
-            const uint32_t code = ~(uint32_t) node;
-            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
-            for (uint32_t i = 0; i < count; ++i) {
-                const f4 *tq = sc.tris + (size_t) (first + i) * kTriQuads;
-                const f4 a = tq[0], b = tq[1], c = tq[2];
-                if (COUNT) cnt.tris++;
-                float u, v, t;
-                if (!tri_test(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), o, d, u, v, t))
-                    continue;
-                if (!(t >= mint && t <= best_t)) continue;
-                const uint32_t gid = f2u(c.y);
-                if (any) { hit.tri = gid; hit.t = t; return true; }
-                if (t == best_t && hit.tri != kNoHit && gid < hit.tri) continue;
-                best_t = t;
-                hit.t = t; hit.u = u; hit.v = v; hit.tri = gid; hit.mesh = f2u(c.z);
-            }
-        }
-        if (stack.empty()) break;
-        node = stack.pop();
+    Trav tv;
+    trav_begin(sc, ray, any, stack, tv);
+    while (tv.active) {
+        if (tv.node >= 0) trav_inner_step<COUNT>(sc, stack, tv, cnt);
+        else trav_leaf_step<COUNT>(sc, stack, tv, cnt);
     }
+    hit = tv.hit;
     return hit.tri != kNoHit;
 }
 

@@ -61,10 +61,11 @@ static f3 run_path(const DevScene &sc, PathState &st, ArrayStack &stack, uint64_
     while (true) {
         const bool any = st.phase == PH_SHADOW;
         Hit hit;
+        const f3 qo = st.ray.o, qd = st.ray.d;
         const bool found = traverse<true>(sc, st.ray, any, stack, hit, tc);
         bool done;
-        if (any) { ++nShadow; done = path_on_shadow(st, found); }
-        else { ++nClosest; done = path_on_closest<INTEG>(sc, st, hit, found); }
+        if (any) { ++nShadow; done = path_on_shadow(st, found, qo); }
+        else { ++nClosest; done = path_on_closest<INTEG>(sc, st, hit, found, qd); }
         if (done) break;
     }
     return st.L;
