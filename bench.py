@@ -93,13 +93,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    from nori_amd import dist as ndist
+
     def step(want_stats=False, count=False):
-        frame.zero_()
-        st = r.render_into(frame, tile_mod=world, tile_rem=rank, stream=stream, want_stats=want_stats,
-                           count_traversal=count)
-        if world > 1:
-            dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)
-        return st
+        # tile split over ranks + one RCCL SUM-reduce of the RGBW frame to rank 0
+        return ndist.render_distributed(r.render_into, frame, "tile", args.spp, rank, world, stream=stream,
+                                        want_stats=want_stats, count_traversal=count)
 
     # one instrumented pass: traversal counters for the roofline (untimed)
     counted = step(want_stats=True, count=True)
@@ -142,7 +141,8 @@ def main():
                        "parallelism": f"tile-split x{world} + RCCL reduce" if world > 1 else "single GPU",
                        "rays_per_step": int(rays_total), "seed_mode": "per_sample"},
             "roofline": {"bound": "hbm", "kernel": "render_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": measured_traffic(args, sc),
                          "kernel_ms": round(k_ms, 3), "algorithmic_bytes": int(alg),
                          "workgroups": int(last["n_workgroups"]), "lds_bytes": int(last["lds_bytes"]),
                          "node_tests": int(counted["n_node_tests"]), "tri_tests": int(counted["n_tri_tests"])},
@@ -156,12 +156,25 @@ def main():
         dist.destroy_process_group()
 
 
+def measured_traffic(args, sc):
+    """HBM bytes per launch of render_kernel from the PMC passes (FETCH_SIZE, WRITE_SIZE; separate
+    rocprofv3 --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  PMC counters cannot be read
+    from inside this process, so the figure comes from the committed summary of a profiled run of this
+    same command (profiles/*_traffic.json); null if there is none for this workload."""
+    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if not os.path.exists(path):
+        return None
+    t = json.load(open(path))
+    key = f"{args.workload}:{args.width}x{args.height}:{args.spp}"
+    return t.get(key, {}).get("hbm_bytes_per_launch")
+
+
 def cpu_baseline(sc, args):
     """The oracle (kind 'port': CPU restatement with a SAH BVH) on all host cores,
     on a bounded sample: the same frame at reduced spp, sized for ~cpu_seconds."""
     from tests.backends import Oracle
     o = Oracle(sc, use_bvh=True)
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     _, st = o.render_host(spp_count=1, threads=cores)
     per_spp = max(st["kernel_ms"] * 1e-3, 1e-3)
     spp = int(max(1, min(args.spp, args.cpu_seconds / per_spp)))

@@ -752,7 +752,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
     if (const char *e = getenv("NORI_HIP_TH_INNER")) a.th_inner = (uint32_t) std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NORI_HIP_TH_LEAF")) a.th_leaf = (uint32_t) std::min(64, std::max(1, atoi(e)));
     /* spp chunking: aim for >= ~8 workgroups per CU slot-round, >= 8 spp per chunk */
-    uint32_t target_wgs = 8192;
+    uint32_t target_wgs = 16384;
     if (const char *e = getenv("NORI_HIP_TARGET_WGS")) target_wgs = (uint32_t) std::max(1, atoi(e));
     uint32_t n_chunks = 1;
     if (a.n_sel_tiles > 0 && a.n_sel_tiles < target_wgs) n_chunks = (target_wgs + a.n_sel_tiles - 1) / a.n_sel_tiles;

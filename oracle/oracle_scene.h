@@ -491,8 +491,13 @@ inline bool Accel::rayIntersect(const Ray &ray_, Intersection &its, bool shadowR
                     }
                 }
             } else {
-                stack[sp++] = nd.left;
-                stack[sp++] = nd.right;
+                /* visit the nearer child first (bbox.h:353-380 gives the entry
+                   distances); order changes speed only, never the answer */
+                float nl, fl, nr, fr;
+                bool hl = nodes[nd.left].box.rayIntersect(ray, nl, fl);
+                bool hr = nodes[nd.right].box.rayIntersect(ray, nr, fr);
+                if (hl && hr && nl < nr) { stack[sp++] = nd.right; stack[sp++] = nd.left; }
+                else { stack[sp++] = nd.left; stack[sp++] = nd.right; }
             }
         }
     }
