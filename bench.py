@@ -169,12 +169,30 @@ def measured_traffic(args, sc):
     return t.get(key, {}).get("hbm_bytes_per_launch")
 
 
+def usable_cores() -> int:
+    """Host cores this process may really use: CPU affinity, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, int(q / p_ + 0.5)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(sc, args):
     """The oracle (kind 'port': CPU restatement with a SAH BVH) on all host cores,
     on a bounded sample: the same frame at reduced spp, sized for ~cpu_seconds."""
     from tests.backends import Oracle
     o = Oracle(sc, use_bvh=True)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     _, st = o.render_host(spp_count=1, threads=cores)
     per_spp = max(st["kernel_ms"] * 1e-3, 1e-3)
     spp = int(max(1, min(args.spp, args.cpu_seconds / per_spp)))

@@ -1,0 +1,21 @@
+/* lbvh.h -- GPU LBVH builder (see lbvh.hip). */
+#pragma once
+#include <string>
+
+#include "rt_types.h"
+
+namespace nrt {
+
+struct LbvhDeviceResult {
+    f4 *d_nodes = nullptr;     /* hipMalloc'ed; ownership passes to the caller */
+    f4 *d_tris = nullptr;
+    int32_t root = 0;
+    uint32_t n_nodes = 0, n_leaves = 0, max_depth = 0;
+    float build_ms = 0.0f;
+};
+
+/* `dev` must have positions / indices / n_triangles set (device pointers);
+ * d_tri_mesh: mesh id per global triangle (device).  Returns "" or an error. */
+std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mesh, LbvhDeviceResult &out);
+
+} // namespace nrt

@@ -1,0 +1,316 @@
+/*
+ * lbvh.hip -- Accel::build on the GPU: a linear BVH (Morton order + radix
+ * tree) emitted directly in the traversal layout of rt_types.h.
+ *
+ * The reference's Accel::build is a no-op (src/accel.cpp:19-21) and its
+ * rayIntersect scans every triangle; a BVH is this project's replacement, and
+ * for the 10-M-triangle configuration (BASELINE config 5) a host build would
+ * dominate wall-clock, so the whole build runs in HIP kernels:
+ *
+ *   1. k_scene_bounds   per-triangle boxes (src/mesh.cpp:78-83) -> scene box
+ *                       (float atomics on order-preserving integer keys)
+ *   2. k_morton         30-bit Morton code of the box centre (src/mesh.cpp:85-90
+ *                       uses the vertex centroid; any centre orders as well),
+ *                       key = code << 32 | triangle  (unique keys)
+ *   3. hipcub radix sort of the 64-bit keys
+ *   4. k_hierarchy      Karras 2012: one thread per internal node finds its key
+ *                       range and split with clz(key_i ^ key_j)
+ *   5. k_leaf_boxes / k_tree_level   padded triangle boxes in sorted order and
+ *                       a min/max segment tree over them (one launch per level):
+ *                       every node covers a CONTIGUOUS sorted range, so its box
+ *                       is a range query -- no bottom-up atomics, no
+ *                       inter-workgroup visibility hazards
+ *   6. k_emit_nodes     64-B two-child-box node records; a child covering <= 4
+ *                       triangles becomes a leaf (contiguous in sorted order)
+ *   7. k_emit_tris      48-B de-indexed leaf triangle records in sorted order
+ *   8. k_depth          longest root-to-leaf chain (sizes the LDS stack)
+ *
+ * Any valid BVH returns the same hits as the linear scan (conservative node
+ * test + tie rule in rt_trace.h); tests/test_gpu_parity.py checks this builder
+ * against the oracle's brute force as well.  The SAH builder (scene_prep.cpp)
+ * gives trees that traverse faster and stays the default for small scenes.
+ */
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <string>
+
+#include "lbvh.h"
+
+using namespace nrt;
+
+namespace {
+
+__device__ __forceinline__ unsigned int float_key(float f) {      /* order preserving */
+    unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float key_float(unsigned int k) {
+    unsigned int u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __builtin_bit_cast(float, u);
+}
+
+__device__ __forceinline__ void tri_box(const f4 *pos, const uint32_t *idx, uint32_t t, f3 &mn, f3 &mx) {
+    const f3 a = xyz(pos[idx[3 * (size_t) t]]), b = xyz(pos[idx[3 * (size_t) t + 1]]), c = xyz(pos[idx[3 * (size_t) t + 2]]);
+    mn = mk3(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
+    mx = mk3(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
+}
+
+__global__ void k_scene_bounds(const f4 *pos, const uint32_t *idx, uint32_t n, unsigned int *bounds) {
+    __shared__ unsigned int s[6];
+    if (threadIdx.x < 3) s[threadIdx.x] = 0xffffffffu; else if (threadIdx.x < 6) s[threadIdx.x] = 0u;
+    __syncthreads();
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < n; t += gridDim.x * blockDim.x) {
+        f3 mn, mx; tri_box(pos, idx, t, mn, mx);
+        atomicMin(&s[0], float_key(mn.x)); atomicMin(&s[1], float_key(mn.y)); atomicMin(&s[2], float_key(mn.z));
+        atomicMax(&s[3], float_key(mx.x)); atomicMax(&s[4], float_key(mx.y)); atomicMax(&s[5], float_key(mx.z));
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicMin(&bounds[threadIdx.x], s[threadIdx.x]);
+    else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s[threadIdx.x]);
+}
+
+__device__ __forceinline__ unsigned int expand10(unsigned int v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+
+__global__ void k_morton(const f4 *pos, const uint32_t *idx, uint32_t n, f3 smin, f3 sinv, unsigned long long *keys) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    f3 mn, mx; tri_box(pos, idx, t, mn, mx);
+    const float cx = (0.5f * (mn.x + mx.x) - smin.x) * sinv.x, cy = (0.5f * (mn.y + mx.y) - smin.y) * sinv.y,
+                cz = (0.5f * (mn.z + mx.z) - smin.z) * sinv.z;
+    const unsigned int ix = (unsigned int) fminf(fmaxf(cx * 1024.0f, 0.0f), 1023.0f);
+    const unsigned int iy = (unsigned int) fminf(fmaxf(cy * 1024.0f, 0.0f), 1023.0f);
+    const unsigned int iz = (unsigned int) fminf(fmaxf(cz * 1024.0f, 0.0f), 1023.0f);
+    const unsigned int code = (expand10(ix) << 2) | (expand10(iy) << 1) | expand10(iz);
+    keys[t] = ((unsigned long long) code << 32) | t;
+}
+
+/* internal node i: children (bit 31 set = leaf primitive position), key range, parent links */
+struct RadixNode { uint32_t left, right, lo, hi; };
+constexpr uint32_t kLeafBit = 0x80000000u;
+
+__device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    return __clzll((long long) (keys[i] ^ keys[j]));
+}
+
+__global__ void k_hierarchy(const unsigned long long *keys, int n, RadixNode *nodes, uint32_t *parent_inner, uint32_t *parent_leaf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1; ; t = (t + 1) >> 1) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int gamma = i + s * d + min(d, 0);
+    const int lo = min(i, j), hi = max(i, j);
+    RadixNode nd;
+    nd.lo = (uint32_t) lo; nd.hi = (uint32_t) hi;
+    if (lo == gamma) { nd.left = kLeafBit | (uint32_t) gamma; parent_leaf[gamma] = (uint32_t) i; }
+    else { nd.left = (uint32_t) gamma; parent_inner[gamma] = (uint32_t) i; }
+    if (hi == gamma + 1) { nd.right = kLeafBit | (uint32_t) (gamma + 1); parent_leaf[gamma + 1] = (uint32_t) i; }
+    else { nd.right = (uint32_t) (gamma + 1); parent_inner[gamma + 1] = (uint32_t) i; }
+    nodes[i] = nd;
+    if (i == 0) parent_inner[0] = 0xffffffffu;
+}
+
+/* segment tree over the sorted, padded triangle boxes: entries [N + k] */
+__global__ void k_leaf_boxes(const f4 *pos, const uint32_t *idx, const unsigned long long *keys, uint32_t n, uint32_t N, float pad,
+                             f4 *tmin, f4 *tmax) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    f4 mn4, mx4;
+    if (k < n) {
+        f3 mn, mx; tri_box(pos, idx, (uint32_t) (keys[k] & 0xffffffffull), mn, mx);
+        mn4.x = mn.x - pad; mn4.y = mn.y - pad; mn4.z = mn.z - pad; mx4.x = mx.x + pad; mx4.y = mx.y + pad; mx4.z = mx.z + pad;
+    } else {
+        mn4.x = mn4.y = mn4.z = kInf; mx4.x = mx4.y = mx4.z = -kInf;
+    }
+    mn4.w = mx4.w = 0.0f;
+    tmin[N + k] = mn4; tmax[N + k] = mx4;
+}
+
+__global__ void k_tree_level(uint32_t first, uint32_t count, f4 *tmin, f4 *tmax) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= count) return;
+    const uint32_t i = first + k;
+    const f4 a = tmin[2 * i], b = tmin[2 * i + 1], c = tmax[2 * i], d = tmax[2 * i + 1];
+    f4 mn, mx;
+    mn.x = fminf(a.x, b.x); mn.y = fminf(a.y, b.y); mn.z = fminf(a.z, b.z); mn.w = 0.0f;
+    mx.x = fmaxf(c.x, d.x); mx.y = fmaxf(c.y, d.y); mx.z = fmaxf(c.z, d.z); mx.w = 0.0f;
+    tmin[i] = mn; tmax[i] = mx;
+}
+
+__device__ __forceinline__ void range_box(const f4 *tmin, const f4 *tmax, uint32_t N, uint32_t lo, uint32_t hi, f3 &mn, f3 &mx) {
+    mn = mk3(kInf); mx = mk3(-kInf);
+    uint32_t l = lo + N, r = hi + N + 1;
+    while (l < r) {
+        if (l & 1u) { const f4 a = tmin[l], b = tmax[l]; ++l;
+            mn = mk3(fminf(mn.x, a.x), fminf(mn.y, a.y), fminf(mn.z, a.z)); mx = mk3(fmaxf(mx.x, b.x), fmaxf(mx.y, b.y), fmaxf(mx.z, b.z)); }
+        if (r & 1u) { --r; const f4 a = tmin[r], b = tmax[r];
+            mn = mk3(fminf(mn.x, a.x), fminf(mn.y, a.y), fminf(mn.z, a.z)); mx = mk3(fmaxf(mx.x, b.x), fmaxf(mx.y, b.y), fmaxf(mx.z, b.z)); }
+        l >>= 1; r >>= 1;
+    }
+}
+
+__device__ __forceinline__ int32_t child_link(const RadixNode *nodes, uint32_t child, uint32_t &lo, uint32_t &hi) {
+    if (child & kLeafBit) {
+        lo = hi = child & ~kLeafBit;
+        return (int32_t) ~((lo << 3) | 0u);
+    }
+    lo = nodes[child].lo; hi = nodes[child].hi;
+    const uint32_t cnt = hi - lo + 1;
+    if (cnt <= 4u) return (int32_t) ~((lo << 3) | (cnt - 1u));
+    return (int32_t) child;
+}
+
+__global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N, f4 *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    const RadixNode nd = nodes[i];
+    uint32_t llo, lhi, rlo, rhi;
+    const int32_t cl = child_link(nodes, nd.left, llo, lhi), cr = child_link(nodes, nd.right, rlo, rhi);
+    f3 lmn, lmx, rmn, rmx;
+    range_box(tmin, tmax, N, llo, lhi, lmn, lmx);
+    range_box(tmin, tmax, N, rlo, rhi, rmn, rmx);
+    f4 *q = out + (size_t) i * kNodeQuads;
+    f4 a, b, c, d;
+    a.x = lmn.x; a.y = lmn.y; a.z = lmn.z; a.w = lmx.x;
+    b.x = lmx.y; b.y = lmx.z; b.z = rmn.x; b.w = rmn.y;
+    c.x = rmn.z; c.y = rmx.x; c.z = rmx.y; c.w = rmx.z;
+    d.x = __uint_as_float((uint32_t) cl); d.y = __uint_as_float((uint32_t) cr); d.z = 0.0f; d.w = 0.0f;
+    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+}
+
+__global__ void k_emit_tris(const f4 *pos, const uint32_t *idx, const uint32_t *tri_mesh, const unsigned long long *keys, uint32_t n, f4 *out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t g = (uint32_t) (keys[k] & 0xffffffffull);
+    const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
+    const f3 e1 = p1 - p0, e2 = p2 - p0;      /* the subtraction mesh.cpp:43 performs per ray */
+    f4 a, b, c;
+    a.x = p0.x; a.y = p0.y; a.z = p0.z; a.w = e1.x;
+    b.x = e1.y; b.y = e1.z; b.z = e2.x; b.w = e2.y;
+    c.x = e2.z; c.y = __uint_as_float(g); c.z = __uint_as_float(tri_mesh[g]); c.w = 0.0f;
+    f4 *q = out + (size_t) k * kTriQuads;
+    q[0] = a; q[1] = b; q[2] = c;
+}
+
+__global__ void k_depth(const uint32_t *parent_inner, const uint32_t *parent_leaf, uint32_t n, unsigned int *max_depth) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    unsigned int depth = 1;
+    uint32_t p = parent_leaf[k];
+    while (p != 0u && p != 0xffffffffu && depth < 4096u) { p = parent_inner[p]; ++depth; }
+    atomicMax(max_depth, depth);
+}
+
+struct Buf {
+    void *p = nullptr;
+    ~Buf() { if (p) (void) hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes < 16 ? 16 : bytes); }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+#define LB_TRY(expr)                                                                    \
+    do { hipError_t e__ = (expr); if (e__ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e__); } while (0)
+
+} // namespace
+
+namespace nrt {
+
+std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mesh, LbvhDeviceResult &out) {
+    out = LbvhDeviceResult();
+    const uint32_t n = dev.n_triangles;
+    hipEvent_t e0, e1;
+    LB_TRY(hipEventCreate(&e0)); LB_TRY(hipEventCreate(&e1));
+    LB_TRY(hipEventRecord(e0, 0));
+
+    if (n == 0) return "lbvh: empty scene";
+    const int B = 256;
+    const uint32_t gridN = (n + B - 1) / B;
+
+    /* 1. scene bounds */
+    Buf bounds; LB_TRY(bounds.alloc(6 * sizeof(unsigned int)));
+    const unsigned int init[6] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0u, 0u, 0u};
+    LB_TRY(hipMemcpy(bounds.p, init, sizeof(init), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_scene_bounds, dim3(std::min<uint32_t>(gridN, 4096)), dim3(B), 0, 0, dev.positions, dev.indices, n, bounds.as<unsigned int>());
+    unsigned int hb[6];
+    LB_TRY(hipMemcpy(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost));
+    f3 smin = mk3(key_float(hb[0]), key_float(hb[1]), key_float(hb[2])), smax = mk3(key_float(hb[3]), key_float(hb[4]), key_float(hb[5]));
+    const float ex = smax.x - smin.x, ey = smax.y - smin.y, ez = smax.z - smin.z;
+    const float pad = 2e-5f * sqrtf(ex * ex + ey * ey + ez * ez) + 1e-30f;    /* as scene_prep.cpp */
+    const f3 sinv = mk3(ex > 0 ? 1.0f / ex : 0.0f, ey > 0 ? 1.0f / ey : 0.0f, ez > 0 ? 1.0f / ez : 0.0f);
+
+    /* 7 first: the triangle records only need the sorted order; tiny scenes are one leaf */
+    Buf keys_a, keys_b;
+    LB_TRY(keys_a.alloc((size_t) n * 8)); LB_TRY(keys_b.alloc((size_t) n * 8));
+    hipLaunchKernelGGL(k_morton, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n, smin, sinv, keys_a.as<unsigned long long>());
+    size_t temp_bytes = 0;
+    LB_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(), (int) n, 0, 62));
+    Buf temp; LB_TRY(temp.alloc(temp_bytes));
+    LB_TRY(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(), (int) n, 0, 62));
+    const unsigned long long *keys = keys_b.as<unsigned long long>();
+
+    f4 *d_tris = nullptr;
+    LB_TRY(hipMalloc((void **) &d_tris, (size_t) n * kTriQuads * sizeof(f4)));
+    out.d_tris = d_tris;
+    hipLaunchKernelGGL(k_emit_tris, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, d_tri_mesh, keys, n, d_tris);
+
+    if (n <= 4) {
+        f4 *d_nodes = nullptr;
+        LB_TRY(hipMalloc((void **) &d_nodes, kNodeQuads * sizeof(f4)));
+        LB_TRY(hipMemset(d_nodes, 0, kNodeQuads * sizeof(f4)));
+        out.d_nodes = d_nodes; out.root = (int32_t) ~((0u << 3) | (n - 1u));
+        out.n_nodes = 0; out.n_leaves = 1; out.max_depth = 0;
+    } else {
+        /* 4. radix tree */
+        Buf rnodes, pin, plf;
+        LB_TRY(rnodes.alloc((size_t) (n - 1) * sizeof(RadixNode)));
+        LB_TRY(pin.alloc((size_t) n * 4)); LB_TRY(plf.alloc((size_t) n * 4));
+        hipLaunchKernelGGL(k_hierarchy, dim3(gridN), dim3(B), 0, 0, keys, (int) n, rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());
+        /* 5. segment tree of boxes */
+        uint32_t N = 1; while (N < n) N <<= 1;
+        Buf tmin, tmax;
+        LB_TRY(tmin.alloc((size_t) 2 * N * sizeof(f4))); LB_TRY(tmax.alloc((size_t) 2 * N * sizeof(f4)));
+        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, keys, n, N, pad, tmin.as<f4>(), tmax.as<f4>());
+        for (uint32_t first = N >> 1; first >= 1; first >>= 1) {
+            hipLaunchKernelGGL(k_tree_level, dim3((first + B - 1) / B), dim3(B), 0, 0, first, first, tmin.as<f4>(), tmax.as<f4>());
+            if (first == 1) break;
+        }
+        /* 6. nodes */
+        f4 *d_nodes = nullptr;
+        LB_TRY(hipMalloc((void **) &d_nodes, (size_t) (n - 1) * kNodeQuads * sizeof(f4)));
+        out.d_nodes = d_nodes;
+        hipLaunchKernelGGL(k_emit_nodes, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, tmin.as<f4>(), tmax.as<f4>(), N, d_nodes);
+        /* 8. depth */
+        Buf md; LB_TRY(md.alloc(4)); LB_TRY(hipMemset(md.p, 0, 4));
+        hipLaunchKernelGGL(k_depth, dim3(gridN), dim3(B), 0, 0, pin.as<uint32_t>(), plf.as<uint32_t>(), n, md.as<unsigned int>());
+        unsigned int depth = 0;
+        LB_TRY(hipMemcpy(&depth, md.p, 4, hipMemcpyDeviceToHost));
+        out.root = 0; out.n_nodes = n - 1; out.n_leaves = 0; out.max_depth = depth;
+        LB_TRY(hipGetLastError());
+    }
+    LB_TRY(hipEventRecord(e1, 0));
+    LB_TRY(hipEventSynchronize(e1));
+    LB_TRY(hipEventElapsedTime(&out.build_ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    return std::string();
+}
+
+} // namespace nrt

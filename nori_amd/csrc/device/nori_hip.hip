@@ -34,6 +34,7 @@
 #include "rt_film.h"
 #include "rt_path.h"
 #include "scene_prep.h"
+#include "lbvh.h"
 
 using namespace nrt;
 
@@ -356,9 +357,11 @@ struct nori_hip_ctx {
     DevScene dev;
     std::vector<void *> allocs_scene, allocs_accel;
     float *d_filter = nullptr;
+    const uint32_t *d_tri_mesh = nullptr;
     unsigned long long *d_stats = nullptr;
     nori_accel_info info;
     int stack_depth = 32;
+    uint64_t lbvh_bytes = 0;
 };
 
 static std::string g_create_error;
@@ -447,6 +450,7 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
     if ((rc = upload(ctx, ctx->allocs_scene, h.meshes, &d.meshes))) return rc;
     if ((rc = upload(ctx, ctx->allocs_scene, h.emitter_cdf, &d.emitter_cdf))) return rc;
     if ((rc = upload(ctx, ctx->allocs_scene, h.emitters, &d.emitters))) return rc;
+    if ((rc = upload(ctx, ctx->allocs_scene, h.tri_mesh, &ctx->d_tri_mesh))) return rc;
     std::vector<float> ft(h.filter.table, h.filter.table + kFilterRes + 1);
     const float *dft = nullptr;
     if ((rc = upload(ctx, ctx->allocs_scene, ft, &dft))) return rc;
@@ -462,21 +466,36 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
 int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     if (!ctx) return NORI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) { ctx->error = "build_accel: no scene uploaded"; return NORI_ERR_NOT_READY; }
-    if (builder != NORI_ACCEL_HOST_SAH) { ctx->error = "build_accel: only NORI_ACCEL_HOST_SAH is implemented"; return NORI_ERR_UNSUPPORTED; }
+    if (builder != NORI_ACCEL_HOST_SAH && builder != NORI_ACCEL_GPU_LBVH) { ctx->error = "build_accel: unknown builder"; return NORI_ERR_INVALID_ARGUMENT; }
     DeviceGuard g(ctx->device);
     free_pool(ctx->allocs_accel);
     ctx->have_accel = false;
-    std::string err = build_bvh_sah(ctx->host, 64, ctx->bvh);
-    if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
-    int rc;
-    if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.nodes, &ctx->dev.nodes))) return rc;
-    if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.tris, &ctx->dev.tris))) return rc;
+    if (builder == NORI_ACCEL_GPU_LBVH && ctx->dev.n_triangles > 0) {
+        LbvhDeviceResult res;
+        std::string err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res);
+        if (res.d_nodes) ctx->allocs_accel.push_back(res.d_nodes);
+        if (res.d_tris) ctx->allocs_accel.push_back(res.d_tris);
+        if (err.empty() && res.max_depth + 1 > 64) err = "LBVH deeper than the traversal stack (64); use NORI_ACCEL_HOST_SAH";
+        if (!err.empty()) { ctx->error = err; free_pool(ctx->allocs_accel); return NORI_ERR_INTERNAL; }
+        ctx->bvh = HostBvh();
+        ctx->bvh.root = res.root; ctx->bvh.n_nodes = res.n_nodes; ctx->bvh.n_leaves = res.n_leaves;
+        ctx->bvh.max_depth = res.max_depth; ctx->bvh.build_ms = res.build_ms; ctx->bvh.sah_cost = 0.0f;
+        ctx->dev.nodes = res.d_nodes; ctx->dev.tris = res.d_tris;
+        ctx->lbvh_bytes = (uint64_t) std::max<uint32_t>(res.n_nodes, 1) * kNodeQuads * 16 + (uint64_t) ctx->dev.n_triangles * kTriQuads * 16;
+    } else {
+        std::string err = build_bvh_sah(ctx->host, 64, ctx->bvh);
+        if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
+        int rc;
+        if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.nodes, &ctx->dev.nodes))) return rc;
+        if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.tris, &ctx->dev.tris))) return rc;
+        ctx->lbvh_bytes = 0;
+    }
     ctx->dev.root = ctx->bvh.root;
     ctx->stack_depth = ctx->bvh.max_depth + 1 <= 32 ? 32 : 64;
     nori_accel_info &in = ctx->info;
     in.n_triangles = ctx->dev.n_triangles; in.n_nodes = ctx->bvh.n_nodes; in.n_leaves = ctx->bvh.n_leaves;
     in.max_depth = ctx->bvh.max_depth; in.node_bytes = kNodeQuads * 16; in.tri_bytes = kTriQuads * 16;
-    in.total_bytes = (uint64_t) ctx->bvh.nodes.size() * 16 + (uint64_t) ctx->bvh.tris.size() * 16;
+    in.total_bytes = ctx->lbvh_bytes ? ctx->lbvh_bytes : (uint64_t) ctx->bvh.nodes.size() * 16 + (uint64_t) ctx->bvh.tris.size() * 16;
     in.build_ms = ctx->bvh.build_ms; in.sah_cost = ctx->bvh.sah_cost;
     ctx->have_accel = true;
     return NORI_OK;
