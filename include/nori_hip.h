@@ -262,6 +262,12 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene);
 int nori_hip_build_accel(nori_hip_ctx *ctx, int builder /* nori_accel_builder */);
 int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out);
 
+/* Tuning / engine selection (no reference counterpart).  Keys:
+ *   "engine"          "megakernel" (default) | "wavefront"
+ *   "wavefront_paths" paths in flight per wavefront batch (default 2^25)
+ * Unknown keys return NORI_ERR_INVALID_ARGUMENT. */
+int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value);
+
 /* ImageBlock::m_borderSize for the uploaded filter (src/block.cpp:20). */
 int nori_hip_border_size(const nori_hip_ctx *ctx);
 

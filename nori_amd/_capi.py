@@ -116,6 +116,7 @@ HIP_PROTOTYPES = {
     "nori_hip_upload_scene": (C.c_int, [_P, C.POINTER(SceneDesc)]),
     "nori_hip_build_accel": (C.c_int, [_P, C.c_int]),
     "nori_hip_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
+    "nori_hip_set_option": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
     "nori_hip_border_size": (C.c_int, [_P]),
     "nori_hip_intersect": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
     "nori_hip_intersect_device": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, _P]),

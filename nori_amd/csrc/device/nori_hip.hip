@@ -35,6 +35,7 @@
 #include "rt_path.h"
 #include "scene_prep.h"
 #include "lbvh.h"
+#include "wavefront.h"
 
 using namespace nrt;
 
@@ -362,6 +363,8 @@ struct nori_hip_ctx {
     nori_accel_info info;
     int stack_depth = 32;
     uint64_t lbvh_bytes = 0;
+    int engine = 0;                 /* 0 megakernel, 1 wavefront */
+    size_t wavefront_paths = (size_t) 1 << 25;
 };
 
 static std::string g_create_error;
@@ -424,6 +427,7 @@ void nori_hip_destroy(nori_hip_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     free_pool(ctx->allocs_scene); free_pool(ctx->allocs_accel);
+    wavefront_release();
     if (ctx->d_stats) (void) hipFree(ctx->d_stats);
     delete ctx;
 }
@@ -455,6 +459,7 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
     const float *dft = nullptr;
     if ((rc = upload(ctx, ctx->allocs_scene, ft, &dft))) return rc;
     ctx->d_filter = const_cast<float *>(dft);
+    d.tri_mesh = ctx->d_tri_mesh;
     d.n_emitters = (uint32_t) h.emitters.size();
     d.n_meshes = (uint32_t) h.meshes.size();
     d.n_triangles = (uint32_t) h.tri_mesh.size();
@@ -499,6 +504,25 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     in.build_ms = ctx->bvh.build_ms; in.sah_cost = ctx->bvh.sah_cost;
     ctx->have_accel = true;
     return NORI_OK;
+}
+
+int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value) {
+    if (!ctx || !key || !value) return NORI_ERR_INVALID_ARGUMENT;
+    const std::string k(key), v(value);
+    if (k == "engine") {
+        if (v == "megakernel") ctx->engine = 0;
+        else if (v == "wavefront") ctx->engine = 1;
+        else { ctx->error = "set_option: engine must be megakernel or wavefront"; return NORI_ERR_INVALID_ARGUMENT; }
+        return NORI_OK;
+    }
+    if (k == "wavefront_paths") {
+        const long long n = atoll(value);
+        if (n < 256) { ctx->error = "set_option: wavefront_paths must be >= 256"; return NORI_ERR_INVALID_ARGUMENT; }
+        ctx->wavefront_paths = (size_t) n;
+        return NORI_OK;
+    }
+    ctx->error = "set_option: unknown key " + k;
+    return NORI_ERR_INVALID_ARGUMENT;
 }
 
 int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out) {
@@ -786,6 +810,20 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         HIP_TRY(ctx, hipEventCreate(&ev0)); HIP_TRY(ctx, hipEventCreate(&ev1));
         HIP_TRY(ctx, hipEventRecord(ev0, s));
     }
+    WfStats wst;
+    int engine = ctx->engine;
+    if (const char *e = getenv("NORI_HIP_ENGINE")) engine = std::string(e) == "wavefront" ? 1 : 0;
+    if (engine == 1 && a.n_sel_tiles > 0 && a.spp_count > 0) {
+        WfLaunch wl;
+        wl.spp_begin = a.spp_begin; wl.spp_count = a.spp_count; wl.tile_mod = a.tile_mod; wl.tile_rem = a.tile_rem;
+        wl.tiles_x = a.tiles_x; wl.tiles_y = a.tiles_y; wl.n_sel_tiles = a.n_sel_tiles; wl.tile_w = a.tile_w;
+        const uint32_t need = ctx->bvh.max_depth + 1;
+        wl.stack_depth = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 64;
+        wl.count_traversal = params->count_traversal != 0;
+        wl.max_paths = ctx->wavefront_paths;
+        std::string err = wavefront_render(ctx->dev, ctx->d_filter, wl, (float *) d_rgbw, s, wst);
+        if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
+    } else
     if (a.n_sel_tiles > 0 && a.spp_count > 0) {
         hipError_t e;
         const bool count = params->count_traversal != 0;
@@ -812,6 +850,12 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         if (getenv("NORI_HIP_CENSUS") && h[8])
             fprintf(stderr, "[census] shade runs %llu lanes %.1f | inner runs %llu lanes %.1f | leaf runs %llu lanes %.1f\n", h[8], (double) h[9] / h[8], h[10], (double) h[11] / std::max(1ull, h[10]), h[12], (double) h[13] / std::max(1ull, h[12]));
         stats->n_workgroups = a.n_sel_tiles * a.n_chunks;
+        if (engine == 1) {
+            stats->n_camera_samples = wst.n_camera; stats->n_closest_rays = wst.n_closest; stats->n_shadow_rays = wst.n_shadow;
+            stats->n_node_tests = wst.n_nodes; stats->n_tri_tests = wst.n_tris; stats->n_invalid = wst.n_invalid;
+            stats->n_workgroups = wst.n_launches;
+            if (getenv("NORI_HIP_CENSUS")) fprintf(stderr, "[wavefront] batches %u iterations %u launches %u state %.1f MB\n", wst.n_batches, wst.n_iterations, wst.n_launches, wst.state_bytes / 1048576.0);
+        }
         const uint32_t need = ctx->bvh.max_depth + 1;
         stats->lds_bytes = (uint32_t) (need <= 16 ? render_lds_bytes<16>(a) : need <= 24 ? render_lds_bytes<24>(a) : need <= 32 ? render_lds_bytes<32>(a) : render_lds_bytes<64>(a));
     }

@@ -156,6 +156,7 @@ struct DevScene {
     const MeshRec *meshes;
     const float *emitter_cdf;
     const uint32_t *emitters;   /* mesh ids of emitters */
+    const uint32_t *tri_mesh;   /* mesh id per global triangle */
     uint32_t n_emitters;
     uint32_t n_meshes;
     uint32_t n_triangles;

@@ -1,0 +1,483 @@
+/*
+ * wavefront.hip -- the wavefront engine of the render path.
+ *
+ * Same per-lane code as the megakernel (rt_path.h, rt_trace.h, rt_film.h), same
+ * pcg32 streams, therefore the same radiance per camera sample; what changes is
+ * how work is laid out for 64-wide waves.  In the megakernel a lane owns a
+ * pixel and, when its path needs shading while its neighbours still traverse,
+ * it waits.  Here paths live in HBM (sized for 288 GB: ~150 B per path, tens of
+ * millions in flight) and every kernel runs with all lanes doing the SAME kind
+ * of work:
+ *
+ *   wf_generate  camera samples -> path state + first ray          (src/main.cpp:41-46)
+ *   loop until no path is alive:
+ *     wf_extend  persistent waves pull rays from a queue; a lane whose ray
+ *                finishes writes the hit and is refilled as soon as enough
+ *                lanes of its wave are idle (__ballot + one atomic per wave)
+ *                -> Accel::rayIntersect, closest and shadow rays together
+ *     wf_shade   one lane per live path: consume the shadow result, shade the
+ *                closest hit (Integrator::Li state machine), append the next
+ *                shadow + continuation rays with wave-aggregated atomics
+ *   wf_splat     one workgroup per tile: its samples are contiguous in HBM; the
+ *                filtered splat runs in LDS exactly as in the megakernel
+ *                (ImageBlock::put, src/block.cpp:62-91) and the tile is merged
+ *                into the frame (ImageBlock::put(ImageBlock&), block.cpp:93-102)
+ *
+ * A path vertex costs ONE iteration: its shadow ray (slot B) and continuation
+ * ray (slot A) are traced in the same wf_extend pass, and the next wf_shade
+ * first adds the emitter sample if B was unoccluded, then shades A's hit --
+ * the order in which the megakernel and the CPU oracle accumulate.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "rt_film.h"
+#include "rt_path.h"
+#include "wavefront.h"
+
+using namespace nrt;
+
+namespace {
+
+constexpr int kB = 256;
+
+enum { C_RQ_CUR = 0, C_RQ_NEXT = 1, C_PQ_CUR = 2, C_PQ_NEXT = 3, C_HEAD = 4, C_COUNT = 8 };
+enum { S_CAM = 0, S_CLOSEST = 1, S_SHADOW = 2, S_NODES = 3, S_TRIS = 4, S_INVALID = 5, S_COUNT = 8 };
+
+/* path flags */
+constexpr uint32_t F_HAS_A = 1u, F_HAS_B = 2u, F_END_AFTER_B = 4u;
+
+struct WfBuf {
+    f4 *ray_o;      /* (o.xyz, mint of slot A) */
+    f4 *rayA_d;     /* (d.xyz, maxt) closest-hit ray   */
+    f4 *rayB_d;     /* (d.xyz, maxt) shadow ray, mint = epsilon, same origin */
+    f4 *hitA, *hitB;   /* (t, u, v, bits tri) */
+    f4 *T_eta, *L_pdf, *Ld;
+    uint32_t *flags;   /* F_* | prev_measure << 4 | depth << 8 */
+    unsigned long long *rng;
+    f2 *samp_pos;
+    f4 *samp_L;        /* (L.rgb, 1) once the path has finished */
+    uint32_t *rq[2];   /* ray queues: path << 1 | slot */
+    uint32_t *pq[2];   /* path queues */
+    uint32_t *ctr;
+    unsigned long long *stats;
+};
+
+struct WfBatch {
+    uint32_t tile_first, n_tiles;       /* range of selected-tile ordinals */
+    uint32_t s_first, n_spp;            /* absolute first sample index, samples per pixel in this batch */
+    uint32_t tile_mod, tile_rem, tiles_x;
+    int32_t tile_w;
+};
+
+template <int DEPTH>
+struct LdsStackW {
+    int *base; int sp;
+    __device__ __forceinline__ void reset() { sp = 0; }
+    __device__ __forceinline__ bool empty() const { return sp == 0; }
+    __device__ __forceinline__ void push(int v) { if (sp < DEPTH) base[sp * kB] = v; sp++; }
+    __device__ __forceinline__ int pop() { sp--; return sp < DEPTH ? base[sp * kB] : 0; }
+};
+
+__device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
+
+/* wave-aggregated queue slot allocation: one atomic per wave */
+__device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter, bool pred) {
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const int leader = __ffsll((long long) mask) - 1;
+    uint32_t base = 0;
+    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t) __popcll(mask));
+    base = (uint32_t) __shfl((int) base, leader);
+    return base + (uint32_t) __popcll(mask & ((1ull << lane_id()) - 1ull));
+}
+
+/* pixel of path-local index `pix` inside a tile: wave w covers the 8x8 quad (w&1, w>>1) */
+__device__ __forceinline__ void tile_pixel(int pix, int x0, int y0, int &px, int &py) {
+    const int wave = pix >> 6, lane = pix & 63;
+    px = x0 + ((wave & 1) << 3) + (lane & 7);
+    py = y0 + ((wave >> 1) << 3) + (lane >> 3);
+}
+
+__global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch bt) {
+    const uint32_t per_tile = 256u * bt.n_spp;
+    const uint32_t n = bt.n_tiles * per_tile;
+    for (uint32_t base = blockIdx.x * kB; base < n; base += gridDim.x * kB) {
+        const uint32_t p = base + threadIdx.x;
+        bool live = p < n;
+        if (live) {
+            const uint32_t tsel = p / per_tile, rem = p - tsel * per_tile;
+            const uint32_t sl = rem >> 8, pix = rem & 255u;
+            const uint32_t tile_id = bt.tile_rem + (bt.tile_first + tsel) * bt.tile_mod;
+            const int x0 = (int) (tile_id % bt.tiles_x) * kTile, y0 = (int) (tile_id / bt.tiles_x) * kTile;
+            int px, py; tile_pixel((int) pix, x0, y0, px, py);
+            f4 sl4; sl4.x = sl4.y = sl4.z = sl4.w = 0.0f;
+            b.samp_L[p] = sl4;
+            live = px < sc.camera.width && py < sc.camera.height;
+            if (live) {
+                /* renderBlock, src/main.cpp:41-46 */
+                Rng rng;
+                rng_seed(rng, (uint64_t) py * (uint64_t) sc.camera.width + (uint64_t) px, (uint64_t) (bt.s_first + sl));
+                const f2 j = rng_next_2d(rng);
+                const f2 ps = mk2((float) px + j.x, (float) py + j.y);
+                (void) rng_next_2d(rng);          /* apertureSample: drawn, unused */
+                RayIn cam; camera_sample_ray(sc.camera, ps, cam);
+                b.samp_pos[p] = ps;
+                f4 o; o.x = cam.o.x; o.y = cam.o.y; o.z = cam.o.z; o.w = cam.mint;
+                f4 d; d.x = cam.d.x; d.y = cam.d.y; d.z = cam.d.z; d.w = cam.maxt;
+                b.ray_o[p] = o; b.rayA_d[p] = d;
+                f4 t; t.x = t.y = t.z = 1.0f; t.w = 1.0f;      /* T = 1, eta = 1 */
+                f4 l; l.x = l.y = l.z = 0.0f; l.w = 0.0f;      /* L = 0, pdf_mat = 0 */
+                b.T_eta[p] = t; b.L_pdf[p] = l;
+                b.flags[p] = F_HAS_A | (2u << 4);             /* prev_measure = discrete, depth 0 */
+                b.rng[p] = rng.state;
+            }
+        }
+        const uint32_t r = wave_alloc(&b.ctr[C_RQ_CUR], live);
+        if (live) b.rq[0][r] = p << 1;
+        const uint32_t q = wave_alloc(&b.ctr[C_PQ_CUR], live);
+        if (live) b.pq[0][q] = p;
+        const unsigned long long lm = __ballot(live);
+        if (lane_id() == 0 && lm) atomicAdd(&b.stats[S_CAM], (unsigned long long) __popcll(lm));
+    }
+}
+
+template <int STACK, bool COUNT>
+__global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, int refill_threshold) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LdsStackW<STACK> stack;
+    stack.base = reinterpret_cast<int *>(smem) + threadIdx.x; stack.sp = 0;
+    const uint32_t n = b.ctr[C_RQ_CUR];
+    const uint32_t *rq = b.rq[cur];
+    const int lane = lane_id();
+    Trav tv; tv.active = false; tv.node = 0;
+    uint32_t rid = 0;
+    bool exhausted = n == 0;
+    uint32_t nClosest = 0, nShadow = 0;
+    TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
+    while (true) {
+        const unsigned long long idle = __ballot(!tv.active);
+        const int nIdle = __popcll(idle);
+        if (!exhausted && (nIdle >= refill_threshold || nIdle == 64)) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&b.ctr[C_HEAD], (uint32_t) nIdle);
+            base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+            if (!tv.active) {
+                const uint32_t my = base + (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
+                if (my < n) {
+                    rid = rq[my];
+                    const uint32_t p = rid >> 1;
+                    const bool any = (rid & 1u) != 0u;
+                    const f4 o = b.ray_o[p];
+                    const f4 d = any ? b.rayB_d[p] : b.rayA_d[p];
+                    RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z);
+                    ray.mint = any ? kEpsilon : o.w; ray.maxt = d.w;
+                    trav_begin(sc, ray, any, stack, tv);
+                    if (any) ++nShadow; else ++nClosest;
+                    if (!tv.active) {            /* empty scene: answer immediately */
+                        f4 h; h.x = ray.maxt; h.y = h.z = 0.0f; h.w = __uint_as_float(kNoHit);
+                        if (any) b.hitB[p] = h; else b.hitA[p] = h;
+                    }
+                }
+            }
+            if (base + (uint32_t) nIdle >= n) exhausted = true;
+        }
+        if (__ballot(tv.active) == 0ull) {
+            if (exhausted) break;
+            continue;
+        }
+        const bool was = tv.active;
+        if (tv.active && tv.node >= 0) trav_inner_step<COUNT>(sc, stack, tv, tc);
+        if (tv.active && tv.node < 0) trav_leaf_step<COUNT>(sc, stack, tv, tc);
+        if (was && !tv.active) {
+            f4 h; h.x = tv.hit.t; h.y = tv.hit.u; h.z = tv.hit.v; h.w = __uint_as_float(tv.hit.tri);
+            if (rid & 1u) b.hitB[rid >> 1] = h; else b.hitA[rid >> 1] = h;
+        }
+    }
+    /* counters: one atomic per wave */
+    for (int off = 32; off > 0; off >>= 1) {
+        nClosest += (uint32_t) __shfl_down((int) nClosest, off);
+        nShadow += (uint32_t) __shfl_down((int) nShadow, off);
+        if (COUNT) { tc.nodes += (uint32_t) __shfl_down((int) tc.nodes, off); tc.tris += (uint32_t) __shfl_down((int) tc.tris, off); }
+    }
+    if (lane == 0) {
+        if (nClosest) atomicAdd(&b.stats[S_CLOSEST], (unsigned long long) nClosest);
+        if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
+        if (COUNT) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
+    }
+}
+
+template <int INTEG>
+__global__ __launch_bounds__(kB) void wf_shade(DevScene sc, WfBuf b, int cur, uint32_t s_first, uint32_t n_spp) {
+    const uint32_t n = b.ctr[C_PQ_CUR];
+    const uint32_t *pq = b.pq[cur];
+    uint32_t *rq_next = b.rq[cur ^ 1], *pq_next = b.pq[cur ^ 1];
+    for (uint32_t base = blockIdx.x * kB; base < n; base += gridDim.x * kB) {
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < n;
+        bool pushA = false, pushB = false;
+        uint32_t p = 0;
+        if (valid) {
+            p = pq[i];
+            const uint32_t fl = b.flags[p];
+            f4 L4 = b.L_pdf[p];
+            bool done = false;
+            if (fl & F_HAS_B) {                       /* path_on_shadow: add the emitter sample if unoccluded */
+                const f4 hb = b.hitB[p];
+                if (__float_as_uint(hb.w) == kNoHit) {
+                    const f4 ld = b.Ld[p];
+                    L4.x = L4.x + ld.x; L4.y = L4.y + ld.y; L4.z = L4.z + ld.z;
+                }
+                if (fl & F_END_AFTER_B) done = true;
+            }
+            PathState st;
+            st.L = mk3(L4.x, L4.y, L4.z);
+            if (!done) {
+                const f4 ha = b.hitA[p];
+                const f4 d4 = b.rayA_d[p];
+                const f4 t4 = b.T_eta[p];
+                Hit hit; hit.t = ha.x; hit.u = ha.y; hit.v = ha.z; hit.tri = __float_as_uint(ha.w);
+                const bool found = hit.tri != kNoHit;
+                hit.mesh = found ? sc.tri_mesh[hit.tri] : kNoHit;
+                st.T = mk3(t4.x, t4.y, t4.z); st.eta = t4.w; st.pdf_mat = L4.w;
+                st.Ld = mk3(0.0f); st.cont_d = mk3(0.0f);
+                st.prev_measure = (int32_t) ((fl >> 4) & 3u); st.depth = (int32_t) (fl >> 8);
+                st.phase = PH_CLOSEST; st.end_after_shadow = 0;
+                st.ray.o = st.ray.d = mk3(0.0f); st.ray.mint = st.ray.maxt = 0.0f;
+                /* pcg32 stream of this camera sample: inc from the sample index, state from HBM */
+                const uint32_t per_tile = 256u * n_spp;
+                const uint32_t sl = (p % per_tile) >> 8;
+                st.rng.inc = ((uint64_t) (s_first + sl) << 1u) | 1u;
+                st.rng.state = b.rng[p];
+                done = path_on_closest<INTEG>(sc, st, hit, found, mk3(d4.x, d4.y, d4.z));
+                if (!done) {
+                    f4 o; o.x = st.ray.o.x; o.y = st.ray.o.y; o.z = st.ray.o.z;
+                    uint32_t nf = ((uint32_t) st.prev_measure << 4) | ((uint32_t) st.depth << 8);
+                    if (st.phase == PH_SHADOW) {
+                        f4 db; db.x = st.ray.d.x; db.y = st.ray.d.y; db.z = st.ray.d.z; db.w = st.ray.maxt;
+                        b.rayB_d[p] = db;
+                        f4 ld; ld.x = st.Ld.x; ld.y = st.Ld.y; ld.z = st.Ld.z; ld.w = 0.0f;
+                        b.Ld[p] = ld;
+                        pushB = true; nf |= F_HAS_B;
+                        o.w = kEpsilon;
+                        if (st.end_after_shadow) nf |= F_END_AFTER_B;
+                        else {
+                            f4 da; da.x = st.cont_d.x; da.y = st.cont_d.y; da.z = st.cont_d.z; da.w = kInf;
+                            b.rayA_d[p] = da; pushA = true; nf |= F_HAS_A;
+                        }
+                    } else {
+                        f4 da; da.x = st.ray.d.x; da.y = st.ray.d.y; da.z = st.ray.d.z; da.w = st.ray.maxt;
+                        b.rayA_d[p] = da; pushA = true; nf |= F_HAS_A;
+                        o.w = st.ray.mint;
+                    }
+                    b.ray_o[p] = o;
+                    b.flags[p] = nf;
+                    f4 t; t.x = st.T.x; t.y = st.T.y; t.z = st.T.z; t.w = st.eta;
+                    b.T_eta[p] = t;
+                    f4 l; l.x = st.L.x; l.y = st.L.y; l.z = st.L.z; l.w = st.pdf_mat;
+                    b.L_pdf[p] = l;
+                    b.rng[p] = st.rng.state;
+                }
+            }
+            if (done) {
+                f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 1.0f;
+                b.samp_L[p] = out;
+            }
+        }
+        const uint32_t ra = wave_alloc(&b.ctr[C_RQ_NEXT], pushA);
+        if (pushA) rq_next[ra] = p << 1;
+        const uint32_t rb = wave_alloc(&b.ctr[C_RQ_NEXT], pushB);
+        if (pushB) rq_next[rb] = (p << 1) | 1u;
+        const uint32_t qn = wave_alloc(&b.ctr[C_PQ_NEXT], pushA || pushB);
+        if (pushA || pushB) pq_next[qn] = p;
+    }
+}
+
+__global__ void wf_swap(uint32_t *ctr) {
+    ctr[C_RQ_CUR] = ctr[C_RQ_NEXT]; ctr[C_RQ_NEXT] = 0;
+    ctr[C_PQ_CUR] = ctr[C_PQ_NEXT]; ctr[C_PQ_NEXT] = 0;
+    ctr[C_HEAD] = 0;
+}
+
+struct LdsAddW {
+    __device__ __forceinline__ void operator()(float *p, float v) const { atomicAdd(p, v); }
+};
+
+__global__ __launch_bounds__(kB) void wf_splat(DevScene sc, WfBuf b, WfBatch bt, const float *__restrict__ filter_table, float *rgbw) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tile = reinterpret_cast<float *>(smem);
+    const int tile_w = bt.tile_w, tile_floats = tile_w * tile_w * 4;
+    float *ftab = tile + tile_floats;
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(ftab + 48);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < tile_floats; i += kB) tile[i] = 0.0f;
+    if (tid <= kFilterRes) ftab[tid] = filter_table[tid];
+    if (tid == 0) cnt[0] = 0u;
+    __syncthreads();
+    const uint32_t tsel = blockIdx.x;
+    const uint32_t tile_id = bt.tile_rem + (bt.tile_first + tsel) * bt.tile_mod;
+    const int x0 = (int) (tile_id % bt.tiles_x) * kTile, y0 = (int) (tile_id / bt.tiles_x) * kTile;
+    const float radius = sc.filter.radius, lookup = sc.filter.lookup_factor;
+    const int border = sc.filter.border;
+    const size_t first = (size_t) tsel * 256u * bt.n_spp;
+    uint32_t invalid = 0;
+    for (uint32_t s = 0; s < bt.n_spp; ++s) {
+        const size_t p = first + (size_t) s * 256u + (size_t) tid;
+        const f4 l = b.samp_L[p];
+        if (l.w != 1.0f) continue;
+        const f3 L = mk3(l.x, l.y, l.z);
+        if (color_valid(L)) splat_tile(tile, tile_w, x0, y0, ftab, radius, lookup, border, b.samp_pos[p], L, LdsAddW());
+        else ++invalid;
+    }
+    if (invalid) atomicAdd(&cnt[0], invalid);
+    __syncthreads();
+    const int cols = sc.camera.width + 2 * border, rows = sc.camera.height + 2 * border;
+    for (int i = tid; i < tile_w * tile_w; i += kB) {
+        const int ty = i / tile_w, tx = i - ty * tile_w;
+        const int gx = x0 + tx, gy = y0 + ty;
+        if (gx >= cols || gy >= rows) continue;
+        const float *p = tile + (i << 2);
+        if (p[3] == 0.0f && p[0] == 0.0f && p[1] == 0.0f && p[2] == 0.0f) continue;
+        float *dst = rgbw + (((size_t) gy * cols + gx) << 2);
+        unsafeAtomicAdd(dst + 0, p[0]); unsafeAtomicAdd(dst + 1, p[1]);
+        unsafeAtomicAdd(dst + 2, p[2]); unsafeAtomicAdd(dst + 3, p[3]);
+    }
+    if (tid == 0 && cnt[0]) atomicAdd(&b.stats[S_INVALID], (unsigned long long) cnt[0]);
+}
+
+/* ----------------------------------------------------------- host driver */
+struct Pool {
+    std::vector<void *> allocs;
+    size_t capacity = 0;       /* paths */
+    size_t bytes = 0;
+    WfBuf buf;
+    uint32_t *h_ctr = nullptr; /* pinned */
+    int device = -1;
+    void release() {
+        for (void *p : allocs) (void) hipFree(p);
+        allocs.clear(); capacity = 0; bytes = 0;
+        if (h_ctr) { (void) hipHostFree(h_ctr); h_ctr = nullptr; }
+    }
+};
+Pool g_pool;
+
+#define WF_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e__); } while (0)
+
+template <class T> std::string pool_alloc(T **out, size_t count) {
+    void *p = nullptr;
+    WF_TRY(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
+    g_pool.allocs.push_back(p); g_pool.bytes += count * sizeof(T);
+    *out = reinterpret_cast<T *>(p);
+    return std::string();
+}
+
+std::string ensure_pool(size_t paths) {
+    int dev = 0; (void) hipGetDevice(&dev);
+    if (g_pool.capacity >= paths && g_pool.device == dev) return std::string();
+    g_pool.release();
+    g_pool.device = dev;
+    WfBuf &b = g_pool.buf;
+    std::string e;
+#define A(field, count) if (!(e = pool_alloc(&b.field, (count))).empty()) return e
+    A(ray_o, paths); A(rayA_d, paths); A(rayB_d, paths); A(hitA, paths); A(hitB, paths);
+    A(T_eta, paths); A(L_pdf, paths); A(Ld, paths); A(flags, paths); A(rng, paths);
+    A(samp_pos, paths); A(samp_L, paths);
+    A(rq[0], 2 * paths); A(rq[1], 2 * paths); A(pq[0], paths); A(pq[1], paths);
+    A(ctr, (size_t) C_COUNT); A(stats, (size_t) S_COUNT);
+#undef A
+    WF_TRY(hipHostMalloc((void **) &g_pool.h_ctr, C_COUNT * sizeof(uint32_t)));
+    g_pool.capacity = paths;
+    return std::string();
+}
+
+template <int STACK, bool COUNT>
+void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((wf_extend<STACK, COUNT>), dim3(grid), dim3(kB), STACK * kB * sizeof(int), s, sc, b, cur, refill);
+}
+
+void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int stack, bool count, hipStream_t s) {
+    /* persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy */
+    const int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / (stack * kB * sizeof(int) + 64))));
+    const int grid = 256 * per_cu;
+#define E(S) if (count) launch_extend<S, true>(sc, b, cur, refill, grid, s); else launch_extend<S, false>(sc, b, cur, refill, grid, s)
+    if (stack <= 16) { E(16); } else if (stack <= 24) { E(24); } else if (stack <= 32) { E(32); } else { E(64); }
+#undef E
+}
+
+void launch_shade(const DevScene &sc, const WfBuf &b, int cur, uint32_t s_first, uint32_t n_spp, hipStream_t s) {
+    const dim3 grid(4096), block(kB);
+    switch (sc.integrator.type) {
+#define SH(I) case I: hipLaunchKernelGGL((wf_shade<I>), grid, block, 0, s, sc, b, cur, s_first, n_spp); break;
+        SH(0) SH(1) SH(2) SH(3) SH(4) SH(5) SH(6)
+#undef SH
+    }
+}
+
+} // namespace
+
+namespace nrt {
+
+void wavefront_release() { g_pool.release(); }
+
+std::string wavefront_render(const DevScene &sc, const float *d_filter_table, const WfLaunch &L, float *d_rgbw, void *stream_, WfStats &stats) {
+    hipStream_t s = (hipStream_t) stream_;
+    stats = WfStats();
+    if (L.n_sel_tiles == 0 || L.spp_count == 0) return std::string();
+    /* batch geometry: all selected tiles x as many samples per pixel as fit */
+    size_t max_paths = std::max<size_t>(L.max_paths, 256);
+    uint32_t tiles_b = L.n_sel_tiles, spp_b = L.spp_count;
+    if ((size_t) tiles_b * 256 > max_paths) { tiles_b = (uint32_t) (max_paths / 256); spp_b = 1; }
+    else spp_b = (uint32_t) std::min<size_t>(L.spp_count, std::max<size_t>(1, max_paths / ((size_t) tiles_b * 256)));
+    const size_t paths = (size_t) tiles_b * 256 * spp_b;
+    std::string err = ensure_pool(paths);
+    if (!err.empty()) return err;
+    const WfBuf &b = g_pool.buf;
+    stats.state_bytes = g_pool.bytes;
+    WF_TRY(hipMemsetAsync(b.stats, 0, S_COUNT * sizeof(unsigned long long), s));
+    int refill = 24;
+    if (const char *e = getenv("NORI_HIP_WF_REFILL")) refill = std::min(64, std::max(1, atoi(e)));
+    const size_t splat_lds = sizeof(float) * ((size_t) L.tile_w * L.tile_w * 4 + 48 + 8);
+
+    for (uint32_t t0 = 0; t0 < L.n_sel_tiles; t0 += tiles_b) {
+        const uint32_t nt = std::min(tiles_b, L.n_sel_tiles - t0);
+        for (uint32_t s0 = 0; s0 < L.spp_count; s0 += spp_b) {
+            const uint32_t ns = std::min(spp_b, L.spp_count - s0);
+            WfBatch bt;
+            bt.tile_first = t0; bt.n_tiles = nt; bt.s_first = L.spp_begin + s0; bt.n_spp = ns;
+            bt.tile_mod = L.tile_mod; bt.tile_rem = L.tile_rem; bt.tiles_x = L.tiles_x; bt.tile_w = L.tile_w;
+            WF_TRY(hipMemsetAsync(b.ctr, 0, C_COUNT * sizeof(uint32_t), s));
+            const size_t n = (size_t) nt * 256 * ns;
+            hipLaunchKernelGGL(wf_generate, dim3((unsigned) std::min<size_t>((n + kB - 1) / kB, 8192)), dim3(kB), 0, s, sc, b, bt);
+            stats.n_launches++; stats.n_batches++;
+            int cur = 0;
+            while (true) {
+                for (int k = 0; k < 6; ++k) {
+                    launch_extend_dyn(sc, b, cur, refill, L.stack_depth, L.count_traversal, s);
+                    launch_shade(sc, b, cur, bt.s_first, ns, s);
+                    hipLaunchKernelGGL(wf_swap, dim3(1), dim3(1), 0, s, b.ctr);
+                    cur ^= 1;
+                    stats.n_iterations++; stats.n_launches += 3;
+                }
+                WF_TRY(hipMemcpyAsync(g_pool.h_ctr, b.ctr, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+                WF_TRY(hipStreamSynchronize(s));
+                if (g_pool.h_ctr[C_PQ_CUR] == 0) break;
+                if (stats.n_iterations > 100000) return "wavefront: path loop did not terminate";
+            }
+            hipLaunchKernelGGL(wf_splat, dim3(nt), dim3(kB), splat_lds, s, sc, b, bt, d_filter_table, d_rgbw);
+            stats.n_launches++;
+            WF_TRY(hipGetLastError());
+        }
+    }
+    unsigned long long h[S_COUNT];
+    WF_TRY(hipMemcpyAsync(h, b.stats, sizeof(h), hipMemcpyDeviceToHost, s));
+    WF_TRY(hipStreamSynchronize(s));
+    stats.n_camera = h[S_CAM]; stats.n_closest = h[S_CLOSEST]; stats.n_shadow = h[S_SHADOW];
+    stats.n_nodes = h[S_NODES]; stats.n_tris = h[S_TRIS]; stats.n_invalid = h[S_INVALID];
+    return std::string();
+}
+
+} // namespace nrt

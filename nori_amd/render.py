@@ -77,6 +77,9 @@ class Renderer:
     def build_accel(self, builder: int = 0):
         self._check(self._lib.nori_hip_build_accel(self._h, int(builder)), "build_accel")
 
+    def set_option(self, key: str, value) -> None:
+        self._check(self._lib.nori_hip_set_option(self._h, key.encode(), str(value).encode()), f"set_option({key})")
+
     def accel_info(self) -> dict:
         info = capi.AccelInfo()
         self._check(self._lib.nori_hip_accel_info(self._h, C.byref(info)), "accel_info")
