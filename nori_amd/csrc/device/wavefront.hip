@@ -106,6 +106,7 @@ __device__ __forceinline__ void tile_pixel(int pix, int x0, int y0, int &px, int
 __global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch bt) {
     const uint32_t per_tile = 256u * bt.n_spp;
     const uint32_t n = bt.n_tiles * per_tile;
+    uint32_t n_live = 0;        /* per wave */
     for (uint32_t base = blockIdx.x * kB; base < n; base += gridDim.x * kB) {
         const uint32_t p = base + threadIdx.x;
         bool live = p < n;
@@ -137,13 +138,17 @@ __global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch 
                 b.rng[p] = rng.state;
             }
         }
-        const uint32_t r = wave_alloc(&b.ctr[C_RQ_CUR], live);
-        if (live) b.rq[0][r] = p << 1;
-        const uint32_t q = wave_alloc(&b.ctr[C_PQ_CUR], live);
-        if (live) b.pq[0][q] = p;
-        const unsigned long long lm = __ballot(live);
-        if (lane_id() == 0 && lm) atomicAdd(&b.stats[S_CAM], (unsigned long long) __popcll(lm));
+        /* first queues are the identity (no compaction atomics): pixels of edge tiles
+           that fall outside the image carry flags == 0 and are skipped downstream */
+        if (p < n) {
+            if (!live) b.flags[p] = 0u;
+            b.rq[0][p] = p << 1;
+            b.pq[0][p] = p;
+        }
+        n_live += (uint32_t) __popcll(__ballot(live));
     }
+    if (threadIdx.x == 0) { b.ctr[C_RQ_CUR] = n; b.ctr[C_PQ_CUR] = n; }      /* same value from every block */
+    if (lane_id() == 0 && n_live) atomicAdd(&b.stats[S_CAM], (unsigned long long) n_live);
 }
 
 template <int STACK, bool COUNT>
@@ -157,21 +162,31 @@ __global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, i
     Trav tv; tv.active = false; tv.node = 0;
     uint32_t rid = 0;
     bool exhausted = n == 0;
+    constexpr uint32_t kChunk = 1024u;
+    uint32_t chunk_pos = 0u, chunk_end = 0u;       /* wave-uniform */
     uint32_t nClosest = 0, nShadow = 0;
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
     while (true) {
         const unsigned long long idle = __ballot(!tv.active);
         const int nIdle = __popcll(idle);
         if (!exhausted && (nIdle >= refill_threshold || nIdle == 64)) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&b.ctr[C_HEAD], (uint32_t) nIdle);
-            base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
-            if (!tv.active) {
-                const uint32_t my = base + (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
-                if (my < n) {
-                    rid = rq[my];
-                    const uint32_t p = rid >> 1;
-                    const bool any = (rid & 1u) != 0u;
+            /* The wave owns a chunk [chunk_pos, chunk_end) of the ray queue and hands it out
+               to idle lanes; one global atomic per kChunk rays (a single hot word sustains
+               only ~90 atomics/us -- MI355X_MICROARCH.md, row "dequeue"). */
+            if (chunk_pos >= chunk_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&b.ctr[C_HEAD], kChunk);
+                base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                chunk_pos = base; chunk_end = min(base + kChunk, n);
+                if (base >= n) { exhausted = true; chunk_pos = chunk_end = 0u; }
+            }
+            const uint32_t avail = chunk_end - chunk_pos;
+            const uint32_t rank = (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
+            if (!tv.active && rank < avail) {
+                rid = rq[chunk_pos + rank];
+                const uint32_t p = rid >> 1;
+                const bool any = (rid & 1u) != 0u;
+                if (b.flags[p] & (any ? F_HAS_B : F_HAS_A)) {     /* 0 for pixels outside the image */
                     const f4 o = b.ray_o[p];
                     const f4 d = any ? b.rayB_d[p] : b.rayA_d[p];
                     RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z);
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, i
                     }
                 }
             }
-            if (base + (uint32_t) nIdle >= n) exhausted = true;
+            chunk_pos += min(avail, (uint32_t) nIdle);
         }
         if (__ballot(tv.active) == 0ull) {
             if (exhausted) break;
@@ -216,6 +231,10 @@ __global__ __launch_bounds__(kB) void wf_shade(DevScene sc, WfBuf b, int cur, ui
     const uint32_t n = b.ctr[C_PQ_CUR];
     const uint32_t *pq = b.pq[cur];
     uint32_t *rq_next = b.rq[cur ^ 1], *pq_next = b.pq[cur ^ 1];
+    constexpr uint32_t kStageRq = 4096u, kStagePq = 2048u;
+    __shared__ uint32_t s_rq[kStageRq], s_pq[kStagePq], s_n[4];
+    if (threadIdx.x < 4) s_n[threadIdx.x] = 0u;
+    __syncthreads();
     for (uint32_t base = blockIdx.x * kB; base < n; base += gridDim.x * kB) {
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < n;
@@ -224,6 +243,7 @@ __global__ __launch_bounds__(kB) void wf_shade(DevScene sc, WfBuf b, int cur, ui
         if (valid) {
             p = pq[i];
             const uint32_t fl = b.flags[p];
+            if (fl & (F_HAS_A | F_HAS_B)) {       /* flags == 0: pixel outside the image (identity first queue) */
             f4 L4 = b.L_pdf[p];
             bool done = false;
             if (fl & F_HAS_B) {                       /* path_on_shadow: add the emitter sample if unoccluded */
@@ -287,13 +307,27 @@ __global__ __launch_bounds__(kB) void wf_shade(DevScene sc, WfBuf b, int cur, ui
                 f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 1.0f;
                 b.samp_L[p] = out;
             }
+            }
         }
-        const uint32_t ra = wave_alloc(&b.ctr[C_RQ_NEXT], pushA);
-        if (pushA) rq_next[ra] = p << 1;
-        const uint32_t rb = wave_alloc(&b.ctr[C_RQ_NEXT], pushB);
-        if (pushB) rq_next[rb] = (p << 1) | 1u;
-        const uint32_t qn = wave_alloc(&b.ctr[C_PQ_NEXT], pushA || pushB);
-        if (pushA || pushB) pq_next[qn] = p;
+        /* compaction: stage the new queue entries of several rounds in LDS, then reserve
+           their place in the global queues with ONE atomic per queue per flush */
+        if (pushA) s_rq[atomicAdd(&s_n[0], 1u)] = p << 1;
+        if (pushB) s_rq[atomicAdd(&s_n[0], 1u)] = (p << 1) | 1u;
+        if (pushA || pushB) s_pq[atomicAdd(&s_n[1], 1u)] = p;
+        __syncthreads();
+        const bool last = base + gridDim.x * kB >= n;
+        if (s_n[0] + 2 * kB > kStageRq || last) {
+            if (threadIdx.x == 0) {
+                s_n[2] = s_n[0] ? atomicAdd(&b.ctr[C_RQ_NEXT], s_n[0]) : 0u;
+                s_n[3] = s_n[1] ? atomicAdd(&b.ctr[C_PQ_NEXT], s_n[1]) : 0u;
+            }
+            __syncthreads();
+            for (uint32_t k = threadIdx.x; k < s_n[0]; k += kB) rq_next[s_n[2] + k] = s_rq[k];
+            for (uint32_t k = threadIdx.x; k < s_n[1]; k += kB) pq_next[s_n[3] + k] = s_pq[k];
+            __syncthreads();
+            if (threadIdx.x == 0) { s_n[0] = 0u; s_n[1] = 0u; }
+            __syncthreads();
+        }
     }
 }
 
@@ -307,7 +341,7 @@ struct LdsAddW {
     __device__ __forceinline__ void operator()(float *p, float v) const { atomicAdd(p, v); }
 };
 
-__global__ __launch_bounds__(kB) void wf_splat(DevScene sc, WfBuf b, WfBatch bt, const float *__restrict__ filter_table, float *rgbw) {
+__global__ __launch_bounds__(kB) void wf_splat(DevScene sc, WfBuf b, WfBatch bt, const float *__restrict__ filter_table, float *tile_acc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *tile = reinterpret_cast<float *>(smem);
     const int tile_w = bt.tile_w, tile_floats = tile_w * tile_w * 4;
@@ -335,18 +369,41 @@ __global__ __launch_bounds__(kB) void wf_splat(DevScene sc, WfBuf b, WfBatch bt,
     }
     if (invalid) atomicAdd(&cnt[0], invalid);
     __syncthreads();
-    const int cols = sc.camera.width + 2 * border, rows = sc.camera.height + 2 * border;
-    for (int i = tid; i < tile_w * tile_w; i += kB) {
-        const int ty = i / tile_w, tx = i - ty * tile_w;
-        const int gx = x0 + tx, gy = y0 + ty;
-        if (gx >= cols || gy >= rows) continue;
-        const float *p = tile + (i << 2);
-        if (p[3] == 0.0f && p[0] == 0.0f && p[1] == 0.0f && p[2] == 0.0f) continue;
-        float *dst = rgbw + (((size_t) gy * cols + gx) << 2);
-        unsafeAtomicAdd(dst + 0, p[0]); unsafeAtomicAdd(dst + 1, p[1]);
-        unsafeAtomicAdd(dst + 2, p[2]); unsafeAtomicAdd(dst + 3, p[3]);
+    /* ImageBlock::put(ImageBlock&), first half: add this batch's tile to the tile's own
+       accumulator in HBM (single writer -> no atomics); wf_resolve merges the overlapping
+       borders of neighbouring tiles into the frame once, in a fixed order */
+    float *acc = tile_acc + (size_t) (bt.tile_first + tsel) * tile_floats;
+    for (int i = tid; i < tile_floats; i += kB) {
+        const float v = tile[i];
+        if (v != 0.0f) acc[i] += v;
     }
     if (tid == 0 && cnt[0]) atomicAdd(&b.stats[S_INVALID], (unsigned long long) cnt[0]);
+}
+
+/* ImageBlock::put(ImageBlock&), second half: every frame pixel gathers the (at most four)
+   tile accumulators whose bordered area covers it -- deterministic summation order */
+__global__ void wf_resolve(int width, int height, int border, int tile_w, uint32_t tiles_x, uint32_t tiles_y,
+                           uint32_t tile_mod, uint32_t tile_rem, const float *tile_acc, float *rgbw) {
+    const int cols = width + 2 * border, rows = height + 2 * border;
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x, gy = blockIdx.y;
+    if (gx >= cols || gy >= rows) return;
+    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int tx1 = min(gx / kTile, (int) tiles_x - 1), ty1 = min(gy / kTile, (int) tiles_y - 1);
+    const int tx0 = max(0, (gx - tile_w + kTile) / kTile), ty0 = max(0, (gy - tile_w + kTile) / kTile);
+    for (int ty = ty0; ty <= ty1; ++ty)
+        for (int tx = tx0; tx <= tx1; ++tx) {
+            const int lx = gx - tx * kTile, ly = gy - ty * kTile;
+            if (lx < 0 || ly < 0 || lx >= tile_w || ly >= tile_w) continue;
+            const uint32_t tile_id = (uint32_t) ty * tiles_x + (uint32_t) tx;
+            if (tile_id < tile_rem || (tile_id - tile_rem) % tile_mod != 0u) continue;
+            const uint32_t ord = (tile_id - tile_rem) / tile_mod;
+            const float4 v = *reinterpret_cast<const float4 *>(tile_acc + ((size_t) ord * tile_w * tile_w + (size_t) ly * tile_w + lx) * 4);
+            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+        }
+    float4 *dst = reinterpret_cast<float4 *>(rgbw) + (size_t) gy * cols + gx;
+    float4 cur = *dst;
+    cur.x += sum.x; cur.y += sum.y; cur.z += sum.z; cur.w += sum.w;
+    *dst = cur;
 }
 
 /* ----------------------------------------------------------- host driver */
@@ -356,10 +413,12 @@ struct Pool {
     size_t bytes = 0;
     WfBuf buf;
     uint32_t *h_ctr = nullptr; /* pinned */
+    float *tile_acc = nullptr; size_t tile_acc_floats = 0;
     int device = -1;
     void release() {
         for (void *p : allocs) (void) hipFree(p);
         allocs.clear(); capacity = 0; bytes = 0;
+        if (tile_acc) { (void) hipFree(tile_acc); tile_acc = nullptr; tile_acc_floats = 0; }
         if (h_ctr) { (void) hipHostFree(h_ctr); h_ctr = nullptr; }
     }
 };
@@ -441,6 +500,14 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     int refill = 24;
     if (const char *e = getenv("NORI_HIP_WF_REFILL")) refill = std::min(64, std::max(1, atoi(e)));
     const size_t splat_lds = sizeof(float) * ((size_t) L.tile_w * L.tile_w * 4 + 48 + 8);
+    const size_t acc_floats = (size_t) L.n_sel_tiles * L.tile_w * L.tile_w * 4;
+    if (g_pool.tile_acc_floats < acc_floats) {
+        if (g_pool.tile_acc) (void) hipFree(g_pool.tile_acc);
+        g_pool.tile_acc = nullptr; g_pool.tile_acc_floats = 0;
+        WF_TRY(hipMalloc((void **) &g_pool.tile_acc, acc_floats * sizeof(float)));
+        g_pool.tile_acc_floats = acc_floats;
+    }
+    WF_TRY(hipMemsetAsync(g_pool.tile_acc, 0, acc_floats * sizeof(float), s));
 
     for (uint32_t t0 = 0; t0 < L.n_sel_tiles; t0 += tiles_b) {
         const uint32_t nt = std::min(tiles_b, L.n_sel_tiles - t0);
@@ -467,10 +534,16 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
                 if (g_pool.h_ctr[C_PQ_CUR] == 0) break;
                 if (stats.n_iterations > 100000) return "wavefront: path loop did not terminate";
             }
-            hipLaunchKernelGGL(wf_splat, dim3(nt), dim3(kB), splat_lds, s, sc, b, bt, d_filter_table, d_rgbw);
+            hipLaunchKernelGGL(wf_splat, dim3(nt), dim3(kB), splat_lds, s, sc, b, bt, d_filter_table, g_pool.tile_acc);
             stats.n_launches++;
             WF_TRY(hipGetLastError());
         }
+    }
+    {
+        const int border = sc.filter.border, cols = sc.camera.width + 2 * border, rows = sc.camera.height + 2 * border;
+        hipLaunchKernelGGL(wf_resolve, dim3((cols + 255) / 256, rows), dim3(256), 0, s, sc.camera.width, sc.camera.height, border,
+                           L.tile_w, L.tiles_x, L.tiles_y, L.tile_mod, L.tile_rem, (const float *) g_pool.tile_acc, d_rgbw);
+        stats.n_launches++;
     }
     unsigned long long h[S_COUNT];
     WF_TRY(hipMemcpyAsync(h, b.stats, sizeof(h), hipMemcpyDeviceToHost, s));
