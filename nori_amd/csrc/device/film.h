@@ -1,0 +1,60 @@
+/*
+ * film.h -- ImageBlock on the device: sample store, filtered splat, block merge.
+ *
+ * Both render engines finish a camera sample by storing (pixelSample, radiance)
+ * -- 24 B -- into a sample store in HBM laid out tile-major:
+ *     index = (tile_ordinal * n_spp + sample_in_launch) * 256 + pixel_in_tile
+ * (pixel_in_tile uses the 8x8-quad numbering of film_tile_pixel).  Then
+ *   film_gather   one workgroup per tile: ImageBlock::put(pos, value)
+ *                 (src/block.cpp:62-91) turned from a scatter into a gather --
+ *                 every pixel of the tile's bordered block sums, in a fixed
+ *                 order, the samples of the tile that reach it, with the
+ *                 reference's own block-relative weights.  No atomics (measured:
+ *                 ds_add_f32 splatting cost 22 % of the render kernel).
+ *                 The block is added to the tile's private accumulator in HBM.
+ *   film_resolve  ImageBlock::put(ImageBlock&) (src/block.cpp:93-102): every
+ *                 frame pixel gathers the <= 4 tile accumulators that cover it.
+ * Deterministic: the same inputs give the same bits, independent of scheduling.
+ */
+#pragma once
+#include <string>
+
+#include "rt_types.h"
+
+namespace nrt {
+
+struct FilmStore {
+    f2 *pos = nullptr;          /* pixelSample */
+    f4 *L = nullptr;            /* radiance rgb, w unused */
+    size_t capacity = 0;        /* samples */
+    float *tile_acc = nullptr;  /* n_tiles x tile_w^2 x 4 */
+    size_t acc_floats = 0;
+    unsigned long long *d_invalid = nullptr;
+};
+
+struct FilmLaunch {
+    uint32_t tile_first, n_tiles;   /* ordinals (within the selected tiles) handled by this gather */
+    uint32_t store_tile_first;      /* ordinal of the tile whose samples start at index 0 of the store */
+    uint32_t n_spp;                 /* samples per pixel present in the store */
+    uint32_t tile_mod, tile_rem, tiles_x, tiles_y;
+    int32_t tile_w;
+};
+
+/* pixel of index `pix` (0..255) inside the tile at (x0, y0): wave w covers the 8x8 quad (w&1, w>>1) */
+NORI_HD void film_tile_pixel(int pix, int x0, int y0, int &px, int &py) {
+    const int wave = pix >> 6, lane = pix & 63;
+    px = x0 + ((wave & 1) << 3) + (lane & 7);
+    py = y0 + ((wave >> 1) << 3) + (lane >> 3);
+}
+
+/* (Re)allocate the process-wide store; zeroes the tile accumulators.  "" or an error. */
+std::string film_prepare(size_t n_samples, size_t n_sel_tiles, int tile_w, void *stream, FilmStore &out);
+/* splat the store's samples of tiles [tile_first, tile_first + n_tiles) into their accumulators */
+void film_gather(const DevScene &sc, const float *d_filter_table, const FilmStore &st, const FilmLaunch &fl, void *stream);
+/* add all accumulators into the caller's RGBW frame */
+void film_resolve(const DevScene &sc, const FilmStore &st, const FilmLaunch &fl, float *d_rgbw, void *stream);
+/* samples dropped by the isValid() guard (src/block.cpp:63-67) since film_prepare; synchronises `stream` */
+unsigned long long film_invalid_count(const FilmStore &st, void *stream);
+void film_release();
+
+} // namespace nrt

@@ -31,7 +31,7 @@
 #include <vector>
 
 #include "../../../include/nori_hip.h"
-#include "rt_film.h"
+#include "film.h"
 #include "rt_path.h"
 #include "scene_prep.h"
 #include "lbvh.h"
@@ -70,27 +70,18 @@ struct RenderArgs {
     uint32_t n_chunks;          /* spp chunks per tile                     */
     uint32_t chunk_spp;
     int32_t tile_w;             /* kTile + 2 * border                      */
+    uint32_t debug_flags;       /* bit0: skip the filtered splat (experiments only) */
     uint32_t th_shade, th_inner, th_leaf;   /* lanes of a wave that must want a kind of work for it to run */
 };
 
-struct LdsAdd {
-    __device__ __forceinline__ void operator()(float *p, float v) const { atomicAdd(p, v); }
-};
-
 template <int INTEG, int STACK, bool COUNT>
-__global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(DevScene sc, RenderArgs args, const float *__restrict__ filter_table,
-                                                        float *rgbw, unsigned long long *stats) {
+__global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(DevScene sc, RenderArgs args, FilmStore film,
+                                                        unsigned long long *stats) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int *lds_stack = reinterpret_cast<int *>(smem);
-    float *tile = reinterpret_cast<float *>(smem + sizeof(int) * STACK * kBlock);
-    const int tile_w = args.tile_w;
-    const int tile_floats = tile_w * tile_w * 4;
-    float *ftab = tile + tile_floats;
-    unsigned int *cnt = reinterpret_cast<unsigned int *>(ftab + 48);
+    unsigned int *cnt = reinterpret_cast<unsigned int *>(smem + sizeof(int) * STACK * kBlock);
 
     const int tid = threadIdx.x;
-    for (int i = tid; i < tile_floats; i += kBlock) tile[i] = 0.0f;
-    if (tid <= kFilterRes) ftab[tid] = filter_table[tid];
     if (tid < 16) cnt[tid] = 0u;
     __syncthreads();
 
@@ -115,10 +106,8 @@ __global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(D
     st.ray.o = st.ray.d = mk3(0.0f); st.ray.mint = st.ray.maxt = 0.0f;
     f2 pixelSample = mk2(0.0f, 0.0f);
     uint32_t s = s0;
-    uint32_t nCam = 0, nClosest = 0, nShadow = 0, nInvalid = 0;
+    uint32_t nCam = 0, nClosest = 0, nShadow = 0;
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
-    const float radius = sc.filter.radius, lookup = sc.filter.lookup_factor;
-    const int border = sc.filter.border;
 
     /* Persistent loop.  At any time a lane wants exactly one of three kinds of
        work: SHADE (its query finished: consume the result, splat, regenerate a
@@ -155,8 +144,12 @@ __global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(D
                 if (st.phase == PH_SHADOW) done = path_on_shadow(st, tv.hit.tri != kNoHit, tv.o);
                 else done = path_on_closest<INTEG>(sc, st, tv.hit, tv.hit.tri != kNoHit, tv.d);
                 if (done) {
-                    if (color_valid(st.L)) splat_tile(tile, tile_w, x0, y0, ftab, radius, lookup, border, pixelSample, st.L, LdsAdd());
-                    else ++nInvalid;
+                    /* block.put(pixelSample, value), src/main.cpp:52: the sample goes to the film's
+                       store (24 B); film_gather applies the reconstruction filter afterwards */
+                    const size_t idx = ((size_t) sel * args.spp_count + (size_t) (s - 1u - args.spp_begin)) * 256u + (size_t) tid;
+                    film.pos[idx] = pixelSample;
+                    f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 0.0f;
+                    film.L[idx] = out;
                     gen = true;
                 }
             }
@@ -186,22 +179,8 @@ __global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(D
     }
 
     atomicAdd(&cnt[0], nCam); atomicAdd(&cnt[1], nClosest); atomicAdd(&cnt[2], nShadow);
-    atomicAdd(&cnt[5], nInvalid);
     if (COUNT) { atomicAdd(&cnt[3], tc.nodes); atomicAdd(&cnt[4], tc.tris); }
     __syncthreads();
-
-    /* ImageBlock::put(ImageBlock&): merge tile + border into the frame */
-    const int cols = sc.camera.width + 2 * border, rows = sc.camera.height + 2 * border;
-    for (int i = tid; i < tile_w * tile_w; i += kBlock) {
-        const int ty = i / tile_w, tx = i - ty * tile_w;
-        const int gx = x0 + tx, gy = y0 + ty;           /* frame coords incl. border */
-        if (gx >= cols || gy >= rows) continue;
-        const float *p = tile + (i << 2);
-        if (p[3] == 0.0f && p[0] == 0.0f && p[1] == 0.0f && p[2] == 0.0f) continue;
-        float *dst = rgbw + (((size_t) gy * cols + gx) << 2);
-        unsafeAtomicAdd(dst + 0, p[0]); unsafeAtomicAdd(dst + 1, p[1]);
-        unsafeAtomicAdd(dst + 2, p[2]); unsafeAtomicAdd(dst + 3, p[3]);
-    }
     if (tid < 16 && cnt[tid] != 0u) atomicAdd(&stats[tid], (unsigned long long) cnt[tid]);
 }
 
@@ -428,6 +407,7 @@ void nori_hip_destroy(nori_hip_ctx *ctx) {
     DeviceGuard g(ctx->device);
     free_pool(ctx->allocs_scene); free_pool(ctx->allocs_accel);
     wavefront_release();
+    film_release();
     if (ctx->d_stats) (void) hipFree(ctx->d_stats);
     delete ctx;
 }
@@ -741,25 +721,37 @@ int nori_hip_splat(nori_hip_ctx *ctx, const float *positions, const float *value
 
 /* ---------------------------------------------------------------- render */
 template <int STACK>
-static size_t render_lds_bytes(const RenderArgs &a) {
-    return sizeof(int) * STACK * kBlock + sizeof(float) * ((size_t) a.tile_w * a.tile_w * 4 + 48 + 16);
+static size_t render_lds_bytes(const RenderArgs &) {
+    return sizeof(int) * STACK * kBlock + sizeof(unsigned int) * 16;       /* traversal stacks + counters */
 }
 
 template <int INTEG, int STACK, bool COUNT>
-static hipError_t launch_render_one(nori_hip_ctx *ctx, const RenderArgs &a, float *d_rgbw, hipStream_t s) {
+static hipError_t launch_render_one(nori_hip_ctx *ctx, const RenderArgs &a, const FilmStore &film, hipStream_t s) {
     const size_t lds = render_lds_bytes<STACK>(a);
     auto kern = render_kernel<INTEG, STACK, COUNT>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_sel_tiles * a.n_chunks), dim3(kBlock), lds, s, ctx->dev, a,
-                       (const float *) ctx->d_filter, d_rgbw, ctx->d_stats);
+    hipLaunchKernelGGL(kern, dim3(a.n_sel_tiles * a.n_chunks), dim3(kBlock), lds, s, ctx->dev, a, film, ctx->d_stats);
     return hipGetLastError();
 }
 
+/* spp chunking: one workgroup per (tile, chunk of samples); enough workgroups for the dispatcher
+   to balance load (measured best around 16 k), at least 8 spp per chunk */
+static void plan_chunks(RenderArgs &a) {
+    uint32_t target_wgs = 16384;
+    if (const char *e = getenv("NORI_HIP_TARGET_WGS")) target_wgs = (uint32_t) std::max(1, atoi(e));
+    uint32_t n_chunks = 1;
+    if (a.n_sel_tiles > 0 && a.n_sel_tiles < target_wgs) n_chunks = (target_wgs + a.n_sel_tiles - 1) / a.n_sel_tiles;
+    n_chunks = std::max(1u, std::min(n_chunks, std::max(1u, a.spp_count / 8)));
+    a.chunk_spp = (a.spp_count + n_chunks - 1) / std::max(1u, n_chunks);
+    if (a.chunk_spp == 0) a.chunk_spp = 1;
+    a.n_chunks = std::max(1u, (a.spp_count + a.chunk_spp - 1) / a.chunk_spp);
+}
+
 template <int STACK, bool COUNT>
-static hipError_t launch_render(nori_hip_ctx *ctx, const RenderArgs &a, float *d_rgbw, hipStream_t s) {
+static hipError_t launch_render(nori_hip_ctx *ctx, const RenderArgs &a, const FilmStore &d_rgbw, hipStream_t s) {
     switch (ctx->dev.integrator.type) {
     case 0: return launch_render_one<0, STACK, COUNT>(ctx, a, d_rgbw, s);
     case 1: return launch_render_one<1, STACK, COUNT>(ctx, a, d_rgbw, s);
@@ -791,18 +783,12 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
     a.n_sel_tiles = n_tiles > a.tile_rem ? (n_tiles - a.tile_rem + a.tile_mod - 1) / a.tile_mod : 0;
     a.tile_w = kTile + 2 * ctx->host.filter.border;
     a.th_shade = 44; a.th_inner = 1; a.th_leaf = 1;
+    a.debug_flags = getenv("NORI_HIP_NOSPLAT") ? 1u : 0u;
     if (const char *e = getenv("NORI_HIP_TH_SHADE")) a.th_shade = (uint32_t) std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NORI_HIP_TH_INNER")) a.th_inner = (uint32_t) std::min(64, std::max(1, atoi(e)));
     if (const char *e = getenv("NORI_HIP_TH_LEAF")) a.th_leaf = (uint32_t) std::min(64, std::max(1, atoi(e)));
-    /* spp chunking: aim for >= ~8 workgroups per CU slot-round, >= 8 spp per chunk */
-    uint32_t target_wgs = 16384;
-    if (const char *e = getenv("NORI_HIP_TARGET_WGS")) target_wgs = (uint32_t) std::max(1, atoi(e));
-    uint32_t n_chunks = 1;
-    if (a.n_sel_tiles > 0 && a.n_sel_tiles < target_wgs) n_chunks = (target_wgs + a.n_sel_tiles - 1) / a.n_sel_tiles;
-    n_chunks = std::max(1u, std::min(n_chunks, std::max(1u, a.spp_count / 8)));
-    a.chunk_spp = (a.spp_count + n_chunks - 1) / std::max(1u, n_chunks);
-    if (a.chunk_spp == 0) a.chunk_spp = 1;
-    a.n_chunks = std::max(1u, (a.spp_count + a.chunk_spp - 1) / a.chunk_spp);
+    plan_chunks(a);
+    unsigned long long n_invalid = 0; uint32_t n_workgroups = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (stats) {
@@ -825,15 +811,37 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
     } else
     if (a.n_sel_tiles > 0 && a.spp_count > 0) {
-        hipError_t e;
+        /* Samples go to the film store (24 B each); if a call produces more than the store
+           budget it is cut into launches over sample sub-ranges, each followed by its splat. */
+        size_t cap = (size_t) 1 << 29;
+        if (const char *e = getenv("NORI_HIP_FILM_SAMPLES")) cap = (size_t) std::max(256ll, atoll(e));
+        const uint32_t spp_per_launch = (uint32_t) std::max<size_t>(1, std::min<size_t>(a.spp_count, cap / ((size_t) a.n_sel_tiles * 256)));
+        FilmStore film;
+        std::string ferr = film_prepare((size_t) a.n_sel_tiles * 256 * spp_per_launch, a.n_sel_tiles, a.tile_w, s, film);
+        if (!ferr.empty()) { ctx->error = ferr; return NORI_ERR_OUT_OF_MEMORY; }
+        FilmLaunch fl;
+        fl.tile_first = 0; fl.store_tile_first = 0; fl.n_tiles = a.n_sel_tiles; fl.tile_mod = a.tile_mod; fl.tile_rem = a.tile_rem;
+        fl.tiles_x = a.tiles_x; fl.tiles_y = a.tiles_y; fl.tile_w = a.tile_w;
         const bool count = params->count_traversal != 0;
         const uint32_t need = ctx->bvh.max_depth + 1;
-        /* the LDS stack is sized to the tree: fewer entries -> more workgroups per CU */
-        if (need <= 16) e = count ? launch_render<16, true>(ctx, a, (float *) d_rgbw, s) : launch_render<16, false>(ctx, a, (float *) d_rgbw, s);
-        else if (need <= 24) e = count ? launch_render<24, true>(ctx, a, (float *) d_rgbw, s) : launch_render<24, false>(ctx, a, (float *) d_rgbw, s);
-        else if (need <= 32) e = count ? launch_render<32, true>(ctx, a, (float *) d_rgbw, s) : launch_render<32, false>(ctx, a, (float *) d_rgbw, s);
-        else e = count ? launch_render<64, true>(ctx, a, (float *) d_rgbw, s) : launch_render<64, false>(ctx, a, (float *) d_rgbw, s);
-        HIP_TRY(ctx, e);
+        for (uint32_t sb = 0; sb < a.spp_count; sb += spp_per_launch) {
+            RenderArgs a2 = a;
+            a2.spp_begin = a.spp_begin + sb; a2.spp_count = std::min(spp_per_launch, a.spp_count - sb);
+            plan_chunks(a2);
+            hipError_t e;
+            /* the LDS stack is sized to the tree: fewer entries -> more workgroups per CU */
+            if (need <= 16) e = count ? launch_render<16, true>(ctx, a2, film, s) : launch_render<16, false>(ctx, a2, film, s);
+            else if (need <= 24) e = count ? launch_render<24, true>(ctx, a2, film, s) : launch_render<24, false>(ctx, a2, film, s);
+            else if (need <= 32) e = count ? launch_render<32, true>(ctx, a2, film, s) : launch_render<32, false>(ctx, a2, film, s);
+            else e = count ? launch_render<64, true>(ctx, a2, film, s) : launch_render<64, false>(ctx, a2, film, s);
+            HIP_TRY(ctx, e);
+            fl.n_spp = a2.spp_count;
+            if (!(a.debug_flags & 1u)) film_gather(ctx->dev, ctx->d_filter, film, fl, s);
+            n_workgroups += a2.n_sel_tiles * a2.n_chunks;
+        }
+        film_resolve(ctx->dev, film, fl, (float *) d_rgbw, s);
+        HIP_TRY(ctx, hipGetLastError());
+        if (stats) n_invalid = film_invalid_count(film, s);
     }
     if (stats) {
         HIP_TRY(ctx, hipEventRecord(ev1, s));
@@ -845,11 +853,11 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         HIP_TRY(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
         memset(stats, 0, sizeof(*stats));
         stats->n_camera_samples = h[0]; stats->n_closest_rays = h[1]; stats->n_shadow_rays = h[2];
-        stats->n_node_tests = h[3]; stats->n_tri_tests = h[4]; stats->n_invalid = h[5];
+        stats->n_node_tests = h[3]; stats->n_tri_tests = h[4]; stats->n_invalid = n_invalid;
         stats->kernel_ms = ms;
         if (getenv("NORI_HIP_CENSUS") && h[8])
             fprintf(stderr, "[census] shade runs %llu lanes %.1f | inner runs %llu lanes %.1f | leaf runs %llu lanes %.1f\n", h[8], (double) h[9] / h[8], h[10], (double) h[11] / std::max(1ull, h[10]), h[12], (double) h[13] / std::max(1ull, h[12]));
-        stats->n_workgroups = a.n_sel_tiles * a.n_chunks;
+        stats->n_workgroups = n_workgroups;
         if (engine == 1) {
             stats->n_camera_samples = wst.n_camera; stats->n_closest_rays = wst.n_closest; stats->n_shadow_rays = wst.n_shadow;
             stats->n_node_tests = wst.n_nodes; stats->n_tri_tests = wst.n_tris; stats->n_invalid = wst.n_invalid;

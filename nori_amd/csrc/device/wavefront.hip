@@ -1,7 +1,7 @@
 /*
  * wavefront.hip -- the wavefront engine of the render path.
  *
- * Same per-lane code as the megakernel (rt_path.h, rt_trace.h, rt_film.h), same
+ * Same per-lane code as the megakernel (rt_path.h, rt_trace.h) and the same film (film.h), same
  * pcg32 streams, therefore the same radiance per camera sample; what changes is
  * how work is laid out for 64-wide waves.  In the megakernel a lane owns a
  * pixel and, when its path needs shading while its neighbours still traverse,
@@ -18,10 +18,9 @@
  *     wf_shade   one lane per live path: consume the shadow result, shade the
  *                closest hit (Integrator::Li state machine), append the next
  *                shadow + continuation rays with wave-aggregated atomics
- *   wf_splat     one workgroup per tile: its samples are contiguous in HBM; the
- *                filtered splat runs in LDS exactly as in the megakernel
- *                (ImageBlock::put, src/block.cpp:62-91) and the tile is merged
- *                into the frame (ImageBlock::put(ImageBlock&), block.cpp:93-102)
+ *   film_gather / film_resolve (film.hip)  the finished samples sit tile-major in the
+ *                film's store; the reconstruction filter and the block merge
+ *                (ImageBlock::put, src/block.cpp:62-102) run as gathers
  *
  * A path vertex costs ONE iteration: its shadow ray (slot B) and continuation
  * ray (slot A) are traced in the same wf_extend pass, and the next wf_shade
@@ -35,7 +34,7 @@
 #include <string>
 #include <vector>
 
-#include "rt_film.h"
+#include "film.h"
 #include "rt_path.h"
 #include "wavefront.h"
 
@@ -60,7 +59,7 @@ struct WfBuf {
     uint32_t *flags;   /* F_* | prev_measure << 4 | depth << 8 */
     unsigned long long *rng;
     f2 *samp_pos;
-    f4 *samp_L;        /* (L.rgb, 1) once the path has finished */
+    f4 *samp_L;        /* the film's sample store (film.h) */
     uint32_t *rq[2];   /* ray queues: path << 1 | slot */
     uint32_t *pq[2];   /* path queues */
     uint32_t *ctr;
@@ -116,8 +115,6 @@ __global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch 
             const uint32_t tile_id = bt.tile_rem + (bt.tile_first + tsel) * bt.tile_mod;
             const int x0 = (int) (tile_id % bt.tiles_x) * kTile, y0 = (int) (tile_id / bt.tiles_x) * kTile;
             int px, py; tile_pixel((int) pix, x0, y0, px, py);
-            f4 sl4; sl4.x = sl4.y = sl4.z = sl4.w = 0.0f;
-            b.samp_L[p] = sl4;
             live = px < sc.camera.width && py < sc.camera.height;
             if (live) {
                 /* renderBlock, src/main.cpp:41-46 */
@@ -162,7 +159,9 @@ __global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, i
     Trav tv; tv.active = false; tv.node = 0;
     uint32_t rid = 0;
     bool exhausted = n == 0;
-    constexpr uint32_t kChunk = 1024u;
+    /* chunk size follows the queue length: big chunks amortise the atomic, small ones keep
+       all waves busy in the long tail of a batch */
+    const uint32_t kChunk = min(1024u, max(64u, (n / (gridDim.x * 8u)) & ~63u));
     uint32_t chunk_pos = 0u, chunk_end = 0u;       /* wave-uniform */
     uint32_t nClosest = 0, nShadow = 0;
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(kB) void wf_shade(DevScene sc, WfBuf b, int cur, ui
     const uint32_t n = b.ctr[C_PQ_CUR];
     const uint32_t *pq = b.pq[cur];
     uint32_t *rq_next = b.rq[cur ^ 1], *pq_next = b.pq[cur ^ 1];
-    constexpr uint32_t kStageRq = 4096u, kStagePq = 2048u;
+    constexpr uint32_t kStageRq = 4096u, kStagePq = 4096u;   /* every path pushes >= 1 ray: pq entries <= rq entries */
     __shared__ uint32_t s_rq[kStageRq], s_pq[kStagePq], s_n[4];
     if (threadIdx.x < 4) s_n[threadIdx.x] = 0u;
     __syncthreads();
@@ -304,7 +303,7 @@ __global__ __launch_bounds__(kB) void wf_shade(DevScene sc, WfBuf b, int cur, ui
                 }
             }
             if (done) {
-                f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 1.0f;
+                f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 0.0f;
                 b.samp_L[p] = out;
             }
             }
@@ -337,75 +336,6 @@ __global__ void wf_swap(uint32_t *ctr) {
     ctr[C_HEAD] = 0;
 }
 
-struct LdsAddW {
-    __device__ __forceinline__ void operator()(float *p, float v) const { atomicAdd(p, v); }
-};
-
-__global__ __launch_bounds__(kB) void wf_splat(DevScene sc, WfBuf b, WfBatch bt, const float *__restrict__ filter_table, float *tile_acc) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *tile = reinterpret_cast<float *>(smem);
-    const int tile_w = bt.tile_w, tile_floats = tile_w * tile_w * 4;
-    float *ftab = tile + tile_floats;
-    unsigned int *cnt = reinterpret_cast<unsigned int *>(ftab + 48);
-    const int tid = threadIdx.x;
-    for (int i = tid; i < tile_floats; i += kB) tile[i] = 0.0f;
-    if (tid <= kFilterRes) ftab[tid] = filter_table[tid];
-    if (tid == 0) cnt[0] = 0u;
-    __syncthreads();
-    const uint32_t tsel = blockIdx.x;
-    const uint32_t tile_id = bt.tile_rem + (bt.tile_first + tsel) * bt.tile_mod;
-    const int x0 = (int) (tile_id % bt.tiles_x) * kTile, y0 = (int) (tile_id / bt.tiles_x) * kTile;
-    const float radius = sc.filter.radius, lookup = sc.filter.lookup_factor;
-    const int border = sc.filter.border;
-    const size_t first = (size_t) tsel * 256u * bt.n_spp;
-    uint32_t invalid = 0;
-    for (uint32_t s = 0; s < bt.n_spp; ++s) {
-        const size_t p = first + (size_t) s * 256u + (size_t) tid;
-        const f4 l = b.samp_L[p];
-        if (l.w != 1.0f) continue;
-        const f3 L = mk3(l.x, l.y, l.z);
-        if (color_valid(L)) splat_tile(tile, tile_w, x0, y0, ftab, radius, lookup, border, b.samp_pos[p], L, LdsAddW());
-        else ++invalid;
-    }
-    if (invalid) atomicAdd(&cnt[0], invalid);
-    __syncthreads();
-    /* ImageBlock::put(ImageBlock&), first half: add this batch's tile to the tile's own
-       accumulator in HBM (single writer -> no atomics); wf_resolve merges the overlapping
-       borders of neighbouring tiles into the frame once, in a fixed order */
-    float *acc = tile_acc + (size_t) (bt.tile_first + tsel) * tile_floats;
-    for (int i = tid; i < tile_floats; i += kB) {
-        const float v = tile[i];
-        if (v != 0.0f) acc[i] += v;
-    }
-    if (tid == 0 && cnt[0]) atomicAdd(&b.stats[S_INVALID], (unsigned long long) cnt[0]);
-}
-
-/* ImageBlock::put(ImageBlock&), second half: every frame pixel gathers the (at most four)
-   tile accumulators whose bordered area covers it -- deterministic summation order */
-__global__ void wf_resolve(int width, int height, int border, int tile_w, uint32_t tiles_x, uint32_t tiles_y,
-                           uint32_t tile_mod, uint32_t tile_rem, const float *tile_acc, float *rgbw) {
-    const int cols = width + 2 * border, rows = height + 2 * border;
-    const int gx = blockIdx.x * blockDim.x + threadIdx.x, gy = blockIdx.y;
-    if (gx >= cols || gy >= rows) return;
-    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const int tx1 = min(gx / kTile, (int) tiles_x - 1), ty1 = min(gy / kTile, (int) tiles_y - 1);
-    const int tx0 = max(0, (gx - tile_w + kTile) / kTile), ty0 = max(0, (gy - tile_w + kTile) / kTile);
-    for (int ty = ty0; ty <= ty1; ++ty)
-        for (int tx = tx0; tx <= tx1; ++tx) {
-            const int lx = gx - tx * kTile, ly = gy - ty * kTile;
-            if (lx < 0 || ly < 0 || lx >= tile_w || ly >= tile_w) continue;
-            const uint32_t tile_id = (uint32_t) ty * tiles_x + (uint32_t) tx;
-            if (tile_id < tile_rem || (tile_id - tile_rem) % tile_mod != 0u) continue;
-            const uint32_t ord = (tile_id - tile_rem) / tile_mod;
-            const float4 v = *reinterpret_cast<const float4 *>(tile_acc + ((size_t) ord * tile_w * tile_w + (size_t) ly * tile_w + lx) * 4);
-            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
-        }
-    float4 *dst = reinterpret_cast<float4 *>(rgbw) + (size_t) gy * cols + gx;
-    float4 cur = *dst;
-    cur.x += sum.x; cur.y += sum.y; cur.z += sum.z; cur.w += sum.w;
-    *dst = cur;
-}
-
 /* ----------------------------------------------------------- host driver */
 struct Pool {
     std::vector<void *> allocs;
@@ -413,12 +343,10 @@ struct Pool {
     size_t bytes = 0;
     WfBuf buf;
     uint32_t *h_ctr = nullptr; /* pinned */
-    float *tile_acc = nullptr; size_t tile_acc_floats = 0;
     int device = -1;
     void release() {
         for (void *p : allocs) (void) hipFree(p);
         allocs.clear(); capacity = 0; bytes = 0;
-        if (tile_acc) { (void) hipFree(tile_acc); tile_acc = nullptr; tile_acc_floats = 0; }
         if (h_ctr) { (void) hipHostFree(h_ctr); h_ctr = nullptr; }
     }
 };
@@ -444,7 +372,6 @@ std::string ensure_pool(size_t paths) {
 #define A(field, count) if (!(e = pool_alloc(&b.field, (count))).empty()) return e
     A(ray_o, paths); A(rayA_d, paths); A(rayB_d, paths); A(hitA, paths); A(hitB, paths);
     A(T_eta, paths); A(L_pdf, paths); A(Ld, paths); A(flags, paths); A(rng, paths);
-    A(samp_pos, paths); A(samp_L, paths);
     A(rq[0], 2 * paths); A(rq[1], 2 * paths); A(pq[0], paths); A(pq[1], paths);
     A(ctr, (size_t) C_COUNT); A(stats, (size_t) S_COUNT);
 #undef A
@@ -494,21 +421,17 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     const size_t paths = (size_t) tiles_b * 256 * spp_b;
     std::string err = ensure_pool(paths);
     if (!err.empty()) return err;
-    const WfBuf &b = g_pool.buf;
-    stats.state_bytes = g_pool.bytes;
-    WF_TRY(hipMemsetAsync(b.stats, 0, S_COUNT * sizeof(unsigned long long), s));
+    stats.state_bytes = g_pool.bytes + paths * 24;
+    WF_TRY(hipMemsetAsync(g_pool.buf.stats, 0, S_COUNT * sizeof(unsigned long long), s));
     int refill = 24;
     if (const char *e = getenv("NORI_HIP_WF_REFILL")) refill = std::min(64, std::max(1, atoi(e)));
-    const size_t splat_lds = sizeof(float) * ((size_t) L.tile_w * L.tile_w * 4 + 48 + 8);
-    const size_t acc_floats = (size_t) L.n_sel_tiles * L.tile_w * L.tile_w * 4;
-    if (g_pool.tile_acc_floats < acc_floats) {
-        if (g_pool.tile_acc) (void) hipFree(g_pool.tile_acc);
-        g_pool.tile_acc = nullptr; g_pool.tile_acc_floats = 0;
-        WF_TRY(hipMalloc((void **) &g_pool.tile_acc, acc_floats * sizeof(float)));
-        g_pool.tile_acc_floats = acc_floats;
-    }
-    WF_TRY(hipMemsetAsync(g_pool.tile_acc, 0, acc_floats * sizeof(float), s));
-
+    FilmStore film;
+    err = film_prepare(paths, L.n_sel_tiles, L.tile_w, s, film);
+    if (!err.empty()) return err;
+    WfBuf b = g_pool.buf;
+    b.samp_pos = film.pos; b.samp_L = film.L;
+    FilmLaunch fl;
+    fl.tile_mod = L.tile_mod; fl.tile_rem = L.tile_rem; fl.tiles_x = L.tiles_x; fl.tiles_y = L.tiles_y; fl.tile_w = L.tile_w;
     for (uint32_t t0 = 0; t0 < L.n_sel_tiles; t0 += tiles_b) {
         const uint32_t nt = std::min(tiles_b, L.n_sel_tiles - t0);
         for (uint32_t s0 = 0; s0 < L.spp_count; s0 += spp_b) {
@@ -534,22 +457,19 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
                 if (g_pool.h_ctr[C_PQ_CUR] == 0) break;
                 if (stats.n_iterations > 100000) return "wavefront: path loop did not terminate";
             }
-            hipLaunchKernelGGL(wf_splat, dim3(nt), dim3(kB), splat_lds, s, sc, b, bt, d_filter_table, g_pool.tile_acc);
+            fl.tile_first = t0; fl.store_tile_first = t0; fl.n_tiles = nt; fl.n_spp = ns;
+            film_gather(sc, d_filter_table, film, fl, s);
             stats.n_launches++;
             WF_TRY(hipGetLastError());
         }
     }
-    {
-        const int border = sc.filter.border, cols = sc.camera.width + 2 * border, rows = sc.camera.height + 2 * border;
-        hipLaunchKernelGGL(wf_resolve, dim3((cols + 255) / 256, rows), dim3(256), 0, s, sc.camera.width, sc.camera.height, border,
-                           L.tile_w, L.tiles_x, L.tiles_y, L.tile_mod, L.tile_rem, (const float *) g_pool.tile_acc, d_rgbw);
-        stats.n_launches++;
-    }
+    film_resolve(sc, film, fl, d_rgbw, s);
+    stats.n_launches++;
     unsigned long long h[S_COUNT];
     WF_TRY(hipMemcpyAsync(h, b.stats, sizeof(h), hipMemcpyDeviceToHost, s));
     WF_TRY(hipStreamSynchronize(s));
     stats.n_camera = h[S_CAM]; stats.n_closest = h[S_CLOSEST]; stats.n_shadow = h[S_SHADOW];
-    stats.n_nodes = h[S_NODES]; stats.n_tris = h[S_TRIS]; stats.n_invalid = h[S_INVALID];
+    stats.n_nodes = h[S_NODES]; stats.n_tris = h[S_TRIS]; stats.n_invalid = film_invalid_count(film, s);
     return std::string();
 }
 
