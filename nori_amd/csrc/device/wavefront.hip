@@ -149,7 +149,8 @@ __global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch 
 }
 
 template <int STACK, bool COUNT>
-__global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, int refill_threshold) {
+__global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds) {
+    const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStackW<STACK> stack;
     stack.base = reinterpret_cast<int *>(smem) + threadIdx.x; stack.sp = 0;
@@ -205,8 +206,13 @@ __global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, i
             continue;
         }
         const bool was = tv.active;
+        /* inner-node steps run every trip; the (rarer) triangle step only when enough lanes
+           wait at a leaf or nobody has an inner node to test */
         if (tv.active && tv.node >= 0) trav_inner_step<COUNT>(sc, stack, tv, tc);
-        if (tv.active && tv.node < 0) trav_leaf_step<COUNT>(sc, stack, tv, tc);
+        const bool atLeaf = tv.active && tv.node < 0;
+        const int nLeaf = __popcll(__ballot(atLeaf));
+        const bool innerLeft = __ballot(tv.active && tv.node >= 0) != 0ull;
+        if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT>(sc, stack, tv, tc);
         if (was && !tv.active) {
             f4 h; h.x = tv.hit.t; h.y = tv.hit.u; h.z = tv.hit.v; h.w = __uint_as_float(tv.hit.tri);
             if (rid & 1u) b.hitB[rid >> 1] = h; else b.hitA[rid >> 1] = h;
@@ -373,9 +379,9 @@ std::string ensure_pool(size_t paths) {
     A(ray_o, paths); A(rayA_d, paths); A(rayB_d, paths); A(hitA, paths); A(hitB, paths);
     A(T_eta, paths); A(L_pdf, paths); A(Ld, paths); A(flags, paths); A(rng, paths);
     A(rq[0], 2 * paths); A(rq[1], 2 * paths); A(pq[0], paths); A(pq[1], paths);
-    A(ctr, (size_t) C_COUNT); A(stats, (size_t) S_COUNT);
+    A(ctr, (size_t) 2 * C_COUNT); A(stats, (size_t) 2 * S_COUNT);
 #undef A
-    WF_TRY(hipHostMalloc((void **) &g_pool.h_ctr, C_COUNT * sizeof(uint32_t)));
+    WF_TRY(hipHostMalloc((void **) &g_pool.h_ctr, 2 * C_COUNT * sizeof(uint32_t)));
     g_pool.capacity = paths;
     return std::string();
 }
@@ -385,10 +391,7 @@ void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int 
     hipLaunchKernelGGL((wf_extend<STACK, COUNT>), dim3(grid), dim3(kB), STACK * kB * sizeof(int), s, sc, b, cur, refill);
 }
 
-void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int stack, bool count, hipStream_t s) {
-    /* persistent grid: enough workgroups to fill every CU at the LDS-limited occupancy */
-    const int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / (stack * kB * sizeof(int) + 64))));
-    const int grid = 256 * per_cu;
+void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int stack, bool count, int grid, hipStream_t s) {
 #define E(S) if (count) launch_extend<S, true>(sc, b, cur, refill, grid, s); else launch_extend<S, false>(sc, b, cur, refill, grid, s)
     if (stack <= 16) { E(16); } else if (stack <= 24) { E(24); } else if (stack <= 32) { E(32); } else { E(64); }
 #undef E
@@ -409,67 +412,159 @@ namespace nrt {
 
 void wavefront_release() { g_pool.release(); }
 
+/* A pipe works through its own list of batches with its own slice of the state pool, on its own
+   HIP stream.  Two pipes interleave so that one pipe's wf_shade (HBM-bound) overlaps the other
+   pipe's wf_extend (VALU-bound); the persistent extend grid is sized to leave room for it. */
+struct Pipe {
+    hipStream_t stream = nullptr;
+    WfBuf b;
+    FilmStore film;
+    uint32_t *h_ctr = nullptr;
+    uint32_t tile_lo = 0, tile_hi = 0;      /* selected-tile ordinals owned by this pipe */
+    uint32_t tiles_b = 0, spp_b = 0;        /* batch geometry */
+    uint32_t t0 = 0, s0 = 0;                /* next batch */
+    bool active = false, finished = false;
+    WfBatch bt;
+    int cur = 0;
+};
+
+static hipStream_t g_streams[2] = {nullptr, nullptr};
+static hipEvent_t g_events[3] = {nullptr, nullptr, nullptr};
+
+static WfBuf slice(const WfBuf &b, size_t off, int k) {
+    WfBuf v = b;
+    v.ray_o += off; v.rayA_d += off; v.rayB_d += off; v.hitA += off; v.hitB += off;
+    v.T_eta += off; v.L_pdf += off; v.Ld += off; v.flags += off; v.rng += off;
+    v.rq[0] += 2 * off; v.rq[1] += 2 * off; v.pq[0] += off; v.pq[1] += off;
+    v.ctr += (size_t) k * C_COUNT; v.stats += (size_t) k * S_COUNT;
+    return v;
+}
+
 std::string wavefront_render(const DevScene &sc, const float *d_filter_table, const WfLaunch &L, float *d_rgbw, void *stream_, WfStats &stats) {
     hipStream_t s = (hipStream_t) stream_;
     stats = WfStats();
     if (L.n_sel_tiles == 0 || L.spp_count == 0) return std::string();
-    /* batch geometry: all selected tiles x as many samples per pixel as fit */
-    size_t max_paths = std::max<size_t>(L.max_paths, 256);
-    uint32_t tiles_b = L.n_sel_tiles, spp_b = L.spp_count;
-    if ((size_t) tiles_b * 256 > max_paths) { tiles_b = (uint32_t) (max_paths / 256); spp_b = 1; }
-    else spp_b = (uint32_t) std::min<size_t>(L.spp_count, std::max<size_t>(1, max_paths / ((size_t) tiles_b * 256)));
-    const size_t paths = (size_t) tiles_b * 256 * spp_b;
-    std::string err = ensure_pool(paths);
+
+    int n_pipes = 2;
+    if (const char *e = getenv("NORI_HIP_WF_PIPES")) n_pipes = std::min(2, std::max(1, atoi(e)));
+    if (L.n_sel_tiles < 2 || (size_t) L.n_sel_tiles * 256 * L.spp_count < ((size_t) 1 << 22)) n_pipes = 1;
+
+    /* state budget per pipe; batch = a range of the pipe's tiles x as many samples per pixel as fit */
+    const size_t budget = std::max<size_t>(L.max_paths / n_pipes, 256);
+    Pipe pipes[2];
+    size_t need[2] = {0, 0};
+    for (int k = 0; k < n_pipes; ++k) {
+        Pipe &P = pipes[k];
+        P.tile_lo = (uint32_t) ((uint64_t) L.n_sel_tiles * k / n_pipes);
+        P.tile_hi = (uint32_t) ((uint64_t) L.n_sel_tiles * (k + 1) / n_pipes);
+        const uint32_t nt = P.tile_hi - P.tile_lo;
+        if ((size_t) nt * 256 > budget) { P.tiles_b = (uint32_t) (budget / 256); P.spp_b = 1; }
+        else { P.tiles_b = nt; P.spp_b = (uint32_t) std::min<size_t>(L.spp_count, std::max<size_t>(1, budget / ((size_t) nt * 256))); }
+        need[k] = (size_t) P.tiles_b * 256 * P.spp_b;
+        P.t0 = P.tile_lo; P.s0 = 0;
+    }
+    const size_t per_pipe = std::max(need[0], need[1]);
+    std::string err = ensure_pool(per_pipe * n_pipes);
     if (!err.empty()) return err;
-    stats.state_bytes = g_pool.bytes + paths * 24;
-    WF_TRY(hipMemsetAsync(g_pool.buf.stats, 0, S_COUNT * sizeof(unsigned long long), s));
-    int refill = 24;
-    if (const char *e = getenv("NORI_HIP_WF_REFILL")) refill = std::min(64, std::max(1, atoi(e)));
     FilmStore film;
-    err = film_prepare(paths, L.n_sel_tiles, L.tile_w, s, film);
+    err = film_prepare(per_pipe * n_pipes, L.n_sel_tiles, L.tile_w, s, film);
     if (!err.empty()) return err;
-    WfBuf b = g_pool.buf;
-    b.samp_pos = film.pos; b.samp_L = film.L;
+    stats.state_bytes = g_pool.bytes + per_pipe * n_pipes * 24;
+    WF_TRY(hipMemsetAsync(g_pool.buf.stats, 0, 2 * S_COUNT * sizeof(unsigned long long), s));
+
+    for (int k = 0; k < 3; ++k) if (!g_events[k]) WF_TRY(hipEventCreateWithFlags(&g_events[k], hipEventDisableTiming));
+    for (int k = 0; k < n_pipes; ++k) {
+        Pipe &P = pipes[k];
+        if (n_pipes == 1) P.stream = s;
+        else {
+            if (!g_streams[k]) WF_TRY(hipStreamCreateWithFlags(&g_streams[k], hipStreamNonBlocking));
+            P.stream = g_streams[k];
+        }
+        P.b = slice(g_pool.buf, per_pipe * k, k);
+        P.film = film; P.film.pos += per_pipe * k; P.film.L += per_pipe * k;
+        P.b.samp_pos = P.film.pos; P.b.samp_L = P.film.L;
+        P.h_ctr = g_pool.h_ctr + (size_t) k * C_COUNT;
+    }
+    if (n_pipes > 1) {      /* the pipes start after whatever the caller queued on its stream */
+        WF_TRY(hipEventRecord(g_events[2], s));
+        for (int k = 0; k < n_pipes; ++k) WF_TRY(hipStreamWaitEvent(pipes[k].stream, g_events[2], 0));
+    }
+
+    int refill = 32;
+    if (const char *e = getenv("NORI_HIP_WF_REFILL")) refill = std::min(64, std::max(1, atoi(e)));
+    int leaf_th = 16;
+    if (const char *e = getenv("NORI_HIP_WF_LEAF")) leaf_th = std::min(64, std::max(1, atoi(e)));
+    const int thresholds = refill | (leaf_th << 8);
+    /* persistent extend grid: fill the CUs, but with two pipes leave half of the wave slots to
+       the other pipe's kernels */
+    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / (L.stack_depth * kB * sizeof(int) + 64))));
+    if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
+    if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(8, std::max(1, atoi(e)));
+    const int extend_grid = 256 * per_cu;
+
     FilmLaunch fl;
     fl.tile_mod = L.tile_mod; fl.tile_rem = L.tile_rem; fl.tiles_x = L.tiles_x; fl.tiles_y = L.tiles_y; fl.tile_w = L.tile_w;
-    for (uint32_t t0 = 0; t0 < L.n_sel_tiles; t0 += tiles_b) {
-        const uint32_t nt = std::min(tiles_b, L.n_sel_tiles - t0);
-        for (uint32_t s0 = 0; s0 < L.spp_count; s0 += spp_b) {
-            const uint32_t ns = std::min(spp_b, L.spp_count - s0);
-            WfBatch bt;
-            bt.tile_first = t0; bt.n_tiles = nt; bt.s_first = L.spp_begin + s0; bt.n_spp = ns;
-            bt.tile_mod = L.tile_mod; bt.tile_rem = L.tile_rem; bt.tiles_x = L.tiles_x; bt.tile_w = L.tile_w;
-            WF_TRY(hipMemsetAsync(b.ctr, 0, C_COUNT * sizeof(uint32_t), s));
+
+    while (true) {
+        bool any = false;
+        for (int k = 0; k < n_pipes; ++k) {         /* start the next batch of idle pipes */
+            Pipe &P = pipes[k];
+            if (P.active || P.finished) { any |= P.active; continue; }
+            if (P.t0 >= P.tile_hi) { P.finished = true; continue; }
+            const uint32_t nt = std::min(P.tiles_b, P.tile_hi - P.t0), ns = std::min(P.spp_b, L.spp_count - P.s0);
+            P.bt.tile_first = P.t0; P.bt.n_tiles = nt; P.bt.s_first = L.spp_begin + P.s0; P.bt.n_spp = ns;
+            P.bt.tile_mod = L.tile_mod; P.bt.tile_rem = L.tile_rem; P.bt.tiles_x = L.tiles_x; P.bt.tile_w = L.tile_w;
+            WF_TRY(hipMemsetAsync(P.b.ctr, 0, C_COUNT * sizeof(uint32_t), P.stream));
             const size_t n = (size_t) nt * 256 * ns;
-            hipLaunchKernelGGL(wf_generate, dim3((unsigned) std::min<size_t>((n + kB - 1) / kB, 8192)), dim3(kB), 0, s, sc, b, bt);
+            hipLaunchKernelGGL(wf_generate, dim3((unsigned) std::min<size_t>((n + kB - 1) / kB, 8192)), dim3(kB), 0, P.stream, sc, P.b, P.bt);
             stats.n_launches++; stats.n_batches++;
-            int cur = 0;
-            while (true) {
-                for (int k = 0; k < 6; ++k) {
-                    launch_extend_dyn(sc, b, cur, refill, L.stack_depth, L.count_traversal, s);
-                    launch_shade(sc, b, cur, bt.s_first, ns, s);
-                    hipLaunchKernelGGL(wf_swap, dim3(1), dim3(1), 0, s, b.ctr);
-                    cur ^= 1;
-                    stats.n_iterations++; stats.n_launches += 3;
-                }
-                WF_TRY(hipMemcpyAsync(g_pool.h_ctr, b.ctr, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-                WF_TRY(hipStreamSynchronize(s));
-                if (g_pool.h_ctr[C_PQ_CUR] == 0) break;
-                if (stats.n_iterations > 100000) return "wavefront: path loop did not terminate";
-            }
-            fl.tile_first = t0; fl.store_tile_first = t0; fl.n_tiles = nt; fl.n_spp = ns;
-            film_gather(sc, d_filter_table, film, fl, s);
-            stats.n_launches++;
-            WF_TRY(hipGetLastError());
+            P.cur = 0; P.active = true; any = true;
         }
+        if (!any) break;
+        for (int it = 0; it < 6; ++it)
+            for (int k = 0; k < n_pipes; ++k) {
+                Pipe &P = pipes[k];
+                if (!P.active) continue;
+                launch_extend_dyn(sc, P.b, P.cur, thresholds, L.stack_depth, L.count_traversal, extend_grid, P.stream);
+                launch_shade(sc, P.b, P.cur, P.bt.s_first, P.bt.n_spp, P.stream);
+                hipLaunchKernelGGL(wf_swap, dim3(1), dim3(1), 0, P.stream, P.b.ctr);
+                P.cur ^= 1;
+                stats.n_launches += 3;
+                if (k == 0) stats.n_iterations++;
+            }
+        for (int k = 0; k < n_pipes; ++k)
+            if (pipes[k].active) WF_TRY(hipMemcpyAsync(pipes[k].h_ctr, pipes[k].b.ctr, C_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, pipes[k].stream));
+        for (int k = 0; k < n_pipes; ++k)
+            if (pipes[k].active) WF_TRY(hipStreamSynchronize(pipes[k].stream));
+        for (int k = 0; k < n_pipes; ++k) {
+            Pipe &P = pipes[k];
+            if (!P.active || P.h_ctr[C_PQ_CUR] != 0) continue;
+            /* batch done: splat its samples (each pipe owns its tiles' accumulators) */
+            fl.tile_first = P.bt.tile_first; fl.store_tile_first = P.bt.tile_first; fl.n_tiles = P.bt.n_tiles; fl.n_spp = P.bt.n_spp;
+            film_gather(sc, d_filter_table, P.film, fl, P.stream);
+            stats.n_launches++;
+            P.active = false;
+            P.s0 += P.bt.n_spp;
+            if (P.s0 >= L.spp_count) { P.s0 = 0; P.t0 += P.bt.n_tiles; }
+        }
+        if (stats.n_iterations > 100000) return "wavefront: path loop did not terminate";
     }
+    if (n_pipes > 1)        /* back to the caller's stream */
+        for (int k = 0; k < n_pipes; ++k) {
+            WF_TRY(hipEventRecord(g_events[k], pipes[k].stream));
+            WF_TRY(hipStreamWaitEvent(s, g_events[k], 0));
+        }
     film_resolve(sc, film, fl, d_rgbw, s);
     stats.n_launches++;
-    unsigned long long h[S_COUNT];
-    WF_TRY(hipMemcpyAsync(h, b.stats, sizeof(h), hipMemcpyDeviceToHost, s));
+    WF_TRY(hipGetLastError());
+    unsigned long long h[2 * S_COUNT];
+    WF_TRY(hipMemcpyAsync(h, g_pool.buf.stats, sizeof(h), hipMemcpyDeviceToHost, s));
     WF_TRY(hipStreamSynchronize(s));
-    stats.n_camera = h[S_CAM]; stats.n_closest = h[S_CLOSEST]; stats.n_shadow = h[S_SHADOW];
-    stats.n_nodes = h[S_NODES]; stats.n_tris = h[S_TRIS]; stats.n_invalid = film_invalid_count(film, s);
+    for (int k = 0; k < 2; ++k) {
+        stats.n_camera += h[k * S_COUNT + S_CAM]; stats.n_closest += h[k * S_COUNT + S_CLOSEST]; stats.n_shadow += h[k * S_COUNT + S_SHADOW];
+        stats.n_nodes += h[k * S_COUNT + S_NODES]; stats.n_tris += h[k * S_COUNT + S_TRIS];
+    }
+    stats.n_invalid = film_invalid_count(film, s);
     return std::string();
 }
 

@@ -1,2 +1,1 @@
-run() { echo -n "WGS=$1: "; NORI_HIP_TARGET_WGS=$1 timeout 120 python bench.py --steps 2 --warmup 1 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['workgroups'])"; }
-for W in 4096 8192 16384 32768 65536; do run $W; done
+for R in 8 16 24 32 48; do for LT in 1 8 16; do echo -n "refill=$R leaf=$LT: "; NORI_HIP_WF_REFILL=$R NORI_HIP_WF_LEAF=$LT REPS=2 timeout 60 python tools/wf_probe.py 2>&1 | tail -1; done; done

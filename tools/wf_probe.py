@@ -1,0 +1,13 @@
+import os, sys
+sys.path.insert(0, ".")
+import torch
+from nori_amd.render import Renderer
+from nori_amd.scene import Scene
+sc = Scene.load_npz("tests/golden/pa4-cbox-path_mis.npz")
+r = Renderer(0).upload(sc)
+r.set_option("engine", os.environ.get("ENGINE", "wavefront"))
+r.set_option("wavefront_paths", int(os.environ.get("PATHS", 1 << 28)))
+f = torch.zeros(r.frame_shape(), device="cuda")
+for i in range(int(os.environ.get("REPS", 3))):
+    f.zero_(); st = r.render_into(f)
+    print(round(st["kernel_ms"], 1), "ms", round((st["n_closest_rays"] + st["n_shadow_rays"]) / st["kernel_ms"] / 1e3, 1), "Mrays/s")
