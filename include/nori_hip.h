@@ -263,7 +263,8 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder /* nori_accel_builder */
 int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out);
 
 /* Tuning / engine selection (no reference counterpart).  Keys:
- *   "engine"          "megakernel" (default) | "wavefront"
+ *   "engine"          "auto" (default: wavefront for >= 2^24 camera samples per call,
+ *                     else megakernel) | "megakernel" | "wavefront"
  *   "wavefront_paths" paths in flight per wavefront batch (default 2^28, ~180 B of HBM each)
  * Unknown keys return NORI_ERR_INVALID_ARGUMENT. */
 int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value);
