@@ -39,15 +39,23 @@ def load_workload(name: str, width: int, height: int, spp: int):
     return sc
 
 
-def algorithmic_bytes(stats: dict, info: dict, tile_w: int, n_workgroups: int, frame_px: int) -> float:
-    """per ray N_node*S_node + N_tri*S_tri; S_io = 0 (register-resident
-    megakernel); per closest hit the surface fetch (3 indices + 3 positions + 3 normals,
-    de-indexed as 16-B records); per workgroup one LDS-tile flush (read-modify-write
-    of (16+2b)^2 RGBW pixels)."""
-    b = stats["n_node_tests"] * info["node_bytes"] + stats["n_tri_tests"] * info["tri_bytes"]
-    b += stats["n_closest_rays"] * (12 + 48 + 48)
-    b += n_workgroups * 2 * 16 * tile_w * tile_w
-    return float(b)
+def algorithmic_bytes(stats: dict, info: dict, tile_w: int, n_tiles: int, engine: str) -> dict:
+    """Algorithmic bytes of one render pass:
+      traversal  N_node * 64 + N_tri * 48                     (both engines; from the COUNT pass)
+      surface    108 B per closest hit (3 indices + 3 positions + 3 normals as 16-B records)
+      film       24 B written + 24 B read per camera sample (sample store), plus one
+                 read-modify-write of every tile accumulator and one frame read-modify-write
+      state      wavefront only: per ray 56 B of queue / ray / hit records (S_io) and per
+                 shaded path vertex 232 B of path state read + written; 0 for the megakernel,
+                 whose paths live in registers."""
+    trav = stats["n_node_tests"] * info["node_bytes"] + stats["n_tri_tests"] * info["tri_bytes"]
+    surface = stats["n_closest_rays"] * (12 + 48 + 48)
+    film = stats["n_camera_samples"] * 48 + n_tiles * 2 * 16 * tile_w * tile_w
+    state = 0
+    if engine == "wavefront":
+        state = (stats["n_closest_rays"] + stats["n_shadow_rays"]) * 56 + stats["n_closest_rays"] * 232
+    return {"traversal": int(trav), "surface": int(surface), "film": int(film), "state": int(state),
+            "total": int(trav + surface + film + state)}
 
 
 def main():
@@ -61,6 +69,7 @@ def main():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--engine", default="auto", choices=["auto", "megakernel", "wavefront"])
     args = ap.parse_args()
 
     import numpy as np
@@ -84,6 +93,12 @@ def main():
 
     from nori_amd.render import Renderer
     r = Renderer(local_rank).upload(sc)
+    tiles = ((args.width + 15) // 16) * ((args.height + 15) // 16)
+    my_tiles = (tiles - rank + world - 1) // world
+    engine = args.engine
+    if engine == "auto":      # the library's rule (nori_hip.h, nori_hip_set_option)
+        engine = "wavefront" if my_tiles * 256 * args.spp >= (1 << 24) else "megakernel"
+    r.set_option("engine", engine)
     info = r.accel_info()
     frame = torch.zeros(r.frame_shape(), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream(dev)
@@ -128,7 +143,8 @@ def main():
         mrays = rays_total / (ms_per_step * 1e-3) / 1e6
         # roofline of the dominant kernel on this rank
         tile_w = 16 + 2 * r.border
-        alg = algorithmic_bytes(counted, info, tile_w, last["n_workgroups"], args.width * args.height)
+        parts = algorithmic_bytes(counted, info, tile_w, my_tiles, engine)
+        alg = parts["total"]
         k_ms = float(np.mean(kernel_ms))
         achieved = alg / (k_ms * 1e-3) / 1e9
         out = {
@@ -139,12 +155,12 @@ def main():
             "config": {"workload": args.workload, "integrator": sc.integrator.type, "width": args.width,
                        "height": args.height, "spp": args.spp, "triangles": info["n_triangles"],
                        "parallelism": f"tile-split x{world} + RCCL reduce" if world > 1 else "single GPU",
-                       "rays_per_step": int(rays_total), "seed_mode": "per_sample"},
-            "roofline": {"bound": "hbm", "kernel": "render_kernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                       "rays_per_step": int(rays_total), "seed_mode": "per_sample", "engine": engine},
+            "roofline": {"bound": "hbm", "kernel": "render pass: wf_generate + (wf_extend, wf_shade)* + film_gather + film_resolve" if engine == "wavefront" else "render pass: render_kernel + film_gather + film_resolve", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(args, sc),
-                         "kernel_ms": round(k_ms, 3), "algorithmic_bytes": int(alg),
-                         "workgroups": int(last["n_workgroups"]), "lds_bytes": int(last["lds_bytes"]),
+                         "traffic": measured_traffic(args, sc, engine),
+                         "kernel_ms": round(k_ms, 3), "algorithmic_bytes": int(alg), "algorithmic_bytes_parts": parts,
+                         "launches_or_workgroups": int(last["n_workgroups"]),
                          "node_tests": int(counted["n_node_tests"]), "tri_tests": int(counted["n_tri_tests"])},
             "accel": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in info.items()},
         }
@@ -156,7 +172,7 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(args, sc):
+def measured_traffic(args, sc, engine):
     """HBM bytes per launch of render_kernel from the PMC passes (FETCH_SIZE, WRITE_SIZE; separate
     rocprofv3 --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  PMC counters cannot be read
     from inside this process, so the figure comes from the committed summary of a profiled run of this
@@ -165,7 +181,7 @@ def measured_traffic(args, sc):
     if not os.path.exists(path):
         return None
     t = json.load(open(path))
-    key = f"{args.workload}:{args.width}x{args.height}:{args.spp}"
+    key = f"{args.workload}:{args.width}x{args.height}:{args.spp}:{engine}"
     return t.get(key, {}).get("hbm_bytes_per_launch")
 
 
