@@ -188,13 +188,11 @@ __global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 
     f3 lmn, lmx, rmn, rmx;
     range_box(tmin, tmax, N, llo, lhi, lmn, lmx);
     range_box(tmin, tmax, N, rlo, rhi, rmn, rmx);
-    f4 *q = out + (size_t) i * kNodeQuads;
-    f4 a, b, c, d;
-    a.x = lmn.x; a.y = lmn.y; a.z = lmn.z; a.w = lmx.x;
-    b.x = lmx.y; b.y = lmx.z; b.z = rmn.x; b.w = rmn.y;
-    c.x = rmn.z; c.y = rmx.x; c.z = rmx.y; c.w = rmx.z;
-    d.x = __uint_as_float((uint32_t) cl); d.y = __uint_as_float((uint32_t) cr); d.z = 0.0f; d.w = 0.0f;
-    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+    const float a0[3] = {lmn.x, lmn.y, lmn.z}, a1[3] = {lmx.x, lmx.y, lmx.z}, b0[3] = {rmn.x, rmn.y, rmn.z}, b1[3] = {rmx.x, rmx.y, rmx.z};
+    f4 q[4];
+    node_pack(a0, a1, b0, b1, cl, cr, q);
+    f4 *dst = out + (size_t) i * kNodeQuads;
+    dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
 }
 
 __global__ void k_emit_tris(const f4 *pos, const uint32_t *idx, const uint32_t *tri_mesh, const unsigned long long *keys, uint32_t n, f4 *out) {

@@ -343,7 +343,7 @@ struct nori_hip_ctx {
     int stack_depth = 32;
     uint64_t lbvh_bytes = 0;
     int engine = -1;                /* -1 auto, 0 megakernel, 1 wavefront */
-    size_t wavefront_paths = (size_t) 1 << 28;     /* ~180 B each: 48 GB of the 288 GB */
+    size_t wavefront_paths = (size_t) 1 << 28;     /* 240 B of state each (two copies) + film: ~80 GB of the 288 GB */
 };
 
 static std::string g_create_error;

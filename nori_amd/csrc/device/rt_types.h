@@ -93,13 +93,21 @@ NORI_HD f3 to_world(const Frame &f, f3 v) { return (f.s * v.x + f.t * v.y) + f.n
 
 /* One BVH2 node = 64 B = 4 x dwordx4: both child boxes + both child links, so
  * one fetch decides both children.
- *   q0 = (lmin.x, lmin.y, lmin.z, lmax.x)
- *   q1 = (lmax.y, lmax.z, rmin.x, rmin.y)
- *   q2 = (rmin.z, rmax.x, rmax.y, rmax.z)
+ *   q0 = (lmin.x, lmin.y, lmax.x, lmax.y)      x/y planes pair up with (o.x, o.y), the z planes of a
+ *   q1 = (rmin.x, rmin.y, rmax.x, rmax.y)      child with each other: the slab test (rt_trace.h,
+ *   q2 = (lmin.z, lmax.z, rmin.z, rmax.z)      slab_two) runs on packed f32 instructions
  *   q3 = (bits left, bits right, 0, 0)
  * child link >= 0: inner node index; < 0: leaf, ~link = (first_tri << 3) | (count - 1)
  */
 constexpr int kNodeQuads = 4;
+
+NORI_HD void node_pack(const float lmn[3], const float lmx[3], const float rmn[3], const float rmx[3],
+                       int32_t left, int32_t right, f4 q[4]) {
+    q[0].x = lmn[0]; q[0].y = lmn[1]; q[0].z = lmx[0]; q[0].w = lmx[1];
+    q[1].x = rmn[0]; q[1].y = rmn[1]; q[1].z = rmx[0]; q[1].w = rmx[1];
+    q[2].x = lmn[2]; q[2].y = lmx[2]; q[2].z = rmn[2]; q[2].w = rmx[2];
+    q[3].x = u2f((uint32_t) left); q[3].y = u2f((uint32_t) right); q[3].z = 0.0f; q[3].w = 0.0f;
+}
 constexpr int kMaxLeafTris = 8;
 
 /* One leaf triangle = 48 B = 3 x dwordx4, de-indexed and pre-gathered in leaf

@@ -372,11 +372,7 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
             const Box &L = bn[bn[b].left].box, &R = bn[bn[b].right].box;
             const int32_t cl = isLeaf(bn[b].left) ? leafCode(bn[b].left) : devId[bn[b].left];
             const int32_t cr = isLeaf(bn[b].right) ? leafCode(bn[b].right) : devId[bn[b].right];
-            f4 *q = &out.nodes[(size_t) devId[b] * kNodeQuads];
-            q[0].x = L.mn[0]; q[0].y = L.mn[1]; q[0].z = L.mn[2]; q[0].w = L.mx[0];
-            q[1].x = L.mx[1]; q[1].y = L.mx[2]; q[1].z = R.mn[0]; q[1].w = R.mn[1];
-            q[2].x = R.mn[2]; q[2].y = R.mx[0]; q[2].z = R.mx[1]; q[2].w = R.mx[2];
-            q[3].x = u2f((uint32_t) cl); q[3].y = u2f((uint32_t) cr); q[3].z = 0.0f; q[3].w = 0.0f;
+            node_pack(L.mn, L.mx, R.mn, R.mx, cl, cr, &out.nodes[(size_t) devId[b] * kNodeQuads]);
         }
         out.root = 0;
         out.n_nodes = nInner;

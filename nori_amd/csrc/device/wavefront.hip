@@ -5,19 +5,20 @@
  * pcg32 streams, therefore the same radiance per camera sample; what changes is
  * how work is laid out for 64-wide waves.  In the megakernel a lane owns a
  * pixel and, when its path needs shading while its neighbours still traverse,
- * it waits.  Here paths live in HBM (sized for 288 GB: ~150 B per path, tens of
- * millions in flight) and every kernel runs with all lanes doing the SAME kind
+ * it waits.  Here paths live in HBM (sized for 288 GB: 240 B per path in two
+ * state copies, 2^28 paths = 70 GB in flight) and every kernel runs with all lanes doing the SAME kind
  * of work:
  *
  *   wf_generate  camera samples -> path state + first ray          (src/main.cpp:41-46)
  *   loop until no path is alive:
- *     wf_extend  persistent waves pull rays from a queue; a lane whose ray
- *                finishes writes the hit and is refilled as soon as enough
- *                lanes of its wave are idle (__ballot + one atomic per wave)
- *                -> Accel::rayIntersect, closest and shadow rays together
- *     wf_shade   one lane per live path: consume the shadow result, shade the
- *                closest hit (Integrator::Li state machine), append the next
- *                shadow + continuation rays with wave-aggregated atomics
+ *     wf_extend  persistent waves pull paths from the dense state array; a lane traces
+ *                the path's shadow ray, then its continuation ray, writes one hit
+ *                record, and is refilled as soon as enough lanes of its wave are idle
+ *                (__ballot + one atomic per chunk of paths)   -> Accel::rayIntersect
+ *     wf_shade   one lane per path: consume the shadow result, shade the closest hit
+ *                (Integrator::Li state machine), write the surviving path with its
+ *                next rays COMPACTED into the second state copy (ping-pong), so
+ *                every pass streams dense arrays however many paths have died
  *   film_gather / film_resolve (film.hip)  the finished samples sit tile-major in the
  *                film's store; the reconstruction filter and the block merge
  *                (ImageBlock::put, src/block.cpp:62-102) run as gathers
@@ -44,26 +45,36 @@ namespace {
 
 constexpr int kB = 256;
 
-enum { C_RQ_CUR = 0, C_RQ_NEXT = 1, C_PQ_CUR = 2, C_PQ_NEXT = 3, C_HEAD = 4, C_COUNT = 8 };
+enum { C_N_CUR = 0, C_N_NEXT = 1, C_HEAD = 2, C_OVERFLOW = 3, C_COUNT = 8 };
 enum { S_CAM = 0, S_CLOSEST = 1, S_SHADOW = 2, S_NODES = 3, S_TRIS = 4, S_INVALID = 5, S_COUNT = 8 };
 
 /* path flags */
 constexpr uint32_t F_HAS_A = 1u, F_HAS_B = 2u, F_END_AFTER_B = 4u;
+/* hit word: low 31 bits = global triangle of the closest hit or kMissA, bit 31 = shadow ray occluded */
+constexpr uint32_t kMissA = 0x7fffffffu, kOccludedB = 0x80000000u;
+constexpr uint32_t kShadeChunk = 4096u;     /* output space a wf_shade workgroup reserves per atomic */
+
+/* The state of the paths in flight, one record per path, structure of arrays.  Two copies: wf_shade
+   reads copy `cur` at index i and writes the surviving paths COMPACTED into copy `cur ^ 1`, so every
+   kernel reads and writes dense, fully coalesced ranges [0, n) however many paths have died. */
+struct WfState {
+    f4 *o;          /* (o.xyz, mint of slot A) */
+    f4 *dA;         /* (d.xyz, maxt) closest-hit ray */
+    f4 *dB;         /* (d.xyz, maxt) shadow ray, mint = epsilon, same origin */
+    f4 *T_eta, *L_pdf, *Ld;
+    uint32_t *flags;   /* F_* | prev_measure << 4 | depth << 8;  0 = no path in this slot */
+    uint32_t *sidx;    /* the path's camera sample: index into the film's sample store */
+    unsigned long long *rng;
+};
 
 struct WfBuf {
-    f4 *ray_o;      /* (o.xyz, mint of slot A) */
-    f4 *rayA_d;     /* (d.xyz, maxt) closest-hit ray   */
-    f4 *rayB_d;     /* (d.xyz, maxt) shadow ray, mint = epsilon, same origin */
-    f4 *hitA, *hitB;   /* (t, u, v, bits tri) */
-    f4 *T_eta, *L_pdf, *Ld;
-    uint32_t *flags;   /* F_* | prev_measure << 4 | depth << 8 */
-    unsigned long long *rng;
+    WfState st[2];
+    f4 *hit;           /* (t, u, v, hit word) written by wf_extend for the paths of copy `cur` */
     f2 *samp_pos;
     f4 *samp_L;        /* the film's sample store (film.h) */
-    uint32_t *rq[2];   /* ray queues: path << 1 | slot */
-    uint32_t *pq[2];   /* path queues */
     uint32_t *ctr;
     unsigned long long *stats;
+    uint32_t capacity; /* records per copy */
 };
 
 struct WfBatch {
@@ -84,25 +95,8 @@ struct LdsStackW {
 
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
 
-/* wave-aggregated queue slot allocation: one atomic per wave */
-__device__ __forceinline__ uint32_t wave_alloc(uint32_t *counter, bool pred) {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return 0u;
-    const int leader = __ffsll((long long) mask) - 1;
-    uint32_t base = 0;
-    if (lane_id() == leader) base = atomicAdd(counter, (uint32_t) __popcll(mask));
-    base = (uint32_t) __shfl((int) base, leader);
-    return base + (uint32_t) __popcll(mask & ((1ull << lane_id()) - 1ull));
-}
-
-/* pixel of path-local index `pix` inside a tile: wave w covers the 8x8 quad (w&1, w>>1) */
-__device__ __forceinline__ void tile_pixel(int pix, int x0, int y0, int &px, int &py) {
-    const int wave = pix >> 6, lane = pix & 63;
-    px = x0 + ((wave & 1) << 3) + (lane & 7);
-    py = y0 + ((wave >> 1) << 3) + (lane >> 3);
-}
-
 __global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch bt) {
+    const WfState S = b.st[0];
     const uint32_t per_tile = 256u * bt.n_spp;
     const uint32_t n = bt.n_tiles * per_tile;
     uint32_t n_live = 0;        /* per wave */
@@ -114,7 +108,7 @@ __global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch 
             const uint32_t sl = rem >> 8, pix = rem & 255u;
             const uint32_t tile_id = bt.tile_rem + (bt.tile_first + tsel) * bt.tile_mod;
             const int x0 = (int) (tile_id % bt.tiles_x) * kTile, y0 = (int) (tile_id / bt.tiles_x) * kTile;
-            int px, py; tile_pixel((int) pix, x0, y0, px, py);
+            int px, py; film_tile_pixel((int) pix, x0, y0, px, py);
             live = px < sc.camera.width && py < sc.camera.height;
             if (live) {
                 /* renderBlock, src/main.cpp:41-46 */
@@ -127,82 +121,85 @@ __global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch 
                 b.samp_pos[p] = ps;
                 f4 o; o.x = cam.o.x; o.y = cam.o.y; o.z = cam.o.z; o.w = cam.mint;
                 f4 d; d.x = cam.d.x; d.y = cam.d.y; d.z = cam.d.z; d.w = cam.maxt;
-                b.ray_o[p] = o; b.rayA_d[p] = d;
+                S.o[p] = o; S.dA[p] = d;
                 f4 t; t.x = t.y = t.z = 1.0f; t.w = 1.0f;      /* T = 1, eta = 1 */
                 f4 l; l.x = l.y = l.z = 0.0f; l.w = 0.0f;      /* L = 0, pdf_mat = 0 */
-                b.T_eta[p] = t; b.L_pdf[p] = l;
-                b.flags[p] = F_HAS_A | (2u << 4);             /* prev_measure = discrete, depth 0 */
-                b.rng[p] = rng.state;
+                S.T_eta[p] = t; S.L_pdf[p] = l;
+                S.rng[p] = rng.state;
+                S.sidx[p] = p;
             }
         }
-        /* first queues are the identity (no compaction atomics): pixels of edge tiles
-           that fall outside the image carry flags == 0 and are skipped downstream */
-        if (p < n) {
-            if (!live) b.flags[p] = 0u;
-            b.rq[0][p] = p << 1;
-            b.pq[0][p] = p;
-        }
+        /* pixels of edge tiles that fall outside the image: empty slots, dropped by the first wf_shade */
+        if (p < n) S.flags[p] = live ? (F_HAS_A | (2u << 4)) : 0u;      /* prev_measure = discrete, depth 0 */
         n_live += (uint32_t) __popcll(__ballot(live));
     }
-    if (threadIdx.x == 0) { b.ctr[C_RQ_CUR] = n; b.ctr[C_PQ_CUR] = n; }      /* same value from every block */
+    if (threadIdx.x == 0) b.ctr[C_N_CUR] = n;      /* same value from every block */
     if (lane_id() == 0 && n_live) atomicAdd(&b.stats[S_CAM], (unsigned long long) n_live);
 }
 
+/* Accel::rayIntersect for every path of copy `cur`: the shadow ray (if any) first, then the
+   continuation ray, by the same lane; one 16-B hit record per path. */
 template <int STACK, bool COUNT>
-__global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds) {
+__global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStackW<STACK> stack;
     stack.base = reinterpret_cast<int *>(smem) + threadIdx.x; stack.sp = 0;
-    const uint32_t n = b.ctr[C_RQ_CUR];
-    const uint32_t *rq = b.rq[cur];
+    const WfState S = b.st[cur];
+    const uint32_t n = b.ctr[C_N_CUR];
     const int lane = lane_id();
-    Trav tv; tv.active = false; tv.node = 0;
-    uint32_t rid = 0;
+    Trav tv; tv.active = false; tv.node = 0; tv.any = false;
+    uint32_t rid = 0;            /* path << 2 | continuation pending << 1 | shadow ray occluded */
     bool exhausted = n == 0;
-    /* chunk size follows the queue length: big chunks amortise the atomic, small ones keep
+    /* chunk size follows the number of paths: big chunks amortise the atomic, small ones keep
        all waves busy in the long tail of a batch */
     const uint32_t kChunk = min(1024u, max(64u, (n / (gridDim.x * 8u)) & ~63u));
     uint32_t chunk_pos = 0u, chunk_end = 0u;       /* wave-uniform */
     uint32_t nClosest = 0, nShadow = 0;
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
     while (true) {
-        const unsigned long long idle = __ballot(!tv.active);
+        /* a lane is idle when it has no ray in flight: either it needs a new path, or its path's
+           shadow ray is answered and the continuation ray is still to be traced (rid bit 1) */
+        const bool pend = !tv.active && (rid & 2u) != 0u;
+        const unsigned long long idle = __ballot(!tv.active), pending = __ballot(pend);
         const int nIdle = __popcll(idle);
-        if (!exhausted && (nIdle >= refill_threshold || nIdle == 64)) {
-            /* The wave owns a chunk [chunk_pos, chunk_end) of the ray queue and hands it out
-               to idle lanes; one global atomic per kChunk rays (a single hot word sustains
-               only ~90 atomics/us -- MI355X_MICROARCH.md, row "dequeue"). */
-            if (chunk_pos >= chunk_end) {
+        if ((!exhausted || pending != 0ull) && (nIdle >= refill_threshold || nIdle == 64)) {
+            /* The wave owns a chunk [chunk_pos, chunk_end) of the paths and hands it out to idle
+               lanes; one global atomic per kChunk paths (a single hot word sustains only
+               ~90 atomics/us -- MI355X_MICROARCH.md, row "dequeue"). */
+            if (!exhausted && chunk_pos >= chunk_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(&b.ctr[C_HEAD], kChunk);
                 base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
                 chunk_pos = base; chunk_end = min(base + kChunk, n);
                 if (base >= n) { exhausted = true; chunk_pos = chunk_end = 0u; }
             }
+            const unsigned long long fresh = idle & ~pending;
             const uint32_t avail = chunk_end - chunk_pos;
-            const uint32_t rank = (uint32_t) __popcll(idle & ((1ull << lane) - 1ull));
-            if (!tv.active && rank < avail) {
-                rid = rq[chunk_pos + rank];
-                const uint32_t p = rid >> 1;
-                const bool any = (rid & 1u) != 0u;
-                if (b.flags[p] & (any ? F_HAS_B : F_HAS_A)) {     /* 0 for pixels outside the image */
-                    const f4 o = b.ray_o[p];
-                    const f4 d = any ? b.rayB_d[p] : b.rayA_d[p];
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (fresh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) fresh, 0u));   /* set bits below this lane */
+            if (pend || (!tv.active && rank < avail)) {
+                const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
+                const uint32_t fl = pend ? F_HAS_A : S.flags[i];
+                if (fl & (F_HAS_A | F_HAS_B)) {      /* 0: empty slot */
+                    const bool any = (fl & F_HAS_B) != 0u;
+                    const f4 o = S.o[i];
+                    const f4 d = any ? S.dB[i] : S.dA[i];
                     RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z);
                     ray.mint = any ? kEpsilon : o.w; ray.maxt = d.w;
+                    rid = pend ? (rid & ~2u) : ((i << 2) | ((any && (fl & F_HAS_A)) ? 2u : 0u));
                     trav_begin(sc, ray, any, stack, tv);
                     if (any) ++nShadow; else ++nClosest;
-                    if (!tv.active) {            /* empty scene: answer immediately */
-                        f4 h; h.x = ray.maxt; h.y = h.z = 0.0f; h.w = __uint_as_float(kNoHit);
-                        if (any) b.hitB[p] = h; else b.hitA[p] = h;
+                    if (!tv.active) {            /* empty scene: nothing occludes, nothing is hit */
+                        if (rid & 2u) { ++nClosest; rid &= ~2u; }
+                        f4 h; h.x = kInf; h.y = h.z = 0.0f; h.w = __uint_as_float(kMissA);
+                        b.hit[i] = h;
                     }
                 }
             }
-            chunk_pos += min(avail, (uint32_t) nIdle);
+            chunk_pos += min(avail, (uint32_t) __popcll(fresh));
         }
         if (__ballot(tv.active) == 0ull) {
-            if (exhausted) break;
+            if (exhausted && __ballot(!tv.active && (rid & 2u) != 0u) == 0ull) break;
             continue;
         }
         const bool was = tv.active;
@@ -214,8 +211,16 @@ __global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, i
         const bool innerLeft = __ballot(tv.active && tv.node >= 0) != 0ull;
         if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT>(sc, stack, tv, tc);
         if (was && !tv.active) {
-            f4 h; h.x = tv.hit.t; h.y = tv.hit.u; h.z = tv.hit.v; h.w = __uint_as_float(tv.hit.tri);
-            if (rid & 1u) b.hitB[rid >> 1] = h; else b.hitA[rid >> 1] = h;
+            if (rid & 2u) {      /* the shadow ray is answered; the continuation ray of the same vertex is next */
+                rid |= tv.hit.tri != kNoHit ? 1u : 0u;
+            } else {
+                f4 h; h.x = tv.hit.t; h.y = tv.hit.u; h.z = tv.hit.v;
+                uint32_t w;
+                if (tv.any) w = kMissA | (tv.hit.tri != kNoHit ? kOccludedB : 0u);      /* a path with a shadow ray only */
+                else w = (tv.hit.tri == kNoHit ? kMissA : tv.hit.tri) | ((rid & 1u) ? kOccludedB : 0u);
+                h.w = __uint_as_float(w);
+                b.hit[rid >> 2] = h;
+            }
         }
     }
     /* counters: one atomic per wave */
@@ -231,121 +236,140 @@ __global__ __launch_bounds__(kB) void wf_extend(DevScene sc, WfBuf b, int cur, i
     }
 }
 
+/* Integrator::Li, one vertex: consume the shadow result, shade the closest hit, write the surviving
+   path -- with its next shadow / continuation rays -- compacted into the other state copy.
+   A workgroup owns a contiguous range of rounds (256 paths each) and reserves output space in
+   chunks of <= kShadeChunk records with one atomic per chunk; what it leaves unused at the end of a
+   chunk (< 256 records, or the tail of its last chunk) is marked empty (flags = 0). */
 template <int INTEG>
 __global__ __launch_bounds__(kB) void wf_shade(DevScene sc, WfBuf b, int cur, uint32_t s_first, uint32_t n_spp) {
-    const uint32_t n = b.ctr[C_PQ_CUR];
-    const uint32_t *pq = b.pq[cur];
-    uint32_t *rq_next = b.rq[cur ^ 1], *pq_next = b.pq[cur ^ 1];
-    constexpr uint32_t kStageRq = 4096u, kStagePq = 4096u;   /* every path pushes >= 1 ray: pq entries <= rq entries */
-    __shared__ uint32_t s_rq[kStageRq], s_pq[kStagePq], s_n[4];
-    if (threadIdx.x < 4) s_n[threadIdx.x] = 0u;
-    __syncthreads();
-    for (uint32_t base = blockIdx.x * kB; base < n; base += gridDim.x * kB) {
-        const uint32_t i = base + threadIdx.x;
-        const bool valid = i < n;
-        bool pushA = false, pushB = false;
-        uint32_t p = 0;
-        if (valid) {
-            p = pq[i];
-            const uint32_t fl = b.flags[p];
-            if (fl & (F_HAS_A | F_HAS_B)) {       /* flags == 0: pixel outside the image (identity first queue) */
-            f4 L4 = b.L_pdf[p];
-            bool done = false;
-            if (fl & F_HAS_B) {                       /* path_on_shadow: add the emitter sample if unoccluded */
-                const f4 hb = b.hitB[p];
-                if (__float_as_uint(hb.w) == kNoHit) {
-                    const f4 ld = b.Ld[p];
-                    L4.x = L4.x + ld.x; L4.y = L4.y + ld.y; L4.z = L4.z + ld.z;
-                }
-                if (fl & F_END_AFTER_B) done = true;
-            }
-            PathState st;
-            st.L = mk3(L4.x, L4.y, L4.z);
-            if (!done) {
-                const f4 ha = b.hitA[p];
-                const f4 d4 = b.rayA_d[p];
-                const f4 t4 = b.T_eta[p];
-                Hit hit; hit.t = ha.x; hit.u = ha.y; hit.v = ha.z; hit.tri = __float_as_uint(ha.w);
-                const bool found = hit.tri != kNoHit;
-                hit.mesh = found ? sc.tri_mesh[hit.tri] : kNoHit;
-                st.T = mk3(t4.x, t4.y, t4.z); st.eta = t4.w; st.pdf_mat = L4.w;
-                st.Ld = mk3(0.0f); st.cont_d = mk3(0.0f);
-                st.prev_measure = (int32_t) ((fl >> 4) & 3u); st.depth = (int32_t) (fl >> 8);
-                st.phase = PH_CLOSEST; st.end_after_shadow = 0;
-                st.ray.o = st.ray.d = mk3(0.0f); st.ray.mint = st.ray.maxt = 0.0f;
-                /* pcg32 stream of this camera sample: inc from the sample index, state from HBM */
-                const uint32_t per_tile = 256u * n_spp;
-                const uint32_t sl = (p % per_tile) >> 8;
-                st.rng.inc = ((uint64_t) (s_first + sl) << 1u) | 1u;
-                st.rng.state = b.rng[p];
-                done = path_on_closest<INTEG>(sc, st, hit, found, mk3(d4.x, d4.y, d4.z));
-                if (!done) {
-                    f4 o; o.x = st.ray.o.x; o.y = st.ray.o.y; o.z = st.ray.o.z;
-                    uint32_t nf = ((uint32_t) st.prev_measure << 4) | ((uint32_t) st.depth << 8);
-                    if (st.phase == PH_SHADOW) {
-                        f4 db; db.x = st.ray.d.x; db.y = st.ray.d.y; db.z = st.ray.d.z; db.w = st.ray.maxt;
-                        b.rayB_d[p] = db;
-                        f4 ld; ld.x = st.Ld.x; ld.y = st.Ld.y; ld.z = st.Ld.z; ld.w = 0.0f;
-                        b.Ld[p] = ld;
-                        pushB = true; nf |= F_HAS_B;
-                        o.w = kEpsilon;
-                        if (st.end_after_shadow) nf |= F_END_AFTER_B;
-                        else {
-                            f4 da; da.x = st.cont_d.x; da.y = st.cont_d.y; da.z = st.cont_d.z; da.w = kInf;
-                            b.rayA_d[p] = da; pushA = true; nf |= F_HAS_A;
-                        }
-                    } else {
-                        f4 da; da.x = st.ray.d.x; da.y = st.ray.d.y; da.z = st.ray.d.z; da.w = st.ray.maxt;
-                        b.rayA_d[p] = da; pushA = true; nf |= F_HAS_A;
-                        o.w = st.ray.mint;
+    const WfState S = b.st[cur], D = b.st[cur ^ 1];
+    const uint32_t n = b.ctr[C_N_CUR];
+    const uint32_t rounds_total = (n + kB - 1) / kB;
+    const uint32_t rounds_per_block = (rounds_total + gridDim.x - 1) / gridDim.x;
+    const uint32_t r0 = blockIdx.x * rounds_per_block, r1 = min(rounds_total, r0 + rounds_per_block);
+    const uint32_t chunk_len = min(kShadeChunk, rounds_per_block * kB);
+    __shared__ uint32_t s_wcnt[2][4], s_newbase;
+    uint32_t out_base = 0u, out_used = 0u, out_len = 0u;     /* workgroup-uniform */
+    bool overflow = false;
+    const int wave = (int) (threadIdx.x >> 6), lane = lane_id();
+    const uint32_t per_tile = 256u * n_spp;
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint32_t i = r * kB + threadIdx.x;
+        bool survive = false;
+        f4 n_o, n_dA, n_dB, n_T, n_L, n_Ld;
+        uint32_t n_fl = 0u, sidx = 0u;
+        unsigned long long n_rng = 0ull;
+        if (i < n) {
+            const uint32_t fl = S.flags[i];
+            if (fl & (F_HAS_A | F_HAS_B)) {
+                sidx = S.sidx[i];
+                const f4 h = b.hit[i];
+                const uint32_t hw = __float_as_uint(h.w);
+                f4 L4 = S.L_pdf[i];
+                bool done = false;
+                if (fl & F_HAS_B) {                       /* path_on_shadow: add the emitter sample if unoccluded */
+                    if (!(hw & kOccludedB)) {
+                        const f4 ld = S.Ld[i];
+                        L4.x = L4.x + ld.x; L4.y = L4.y + ld.y; L4.z = L4.z + ld.z;
                     }
-                    b.ray_o[p] = o;
-                    b.flags[p] = nf;
-                    f4 t; t.x = st.T.x; t.y = st.T.y; t.z = st.T.z; t.w = st.eta;
-                    b.T_eta[p] = t;
-                    f4 l; l.x = st.L.x; l.y = st.L.y; l.z = st.L.z; l.w = st.pdf_mat;
-                    b.L_pdf[p] = l;
-                    b.rng[p] = st.rng.state;
+                    if (fl & F_END_AFTER_B) done = true;
+                }
+                PathState st;
+                st.L = mk3(L4.x, L4.y, L4.z);
+                if (!done) {
+                    const f4 d4 = S.dA[i];
+                    const f4 t4 = S.T_eta[i];
+                    Hit hit; hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = hw & kMissA;
+                    const bool found = hit.tri != kMissA;
+                    if (!found) hit.tri = kNoHit;
+                    hit.mesh = found ? sc.tri_mesh[hit.tri] : kNoHit;
+                    st.T = mk3(t4.x, t4.y, t4.z); st.eta = t4.w; st.pdf_mat = L4.w;
+                    st.Ld = mk3(0.0f); st.cont_d = mk3(0.0f);
+                    st.prev_measure = (int32_t) ((fl >> 4) & 3u); st.depth = (int32_t) (fl >> 8);
+                    st.phase = PH_CLOSEST; st.end_after_shadow = 0;
+                    st.ray.o = st.ray.d = mk3(0.0f); st.ray.mint = st.ray.maxt = 0.0f;
+                    /* pcg32 stream of this camera sample: inc from the sample index, state from HBM */
+                    const uint32_t sl = (sidx % per_tile) >> 8;
+                    st.rng.inc = ((uint64_t) (s_first + sl) << 1u) | 1u;
+                    st.rng.state = S.rng[i];
+                    done = path_on_closest<INTEG>(sc, st, hit, found, mk3(d4.x, d4.y, d4.z));
+                    if (!done) {
+                        survive = true;
+                        n_o.x = st.ray.o.x; n_o.y = st.ray.o.y; n_o.z = st.ray.o.z;
+                        n_fl = ((uint32_t) st.prev_measure << 4) | ((uint32_t) st.depth << 8);
+                        if (st.phase == PH_SHADOW) {
+                            n_dB.x = st.ray.d.x; n_dB.y = st.ray.d.y; n_dB.z = st.ray.d.z; n_dB.w = st.ray.maxt;
+                            n_Ld.x = st.Ld.x; n_Ld.y = st.Ld.y; n_Ld.z = st.Ld.z; n_Ld.w = 0.0f;
+                            n_fl |= F_HAS_B;
+                            n_o.w = kEpsilon;
+                            if (st.end_after_shadow) n_fl |= F_END_AFTER_B;
+                            else {
+                                n_dA.x = st.cont_d.x; n_dA.y = st.cont_d.y; n_dA.z = st.cont_d.z; n_dA.w = kInf;
+                                n_fl |= F_HAS_A;
+                            }
+                        } else {
+                            n_dA.x = st.ray.d.x; n_dA.y = st.ray.d.y; n_dA.z = st.ray.d.z; n_dA.w = st.ray.maxt;
+                            n_fl |= F_HAS_A;
+                            n_o.w = st.ray.mint;
+                        }
+                        n_T.x = st.T.x; n_T.y = st.T.y; n_T.z = st.T.z; n_T.w = st.eta;
+                        n_L.x = st.L.x; n_L.y = st.L.y; n_L.z = st.L.z; n_L.w = st.pdf_mat;
+                        n_rng = st.rng.state;
+                    }
+                }
+                if (done) {
+                    f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 0.0f;
+                    b.samp_L[sidx] = out;
                 }
             }
-            if (done) {
-                f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 0.0f;
-                b.samp_L[p] = out;
-            }
-            }
         }
-        /* compaction: stage the new queue entries of several rounds in LDS, then reserve
-           their place in the global queues with ONE atomic per queue per flush */
-        if (pushA) s_rq[atomicAdd(&s_n[0], 1u)] = p << 1;
-        if (pushB) s_rq[atomicAdd(&s_n[0], 1u)] = (p << 1) | 1u;
-        if (pushA || pushB) s_pq[atomicAdd(&s_n[1], 1u)] = p;
+        /* compaction: rank of this survivor among the workgroup's survivors of the round */
+        const unsigned long long mask = __ballot(survive);
+        if (lane == 0) s_wcnt[r & 1u][wave] = (uint32_t) __popcll(mask);
         __syncthreads();
-        const bool last = base + gridDim.x * kB >= n;
-        if (s_n[0] + 2 * kB > kStageRq || last) {
-            if (threadIdx.x == 0) {
-                s_n[2] = s_n[0] ? atomicAdd(&b.ctr[C_RQ_NEXT], s_n[0]) : 0u;
-                s_n[3] = s_n[1] ? atomicAdd(&b.ctr[C_PQ_NEXT], s_n[1]) : 0u;
-            }
+        const uint32_t c0 = s_wcnt[r & 1u][0], c1 = s_wcnt[r & 1u][1], c2 = s_wcnt[r & 1u][2], c3 = s_wcnt[r & 1u][3];
+        const uint32_t c = c0 + c1 + c2 + c3;
+        uint32_t off = (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
+        off += wave > 0 ? c0 : 0u; off += wave > 1 ? c1 : 0u; off += wave > 2 ? c2 : 0u;
+        if (c != 0u && out_used + c > out_len) {         /* workgroup-uniform: reserve the next chunk */
+            for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kB) D.flags[out_base + k] = 0u;
+            if (threadIdx.x == 0) s_newbase = atomicAdd(&b.ctr[C_N_NEXT], chunk_len);
             __syncthreads();
-            for (uint32_t k = threadIdx.x; k < s_n[0]; k += kB) rq_next[s_n[2] + k] = s_rq[k];
-            for (uint32_t k = threadIdx.x; k < s_n[1]; k += kB) pq_next[s_n[3] + k] = s_pq[k];
-            __syncthreads();
-            if (threadIdx.x == 0) { s_n[0] = 0u; s_n[1] = 0u; }
-            __syncthreads();
+            out_base = s_newbase; out_used = 0u; out_len = chunk_len;
+            if (out_base + chunk_len > b.capacity) { overflow = true; out_len = 0u; }
         }
+        if (survive && !overflow) {
+            const uint32_t j = out_base + out_used + off;
+            D.o[j] = n_o; D.T_eta[j] = n_T; D.L_pdf[j] = n_L; D.flags[j] = n_fl; D.rng[j] = n_rng; D.sidx[j] = sidx;
+            if (n_fl & F_HAS_A) D.dA[j] = n_dA;
+            if (n_fl & F_HAS_B) { D.dB[j] = n_dB; D.Ld[j] = n_Ld; }
+        }
+        if (!overflow) out_used += c;
     }
+    for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kB) D.flags[out_base + k] = 0u;
+    if (overflow && threadIdx.x == 0) b.ctr[C_OVERFLOW] = 1u;
 }
 
 __global__ void wf_swap(uint32_t *ctr) {
-    ctr[C_RQ_CUR] = ctr[C_RQ_NEXT]; ctr[C_RQ_NEXT] = 0;
-    ctr[C_PQ_CUR] = ctr[C_PQ_NEXT]; ctr[C_PQ_NEXT] = 0;
+    ctr[C_N_CUR] = ctr[C_N_NEXT]; ctr[C_N_NEXT] = 0;
     ctr[C_HEAD] = 0;
 }
 
 /* ----------------------------------------------------------- host driver */
+constexpr int kShadeGridMax = 4096;
+
+int shade_grid(size_t paths) { return (int) std::min<size_t>(kShadeGridMax, std::max<size_t>(64, (paths + kShadeChunk - 1) / kShadeChunk)); }
+
+/* records per state copy for a batch of `paths`: survivors + what compaction leaves unused (< 256 per
+   chunk of kShadeChunk, plus the tail of every workgroup's last chunk) */
+size_t state_capacity(size_t paths) {
+    return paths + paths / 14 + (size_t) (kShadeChunk + 256) * (size_t) shade_grid(paths) + 1024;
+}
+
 struct Pool {
     std::vector<void *> allocs;
-    size_t capacity = 0;       /* paths */
+    size_t capacity = 0;       /* records per copy, all pipes */
     size_t bytes = 0;
     WfBuf buf;
     uint32_t *h_ctr = nullptr; /* pinned */
@@ -368,21 +392,24 @@ template <class T> std::string pool_alloc(T **out, size_t count) {
     return std::string();
 }
 
-std::string ensure_pool(size_t paths) {
+std::string ensure_pool(size_t records) {
     int dev = 0; (void) hipGetDevice(&dev);
-    if (g_pool.capacity >= paths && g_pool.device == dev) return std::string();
+    if (g_pool.capacity >= records && g_pool.device == dev) return std::string();
     g_pool.release();
     g_pool.device = dev;
     WfBuf &b = g_pool.buf;
     std::string e;
 #define A(field, count) if (!(e = pool_alloc(&b.field, (count))).empty()) return e
-    A(ray_o, paths); A(rayA_d, paths); A(rayB_d, paths); A(hitA, paths); A(hitB, paths);
-    A(T_eta, paths); A(L_pdf, paths); A(Ld, paths); A(flags, paths); A(rng, paths);
-    A(rq[0], 2 * paths); A(rq[1], 2 * paths); A(pq[0], paths); A(pq[1], paths);
+    for (int k = 0; k < 2; ++k) {
+        A(st[k].o, records); A(st[k].dA, records); A(st[k].dB, records);
+        A(st[k].T_eta, records); A(st[k].L_pdf, records); A(st[k].Ld, records);
+        A(st[k].flags, records); A(st[k].sidx, records); A(st[k].rng, records);
+    }
+    A(hit, records);
     A(ctr, (size_t) 2 * C_COUNT); A(stats, (size_t) 2 * S_COUNT);
 #undef A
     WF_TRY(hipHostMalloc((void **) &g_pool.h_ctr, 2 * C_COUNT * sizeof(uint32_t)));
-    g_pool.capacity = paths;
+    g_pool.capacity = records;
     return std::string();
 }
 
@@ -397,8 +424,8 @@ void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, 
 #undef E
 }
 
-void launch_shade(const DevScene &sc, const WfBuf &b, int cur, uint32_t s_first, uint32_t n_spp, hipStream_t s) {
-    const dim3 grid(4096), block(kB);
+void launch_shade(const DevScene &sc, const WfBuf &b, int cur, uint32_t s_first, uint32_t n_spp, int grid_, hipStream_t s) {
+    const dim3 grid(grid_), block(kB);
     switch (sc.integrator.type) {
 #define SH(I) case I: hipLaunchKernelGGL((wf_shade<I>), grid, block, 0, s, sc, b, cur, s_first, n_spp); break;
         SH(0) SH(1) SH(2) SH(3) SH(4) SH(5) SH(6)
@@ -431,12 +458,16 @@ struct Pipe {
 static hipStream_t g_streams[2] = {nullptr, nullptr};
 static hipEvent_t g_events[3] = {nullptr, nullptr, nullptr};
 
-static WfBuf slice(const WfBuf &b, size_t off, int k) {
+static WfBuf slice(const WfBuf &b, size_t off, size_t records, int k) {
     WfBuf v = b;
-    v.ray_o += off; v.rayA_d += off; v.rayB_d += off; v.hitA += off; v.hitB += off;
-    v.T_eta += off; v.L_pdf += off; v.Ld += off; v.flags += off; v.rng += off;
-    v.rq[0] += 2 * off; v.rq[1] += 2 * off; v.pq[0] += off; v.pq[1] += off;
+    for (int c = 0; c < 2; ++c) {
+        WfState &t = v.st[c];
+        t.o += off; t.dA += off; t.dB += off; t.T_eta += off; t.L_pdf += off; t.Ld += off;
+        t.flags += off; t.sidx += off; t.rng += off;
+    }
+    v.hit += off;
     v.ctr += (size_t) k * C_COUNT; v.stats += (size_t) k * S_COUNT;
+    v.capacity = (uint32_t) records;
     return v;
 }
 
@@ -445,7 +476,7 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     stats = WfStats();
     if (L.n_sel_tiles == 0 || L.spp_count == 0) return std::string();
 
-    int n_pipes = 2;
+    int n_pipes = 1;        /* measured: 2 pipes are 5 % slower (wf_extend wants all 8 waves/SIMD); NORI_HIP_WF_PIPES=2 to try */
     if (const char *e = getenv("NORI_HIP_WF_PIPES")) n_pipes = std::min(2, std::max(1, atoi(e)));
     if (L.n_sel_tiles < 2 || (size_t) L.n_sel_tiles * 256 * L.spp_count < ((size_t) 1 << 22)) n_pipes = 1;
 
@@ -464,7 +495,10 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
         P.t0 = P.tile_lo; P.s0 = 0;
     }
     const size_t per_pipe = std::max(need[0], need[1]);
-    std::string err = ensure_pool(per_pipe * n_pipes);
+    const size_t records = state_capacity(per_pipe);            /* per pipe, per state copy */
+    const int sh_grid = shade_grid(per_pipe);
+    if (records >= ((size_t) 1 << 30)) return "wavefront: wavefront_paths too large (state index is 30 bits)";
+    std::string err = ensure_pool(records * n_pipes);
     if (!err.empty()) return err;
     FilmStore film;
     err = film_prepare(per_pipe * n_pipes, L.n_sel_tiles, L.tile_w, s, film);
@@ -480,7 +514,7 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             if (!g_streams[k]) WF_TRY(hipStreamCreateWithFlags(&g_streams[k], hipStreamNonBlocking));
             P.stream = g_streams[k];
         }
-        P.b = slice(g_pool.buf, per_pipe * k, k);
+        P.b = slice(g_pool.buf, records * k, records, k);
         P.film = film; P.film.pos += per_pipe * k; P.film.L += per_pipe * k;
         P.b.samp_pos = P.film.pos; P.b.samp_L = P.film.L;
         P.h_ctr = g_pool.h_ctr + (size_t) k * C_COUNT;
@@ -526,7 +560,7 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
                 launch_extend_dyn(sc, P.b, P.cur, thresholds, L.stack_depth, L.count_traversal, extend_grid, P.stream);
-                launch_shade(sc, P.b, P.cur, P.bt.s_first, P.bt.n_spp, P.stream);
+                launch_shade(sc, P.b, P.cur, P.bt.s_first, P.bt.n_spp, sh_grid, P.stream);
                 hipLaunchKernelGGL(wf_swap, dim3(1), dim3(1), 0, P.stream, P.b.ctr);
                 P.cur ^= 1;
                 stats.n_launches += 3;
@@ -538,7 +572,8 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             if (pipes[k].active) WF_TRY(hipStreamSynchronize(pipes[k].stream));
         for (int k = 0; k < n_pipes; ++k) {
             Pipe &P = pipes[k];
-            if (!P.active || P.h_ctr[C_PQ_CUR] != 0) continue;
+            if (P.active && P.h_ctr[C_OVERFLOW] != 0) return "wavefront: path state pool overflow";
+            if (!P.active || P.h_ctr[C_N_CUR] != 0) continue;
             /* batch done: splat its samples (each pipe owns its tiles' accumulators) */
             fl.tile_first = P.bt.tile_first; fl.store_tile_first = P.bt.tile_first; fl.n_tiles = P.bt.n_tiles; fl.n_spp = P.bt.n_spp;
             film_gather(sc, d_filter_table, P.film, fl, P.stream);

@@ -89,3 +89,16 @@ def test_wavefront_empty_scene_and_options(renderer_factory):
         r.set_option("engine", "nope")
     with pytest.raises(NoriError):
         r.set_option("bogus", 1)
+
+
+@pytest.mark.gpu
+def test_gpu_large_scene_lbvh_both_engines():
+    """configs[4] in small: 2 M-triangle terrain, BVH built on the device, both engines; camera-ray hits
+    bit-identical to the oracle's brute-force scan, engines agree on every ray count."""
+    from tests.stress_large import run
+    a = run(n_tris=2_000_000, size=128, spp=4, check=96, builder=1, engine="wavefront", reps=1)
+    b = run(n_tris=2_000_000, size=128, spp=4, check=0, builder=1, engine="megakernel", reps=1)
+    assert a["bit_exact"] and a["hits"] > 30 and a["finite"] and b["finite"]
+    assert a["max_depth"] < 64 and a["build_ms"] < 2000
+    assert a["rays"] == b["rays"] and a["node_tests_per_ray"] == b["node_tests_per_ray"]
+    assert abs(a["mean_w"] - b["mean_w"]) < 1e-6
