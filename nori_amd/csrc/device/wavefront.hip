@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -45,7 +46,8 @@ namespace {
 
 constexpr int kB = 256;
 
-enum { C_N_CUR = 0, C_N_NEXT = 1, C_HEAD = 2, C_OVERFLOW = 3, C_COUNT = 8 };
+/* counters: path count and dynamic-chunk head per state copy (index + copy), overflow flag */
+enum { C_N = 0, C_HEAD = 2, C_OVERFLOW = 4, C_COUNT = 8 };
 enum { S_CAM = 0, S_CLOSEST = 1, S_SHADOW = 2, S_NODES = 3, S_TRIS = 4, S_INVALID = 5, S_COUNT = 8 };
 
 /* path flags */
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch 
         if (p < n) S.flags[p] = live ? (F_HAS_A | (2u << 4)) : 0u;      /* prev_measure = discrete, depth 0 */
         n_live += (uint32_t) __popcll(__ballot(live));
     }
-    if (threadIdx.x == 0) b.ctr[C_N_CUR] = n;      /* same value from every block */
+    if (threadIdx.x == 0) b.ctr[C_N + 0] = n;      /* same value from every block */
     if (lane_id() == 0 && n_live) atomicAdd(&b.stats[S_CAM], (unsigned long long) n_live);
 }
 
@@ -146,15 +148,25 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
     LdsStackW<STACK> stack;
     stack.base = reinterpret_cast<int *>(smem) + threadIdx.x; stack.sp = 0;
     const WfState S = b.st[cur];
-    const uint32_t n = b.ctr[C_N_CUR];
+    const uint32_t n = b.ctr[C_N + cur];
+    /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
+       reset them for the wf_shade that follows this kernel and for the next wf_extend */
+    if (blockIdx.x == 0 && threadIdx.x == 0) { b.ctr[C_N + (cur ^ 1)] = 0u; b.ctr[C_HEAD + (cur ^ 1)] = 0u; }
     const int lane = lane_id();
     Trav tv; tv.active = false; tv.node = 0; tv.any = false;
     uint32_t rid = 0;            /* path << 2 | continuation pending << 1 | shadow ray occluded */
     bool exhausted = n == 0;
-    /* chunk size follows the number of paths: big chunks amortise the atomic, small ones keep
-       all waves busy in the long tail of a batch */
-    const uint32_t kChunk = min(1024u, max(64u, (n / (gridDim.x * 8u)) & ~63u));
-    uint32_t chunk_pos = 0u, chunk_end = 0u;       /* wave-uniform */
+    /* Paths are handed to waves in chunks: every wave starts with a static chunk (no atomic), the
+       rest -- about half, for load balance -- is claimed dynamically with one atomic per chunk.  The
+       chunk size follows the number of paths: big chunks amortise the atomic, small ones keep all
+       waves busy; in the long tail of a batch the static chunks cover everything and no wave
+       touches the counter (a single hot word sustains only ~90 atomics/us --
+       MI355X_MICROARCH.md, row "dequeue" -- which used to cost 0.2 ms per tail iteration). */
+    const uint32_t n_waves = gridDim.x * (kB / 64u), wave_id = blockIdx.x * (kB / 64u) + (threadIdx.x >> 6);
+    const uint32_t kChunk = n <= n_waves * 1024u ? (((n + n_waves - 1u) / n_waves + 63u) & ~63u)      /* all static */
+                                                 : min(1024u, max(64u, (n / (n_waves * 2u)) & ~63u));
+    const uint32_t dyn0 = n_waves * kChunk;        /* first dynamically claimed path */
+    uint32_t chunk_pos = min(wave_id * kChunk, n), chunk_end = min(chunk_pos + kChunk, n);       /* wave-uniform */
     uint32_t nClosest = 0, nShadow = 0;
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
     while (true) {
@@ -164,13 +176,13 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
         const unsigned long long idle = __ballot(!tv.active), pending = __ballot(pend);
         const int nIdle = __popcll(idle);
         if ((!exhausted || pending != 0ull) && (nIdle >= refill_threshold || nIdle == 64)) {
-            /* The wave owns a chunk [chunk_pos, chunk_end) of the paths and hands it out to idle
-               lanes; one global atomic per kChunk paths (a single hot word sustains only
-               ~90 atomics/us -- MI355X_MICROARCH.md, row "dequeue"). */
+            /* the wave owns [chunk_pos, chunk_end) and hands it out to its idle lanes */
             if (!exhausted && chunk_pos >= chunk_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&b.ctr[C_HEAD], kChunk);
-                base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                uint32_t base = n;
+                if (dyn0 < n) {
+                    if (lane == 0) base = dyn0 + atomicAdd(&b.ctr[C_HEAD + cur], kChunk);
+                    base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                }
                 chunk_pos = base; chunk_end = min(base + kChunk, n);
                 if (base >= n) { exhausted = true; chunk_pos = chunk_end = 0u; }
             }
@@ -239,12 +251,12 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
 /* Integrator::Li, one vertex: consume the shadow result, shade the closest hit, write the surviving
    path -- with its next shadow / continuation rays -- compacted into the other state copy.
    A workgroup owns a contiguous range of rounds (256 paths each) and reserves output space in
-   chunks of <= kShadeChunk records with one atomic per chunk; what it leaves unused at the end of a
-   chunk (< 256 records, or the tail of its last chunk) is marked empty (flags = 0). */
+   chunks of <= kShadeChunk records with one atomic per chunk, sized by the survival rate it sees;
+   what it leaves unused of its last chunk is marked empty (flags = 0) and dropped by the next pass. */
 template <int INTEG>
-__global__ __launch_bounds__(kB) void wf_shade(DevScene sc, WfBuf b, int cur, uint32_t s_first, uint32_t n_spp) {
+__global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, uint32_t s_first, uint32_t n_spp) {
     const WfState S = b.st[cur], D = b.st[cur ^ 1];
-    const uint32_t n = b.ctr[C_N_CUR];
+    const uint32_t n = b.ctr[C_N + cur];
     const uint32_t rounds_total = (n + kB - 1) / kB;
     const uint32_t rounds_per_block = (rounds_total + gridDim.x - 1) / gridDim.x;
     const uint32_t r0 = blockIdx.x * rounds_per_block, r1 = min(rounds_total, r0 + rounds_per_block);
@@ -332,28 +344,28 @@ __global__ __launch_bounds__(kB) void wf_shade(DevScene sc, WfBuf b, int cur, ui
         const uint32_t c = c0 + c1 + c2 + c3;
         uint32_t off = (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
         off += wave > 0 ? c0 : 0u; off += wave > 1 ? c1 : 0u; off += wave > 2 ? c2 : 0u;
-        if (c != 0u && out_used + c > out_len) {         /* workgroup-uniform: reserve the next chunk */
-            for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kB) D.flags[out_base + k] = 0u;
-            if (threadIdx.x == 0) s_newbase = atomicAdd(&b.ctr[C_N_NEXT], chunk_len);
+        /* the round's survivors fill what is left of the current chunk, the rest opens a new one */
+        const uint32_t room = out_len - out_used;
+        uint32_t new_base = 0u, want = 0u;
+        if (c > room) {                                  /* workgroup-uniform: reserve the next chunk */
+            const uint32_t expect = c * (r1 - r);        /* survivors from here to the end of the range, at this round's rate */
+            want = r + 1u == r1 ? c - room : min(kShadeChunk, max(c - room, ((expect + expect / 8u + 63u) & ~63u) - min(room, expect)));
+            if (threadIdx.x == 0) s_newbase = atomicAdd(&b.ctr[C_N + (cur ^ 1)], want);
             __syncthreads();
-            out_base = s_newbase; out_used = 0u; out_len = chunk_len;
-            if (out_base + chunk_len > b.capacity) { overflow = true; out_len = 0u; }
+            new_base = s_newbase;
+            if (new_base + want > b.capacity) overflow = true;
         }
         if (survive && !overflow) {
-            const uint32_t j = out_base + out_used + off;
+            const uint32_t j = off < room ? out_base + out_used + off : new_base + (off - room);
             D.o[j] = n_o; D.T_eta[j] = n_T; D.L_pdf[j] = n_L; D.flags[j] = n_fl; D.rng[j] = n_rng; D.sidx[j] = sidx;
             if (n_fl & F_HAS_A) D.dA[j] = n_dA;
             if (n_fl & F_HAS_B) { D.dB[j] = n_dB; D.Ld[j] = n_Ld; }
         }
-        if (!overflow) out_used += c;
+        if (c > room) { out_base = new_base; out_used = c - room; out_len = want; }
+        else out_used += c;
     }
     for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kB) D.flags[out_base + k] = 0u;
     if (overflow && threadIdx.x == 0) b.ctr[C_OVERFLOW] = 1u;
-}
-
-__global__ void wf_swap(uint32_t *ctr) {
-    ctr[C_N_CUR] = ctr[C_N_NEXT]; ctr[C_N_NEXT] = 0;
-    ctr[C_HEAD] = 0;
 }
 
 /* ----------------------------------------------------------- host driver */
@@ -361,10 +373,11 @@ constexpr int kShadeGridMax = 4096;
 
 int shade_grid(size_t paths) { return (int) std::min<size_t>(kShadeGridMax, std::max<size_t>(64, (paths + kShadeChunk - 1) / kShadeChunk)); }
 
-/* records per state copy for a batch of `paths`: survivors + what compaction leaves unused (< 256 per
-   chunk of kShadeChunk, plus the tail of every workgroup's last chunk) */
+/* records per state copy for a batch of `paths`: the survivors plus the unused tail of every
+   wf_shade workgroup's last chunk (a round that does not fit is split across two chunks, so
+   nothing else is ever left empty) */
 size_t state_capacity(size_t paths) {
-    return paths + paths / 14 + (size_t) (kShadeChunk + 256) * (size_t) shade_grid(paths) + 1024;
+    return paths + (size_t) kShadeChunk * (size_t) shade_grid(paths) + 1024;
 }
 
 struct Pool {
@@ -536,6 +549,10 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(8, std::max(1, atoi(e)));
     const int extend_grid = 256 * per_cu;
 
+    int sync_every = 6;      /* path-loop iterations between two readbacks of the path count */
+    if (const char *e = getenv("NORI_HIP_WF_SYNC_EVERY")) sync_every = std::min(64, std::max(1, atoi(e)));
+    const bool census = getenv("NORI_HIP_CENSUS") != nullptr;
+
     FilmLaunch fl;
     fl.tile_mod = L.tile_mod; fl.tile_rem = L.tile_rem; fl.tiles_x = L.tiles_x; fl.tiles_y = L.tiles_y; fl.tile_w = L.tile_w;
 
@@ -555,15 +572,14 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             P.cur = 0; P.active = true; any = true;
         }
         if (!any) break;
-        for (int it = 0; it < 6; ++it)
+        for (int it = 0; it < sync_every; ++it)
             for (int k = 0; k < n_pipes; ++k) {
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
                 launch_extend_dyn(sc, P.b, P.cur, thresholds, L.stack_depth, L.count_traversal, extend_grid, P.stream);
                 launch_shade(sc, P.b, P.cur, P.bt.s_first, P.bt.n_spp, sh_grid, P.stream);
-                hipLaunchKernelGGL(wf_swap, dim3(1), dim3(1), 0, P.stream, P.b.ctr);
                 P.cur ^= 1;
-                stats.n_launches += 3;
+                stats.n_launches += 2;
                 if (k == 0) stats.n_iterations++;
             }
         for (int k = 0; k < n_pipes; ++k)
@@ -573,7 +589,8 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
         for (int k = 0; k < n_pipes; ++k) {
             Pipe &P = pipes[k];
             if (P.active && P.h_ctr[C_OVERFLOW] != 0) return "wavefront: path state pool overflow";
-            if (!P.active || P.h_ctr[C_N_CUR] != 0) continue;
+            if (census && P.active) fprintf(stderr, "[wavefront] pipe %d iteration %u: %u path slots\n", k, stats.n_iterations, P.h_ctr[C_N + P.cur]);
+            if (!P.active || P.h_ctr[C_N + P.cur] != 0) continue;
             /* batch done: splat its samples (each pipe owns its tiles' accumulators) */
             fl.tile_first = P.bt.tile_first; fl.store_tile_first = P.bt.tile_first; fl.n_tiles = P.bt.n_tiles; fl.n_spp = P.bt.n_spp;
             film_gather(sc, d_filter_table, P.film, fl, P.stream);
