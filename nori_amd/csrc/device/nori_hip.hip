@@ -808,7 +808,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         wl.spp_begin = a.spp_begin; wl.spp_count = a.spp_count; wl.tile_mod = a.tile_mod; wl.tile_rem = a.tile_rem;
         wl.tiles_x = a.tiles_x; wl.tiles_y = a.tiles_y; wl.n_sel_tiles = a.n_sel_tiles; wl.tile_w = a.tile_w;
         const uint32_t need = ctx->bvh.max_depth + 1;
-        wl.stack_depth = need <= 16 ? 16 : need <= 24 ? 24 : need <= 32 ? 32 : 64;
+        wl.stack_depth = (int) need;
         wl.count_traversal = params->count_traversal != 0;
         wl.max_paths = ctx->wavefront_paths;
         std::string err = wavefront_render(ctx->dev, ctx->d_filter, wl, (float *) d_rgbw, s, wst);

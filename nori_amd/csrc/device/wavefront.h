@@ -12,7 +12,7 @@ struct WfLaunch {
     uint32_t tile_mod, tile_rem;
     uint32_t tiles_x, tiles_y, n_sel_tiles;
     int32_t tile_w;
-    int stack_depth;            /* 16 / 24 / 32 / 64 */
+    int stack_depth;            /* traversal stack entries the tree needs: max_depth + 1 */
     bool count_traversal;
     size_t max_paths;           /* paths in flight per batch */
 };

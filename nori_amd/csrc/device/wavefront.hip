@@ -77,6 +77,7 @@ struct WfBuf {
     uint32_t *ctr;
     unsigned long long *stats;
     uint32_t capacity; /* records per copy */
+    int *stack_spill;  /* [entry beyond the LDS stack][lane of the wf_extend grid] */
 };
 
 struct WfBatch {
@@ -86,13 +87,26 @@ struct WfBatch {
     int32_t tile_w;
 };
 
-template <int DEPTH>
+/* Per-lane traversal stack: the first DEPTH entries in LDS ([entry][thread], bank = lane), deeper
+   ones -- rare, and only in trees deeper than DEPTH -- in a per-lane column of a global buffer.  A
+   small DEPTH keeps wf_extend at 8 waves/SIMD however deep the tree is (a 64-entry LDS stack would
+   allow 2), which is what hides the HBM latency of scenes that do not fit in L2. */
+template <int DEPTH, bool SPILL>
 struct LdsStackW {
     int *base; int sp;
+    int *spill; uint32_t spill_stride;      /* wave-uniform base, lanes in flight */
     __device__ __forceinline__ void reset() { sp = 0; }
     __device__ __forceinline__ bool empty() const { return sp == 0; }
-    __device__ __forceinline__ void push(int v) { if (sp < DEPTH) base[sp * kB] = v; sp++; }
-    __device__ __forceinline__ int pop() { sp--; return sp < DEPTH ? base[sp * kB] : 0; }
+    __device__ __forceinline__ void push(int v) {
+        if (sp < DEPTH) base[sp * kB] = v;
+        else if (SPILL) spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * kB + threadIdx.x] = v;
+        sp++;
+    }
+    __device__ __forceinline__ int pop() {
+        sp--;
+        if (sp < DEPTH) return base[sp * kB];
+        return SPILL ? spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * kB + threadIdx.x] : 0;
+    }
 };
 
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
@@ -141,12 +155,13 @@ __global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch 
 
 /* Accel::rayIntersect for every path of copy `cur`: the shadow ray (if any) first, then the
    continuation ray, by the same lane; one 16-B hit record per path. */
-template <int STACK, bool COUNT>
+template <int STACK, bool SPILL, bool COUNT>
 __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LdsStackW<STACK> stack;
+    LdsStackW<STACK, SPILL> stack;
     stack.base = reinterpret_cast<int *>(smem) + threadIdx.x; stack.sp = 0;
+    stack.spill = b.stack_spill; stack.spill_stride = gridDim.x * kB;
     const WfState S = b.st[cur];
     const uint32_t n = b.ctr[C_N + cur];
     /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
@@ -386,10 +401,13 @@ struct Pool {
     size_t bytes = 0;
     WfBuf buf;
     uint32_t *h_ctr = nullptr; /* pinned */
+    int *spill = nullptr;      /* traversal-stack overflow of wf_extend, one column per lane and pipe */
+    size_t spill_ints = 0;
     int device = -1;
     void release() {
         for (void *p : allocs) (void) hipFree(p);
         allocs.clear(); capacity = 0; bytes = 0;
+        if (spill) { (void) hipFree(spill); spill = nullptr; spill_ints = 0; }
         if (h_ctr) { (void) hipHostFree(h_ctr); h_ctr = nullptr; }
     }
 };
@@ -426,14 +444,17 @@ std::string ensure_pool(size_t records) {
     return std::string();
 }
 
-template <int STACK, bool COUNT>
+template <int STACK, bool SPILL, bool COUNT>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((wf_extend<STACK, COUNT>), dim3(grid), dim3(kB), STACK * kB * sizeof(int), s, sc, b, cur, refill);
+    hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT>), dim3(grid), dim3(kB), STACK * kB * sizeof(int), s, sc, b, cur, refill);
 }
 
-void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int stack, bool count, int grid, hipStream_t s) {
-#define E(S) if (count) launch_extend<S, true>(sc, b, cur, refill, grid, s); else launch_extend<S, false>(sc, b, cur, refill, grid, s)
-    if (stack <= 16) { E(16); } else if (stack <= 24) { E(24); } else if (stack <= 32) { E(32); } else { E(64); }
+/* lds_stack: entries kept in LDS (16 / 24 / 32); spill: the tree is deeper than that */
+void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int lds_stack, bool spill, bool count, int grid, hipStream_t s) {
+#define E(S, P) if (count) launch_extend<S, P, true>(sc, b, cur, refill, grid, s); else launch_extend<S, P, false>(sc, b, cur, refill, grid, s)
+#define F(S) if (spill) { E(S, true); } else { E(S, false); }
+    if (lds_stack <= 16) { F(16); } else if (lds_stack <= 24) { F(24); } else { F(32); }
+#undef F
 #undef E
 }
 
@@ -544,10 +565,24 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     const int thresholds = refill | (leaf_th << 8);
     /* persistent extend grid: fill the CUs, but with two pipes leave half of the wave slots to
        the other pipe's kernels */
-    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / (L.stack_depth * kB * sizeof(int) + 64))));
+    /* traversal stack: what the tree needs, at most `lds_stack` entries of it in LDS */
+    int lds_stack = L.stack_depth <= 16 ? 16 : 24;
+    if (const char *e = getenv("NORI_HIP_WF_STACK")) lds_stack = atoi(e) <= 16 ? 16 : atoi(e) <= 24 ? 24 : 32;
+    const bool spill = L.stack_depth > lds_stack;
+    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / (lds_stack * kB * sizeof(int) + 64))));
     if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(8, std::max(1, atoi(e)));
     const int extend_grid = 256 * per_cu;
+    if (spill) {
+        const size_t per_pipe_ints = (size_t) (L.stack_depth - lds_stack) * extend_grid * kB, ints = per_pipe_ints * n_pipes;
+        if (g_pool.spill_ints < ints) {
+            if (g_pool.spill) (void) hipFree(g_pool.spill);
+            g_pool.spill = nullptr; g_pool.spill_ints = 0;
+            WF_TRY(hipMalloc((void **) &g_pool.spill, ints * sizeof(int)));
+            g_pool.spill_ints = ints;
+        }
+        for (int k = 0; k < n_pipes; ++k) pipes[k].b.stack_spill = g_pool.spill + per_pipe_ints * k;
+    }
 
     int sync_every = 6;      /* path-loop iterations between two readbacks of the path count */
     if (const char *e = getenv("NORI_HIP_WF_SYNC_EVERY")) sync_every = std::min(64, std::max(1, atoi(e)));
@@ -576,7 +611,7 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             for (int k = 0; k < n_pipes; ++k) {
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
-                launch_extend_dyn(sc, P.b, P.cur, thresholds, L.stack_depth, L.count_traversal, extend_grid, P.stream);
+                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, extend_grid, P.stream);
                 launch_shade(sc, P.b, P.cur, P.bt.s_first, P.bt.n_spp, sh_grid, P.stream);
                 P.cur ^= 1;
                 stats.n_launches += 2;
