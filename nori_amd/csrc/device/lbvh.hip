@@ -9,12 +9,12 @@
  *
  *   1. k_scene_bounds   per-triangle boxes (src/mesh.cpp:78-83) -> scene box
  *                       (float atomics on order-preserving integer keys)
- *   2. k_morton         30-bit Morton code of the box centre (src/mesh.cpp:85-90
- *                       uses the vertex centroid; any centre orders as well),
- *                       key = code << 32 | triangle  (unique keys)
- *   3. hipcub radix sort of the 64-bit keys
+ *   2. k_morton         63-bit Morton code of the box centre (src/mesh.cpp:85-90
+ *                       uses the vertex centroid; any centre orders as well)
+ *   3. hipcub radix sort of (code, triangle) pairs
  *   4. k_hierarchy      Karras 2012: one thread per internal node finds its key
- *                       range and split with clz(key_i ^ key_j)
+ *                       range and split with clz(key_i ^ key_j); equal codes are
+ *                       told apart by their sorted position
  *   5. k_leaf_boxes / k_tree_level   padded triangle boxes in sorted order and
  *                       a min/max segment tree over them (one launch per level):
  *                       every node covers a CONTIGUOUS sorted range, so its box
@@ -70,34 +70,44 @@ __global__ void k_scene_bounds(const f4 *pos, const uint32_t *idx, uint32_t n, u
     else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s[threadIdx.x]);
 }
 
-__device__ __forceinline__ unsigned int expand10(unsigned int v) {
-    v = (v * 0x00010001u) & 0xFF0000FFu;
-    v = (v * 0x00000101u) & 0x0F00F00Fu;
-    v = (v * 0x00000011u) & 0xC30C30C3u;
-    v = (v * 0x00000005u) & 0x49249249u;
+/* spread the low 21 bits of v to every third bit */
+__device__ __forceinline__ unsigned long long expand21(unsigned long long v) {
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x001f00000000ffffull;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
     return v;
 }
 
-__global__ void k_morton(const f4 *pos, const uint32_t *idx, uint32_t n, f3 smin, f3 sinv, unsigned long long *keys) {
+/* 63-bit Morton code of the triangle's box centre (21 bits per axis: a 2M^3 grid keeps the
+   triangles of multi-million-triangle meshes in distinct cells; with 10 bits per axis whole
+   clusters shared a code and were split in index order) */
+__global__ void k_morton(const f4 *pos, const uint32_t *idx, uint32_t n, f3 smin, f3 sinv, unsigned long long *keys, uint32_t *vals) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     f3 mn, mx; tri_box(pos, idx, t, mn, mx);
     const float cx = (0.5f * (mn.x + mx.x) - smin.x) * sinv.x, cy = (0.5f * (mn.y + mx.y) - smin.y) * sinv.y,
                 cz = (0.5f * (mn.z + mx.z) - smin.z) * sinv.z;
-    const unsigned int ix = (unsigned int) fminf(fmaxf(cx * 1024.0f, 0.0f), 1023.0f);
-    const unsigned int iy = (unsigned int) fminf(fmaxf(cy * 1024.0f, 0.0f), 1023.0f);
-    const unsigned int iz = (unsigned int) fminf(fmaxf(cz * 1024.0f, 0.0f), 1023.0f);
-    const unsigned int code = (expand10(ix) << 2) | (expand10(iy) << 1) | expand10(iz);
-    keys[t] = ((unsigned long long) code << 32) | t;
+    const float S = 2097152.0f, M = 2097151.0f;
+    const unsigned long long ix = (unsigned long long) fminf(fmaxf(cx * S, 0.0f), M);
+    const unsigned long long iy = (unsigned long long) fminf(fmaxf(cy * S, 0.0f), M);
+    const unsigned long long iz = (unsigned long long) fminf(fmaxf(cz * S, 0.0f), M);
+    keys[t] = (expand21(ix) << 2) | (expand21(iy) << 1) | expand21(iz);
+    vals[t] = t;
 }
 
 /* internal node i: children (bit 31 set = leaf primitive position), key range, parent links */
 struct RadixNode { uint32_t left, right, lo, hi; };
 constexpr uint32_t kLeafBit = 0x80000000u;
 
+/* common-prefix length of the (key, position) pairs i and j: equal codes are told apart by their
+   position in the sorted order, so every pair has a distinct prefix length */
 __device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j) {
     if (j < 0 || j >= n) return -1;
-    return __clzll((long long) (keys[i] ^ keys[j]));
+    const unsigned long long x = keys[i] ^ keys[j];
+    return x ? __clzll((long long) x) : 64 + __clz(i ^ j);
 }
 
 __global__ void k_hierarchy(const unsigned long long *keys, int n, RadixNode *nodes, uint32_t *parent_inner, uint32_t *parent_leaf) {
@@ -130,13 +140,13 @@ __global__ void k_hierarchy(const unsigned long long *keys, int n, RadixNode *no
 }
 
 /* segment tree over the sorted, padded triangle boxes: entries [N + k] */
-__global__ void k_leaf_boxes(const f4 *pos, const uint32_t *idx, const unsigned long long *keys, uint32_t n, uint32_t N, float pad,
+__global__ void k_leaf_boxes(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, uint32_t N, float pad,
                              f4 *tmin, f4 *tmax) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     f4 mn4, mx4;
     if (k < n) {
-        f3 mn, mx; tri_box(pos, idx, (uint32_t) (keys[k] & 0xffffffffull), mn, mx);
+        f3 mn, mx; tri_box(pos, idx, order[k], mn, mx);
         mn4.x = mn.x - pad; mn4.y = mn.y - pad; mn4.z = mn.z - pad; mx4.x = mx.x + pad; mx4.y = mx.y + pad; mx4.z = mx.z + pad;
     } else {
         mn4.x = mn4.y = mn4.z = kInf; mx4.x = mx4.y = mx4.z = -kInf;
@@ -195,10 +205,10 @@ __global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 
     dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
 }
 
-__global__ void k_emit_tris(const f4 *pos, const uint32_t *idx, const uint32_t *tri_mesh, const unsigned long long *keys, uint32_t n, f4 *out) {
+__global__ void k_emit_tris(const f4 *pos, const uint32_t *idx, const uint32_t *tri_mesh, const uint32_t *order, uint32_t n, f4 *out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const uint32_t g = (uint32_t) (keys[k] & 0xffffffffull);
+    const uint32_t g = order[k];
     const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
     const f3 e1 = p1 - p0, e2 = p2 - p0;      /* the subtraction mesh.cpp:43 performs per ray */
     f4 a, b, c;
@@ -256,19 +266,23 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     const f3 sinv = mk3(ex > 0 ? 1.0f / ex : 0.0f, ey > 0 ? 1.0f / ey : 0.0f, ez > 0 ? 1.0f / ez : 0.0f);
 
     /* 7 first: the triangle records only need the sorted order; tiny scenes are one leaf */
-    Buf keys_a, keys_b;
+    Buf keys_a, keys_b, vals_a, vals_b;
     LB_TRY(keys_a.alloc((size_t) n * 8)); LB_TRY(keys_b.alloc((size_t) n * 8));
-    hipLaunchKernelGGL(k_morton, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n, smin, sinv, keys_a.as<unsigned long long>());
+    LB_TRY(vals_a.alloc((size_t) n * 4)); LB_TRY(vals_b.alloc((size_t) n * 4));
+    hipLaunchKernelGGL(k_morton, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n, smin, sinv, keys_a.as<unsigned long long>(), vals_a.as<uint32_t>());
     size_t temp_bytes = 0;
-    LB_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(), (int) n, 0, 62));
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(),
+                                              vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), (int) n, 0, 63));
     Buf temp; LB_TRY(temp.alloc(temp_bytes));
-    LB_TRY(hipcub::DeviceRadixSort::SortKeys(temp.p, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(), (int) n, 0, 62));
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(),
+                                              vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), (int) n, 0, 63));
     const unsigned long long *keys = keys_b.as<unsigned long long>();
+    const uint32_t *order = vals_b.as<uint32_t>();      /* sorted position -> global triangle */
 
     f4 *d_tris = nullptr;
     LB_TRY(hipMalloc((void **) &d_tris, (size_t) n * kTriQuads * sizeof(f4)));
     out.d_tris = d_tris;
-    hipLaunchKernelGGL(k_emit_tris, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, d_tri_mesh, keys, n, d_tris);
+    hipLaunchKernelGGL(k_emit_tris, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, d_tri_mesh, order, n, d_tris);
 
     if (n <= 4) {
         f4 *d_nodes = nullptr;
@@ -286,7 +300,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         uint32_t N = 1; while (N < n) N <<= 1;
         Buf tmin, tmax;
         LB_TRY(tmin.alloc((size_t) 2 * N * sizeof(f4))); LB_TRY(tmax.alloc((size_t) 2 * N * sizeof(f4)));
-        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, keys, n, N, pad, tmin.as<f4>(), tmax.as<f4>());
+        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, order, n, N, pad, tmin.as<f4>(), tmax.as<f4>());
         for (uint32_t first = N >> 1; first >= 1; first >>= 1) {
             hipLaunchKernelGGL(k_tree_level, dim3((first + B - 1) / B), dim3(B), 0, 0, first, first, tmin.as<f4>(), tmax.as<f4>());
             if (first == 1) break;
