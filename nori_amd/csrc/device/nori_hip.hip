@@ -54,6 +54,7 @@ struct LdsStack {
         sp--;
         return sp < DEPTH ? base[sp * STRIDE] : 0;
     }
+    __device__ __forceinline__ int pop_or(int empty_value) { return sp == 0 ? empty_value : pop(); }
 };
 
 constexpr int kBlock = 256;
@@ -117,13 +118,13 @@ __global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(D
        of code executes for a handful of the 64 lanes; if no kind reaches its
        threshold the most wanted one runs, which guarantees progress. */
     Trav tv;
-    tv.active = false; tv.node = 0;
+    trav_idle(tv);
     bool finished = !live;
     const int thS = (int) args.th_shade, thI = (int) args.th_inner, thL = (int) args.th_leaf;
     while (true) {
-        const bool wantS = !tv.active && !finished;
-        const bool wantI = tv.active && tv.node >= 0;
-        const bool wantL = tv.active && tv.node < 0;
+        const bool wantS = !trav_active(tv) && !finished;
+        const bool wantI = trav_at_inner(tv);
+        const bool wantL = trav_at_leaf(tv);
         const int cS = __popcll(__ballot(wantS)), cI = __popcll(__ballot(wantI)), cL = __popcll(__ballot(wantL));
         if ((cS | cI | cL) == 0) break;
         bool runS = cS >= thS, runI = cI >= thI, runL = cL >= thL;
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(D
                 trav_begin(sc, st.ray, any, stack, tv);
             }
         }
-        if (runI && tv.active && tv.node >= 0) trav_inner_step<COUNT>(sc, stack, tv, tc);
-        if (runL && tv.active && tv.node < 0) trav_leaf_step<COUNT>(sc, stack, tv, tc);
+        if (runI && trav_at_inner(tv)) trav_inner_step<COUNT>(sc, stack, tv, tc);
+        if (runL && trav_at_leaf(tv)) trav_leaf_step<COUNT>(sc, stack, tv, tc);
     }
 
     atomicAdd(&cnt[0], nCam); atomicAdd(&cnt[1], nClosest); atomicAdd(&cnt[2], nShadow);

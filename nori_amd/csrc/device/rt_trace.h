@@ -9,9 +9,9 @@
  * slab test of include/nori/bbox.h:323-350, made conservative (far side
  * widened by 2 ulp-ish) so no leaf whose triangle test would accept is culled.
  *
- * `Stack` is a policy with push(int)/pop()->int/empty(): in the HIP kernels it
- * is an LDS column ([depth][lane], bank = lane -> conflict free); the CPU
- * emulation harness passes a plain array.
+ * `Stack` is a policy with reset()/push(int)/pop_or(int empty_value)->int: in the
+ * HIP kernels it is an LDS column ([depth][lane], bank = lane -> conflict free);
+ * the CPU emulation harness passes a plain array.
  */
 #pragma once
 #include "rt_types.h"
@@ -71,47 +71,45 @@ NORI_HD void slab_two(const f4 &q0, const f4 &q1, const f4 &q2, f3 o, f3 rcp, fl
 
 /* Traversal state of one ray, advanced ONE step at a time so that a kernel can
  * interleave traversal with other work (regenerating finished lanes) instead of
- * letting 63 lanes wait for the longest walk of the wave.
- *   node >= 0           : next step tests an inner node
- *   node <  0, tri_cur < tri_end : next step tests ONE leaf triangle
- *   active == false     : traversal finished; `hit` is the answer
+ * letting 63 lanes wait for the longest walk of the wave.  The whole control
+ * state is ONE register:
+ *   node >= 0          next step tests the inner node `node` (both child boxes)
+ *   node <  0, != done next step tests ONE leaf triangle: ~node = (tri << 3) | (left - 1),
+ *                      i.e. a leaf link is its own cursor; advancing is ~node += 7
+ *   node == kTravDone  finished; `hit` is the answer
  * Closest-hit (any = false) or any-hit / shadow (any = true); `any` is run-time
- * state so both kinds of query share one instruction stream. */
+ * state so both kinds of query share one instruction stream.  hit.t doubles as
+ * the current far limit of the ray. */
+constexpr int kTravDone = (int) 0x80000000u;      /* ~kTravDone is no valid leaf link: first_tri < 2^28 */
+
 struct Trav {
     f3 o, d, rcp;
-    float mint, best_t;
+    float mint;
     int node;
-    uint32_t tri_cur, tri_end;
     Hit hit;
-    bool any, active;
+    bool any;
 };
+
+NORI_HD bool trav_active(const Trav &tv) { return tv.node != kTravDone; }
+NORI_HD bool trav_at_inner(const Trav &tv) { return tv.node >= 0; }
+NORI_HD bool trav_at_leaf(const Trav &tv) { return (uint32_t) tv.node > 0x80000000u; }
+NORI_HD void trav_idle(Trav &tv) { tv.node = kTravDone; tv.any = false; }
 
 template <class Stack>
 NORI_HD void trav_begin(const DevScene &sc, const RayIn &ray, bool any, Stack &stack, Trav &tv) {
     tv.o = ray.o; tv.d = ray.d;
     tv.rcp = mk3(slab_rcp(ray.d.x), slab_rcp(ray.d.y), slab_rcp(ray.d.z));
-    tv.mint = ray.mint; tv.best_t = ray.maxt;
+    tv.mint = ray.mint;
     tv.hit.tri = kNoHit; tv.hit.mesh = kNoHit; tv.hit.t = ray.maxt; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
     tv.any = any;
-    tv.tri_cur = tv.tri_end = 0;
     stack.reset();
-    tv.active = sc.n_triangles != 0;
-    tv.node = sc.root;
-    if (tv.active && tv.node < 0) {          /* the whole scene is one leaf */
-        const uint32_t code = ~(uint32_t) tv.node;
-        tv.tri_cur = code >> 3; tv.tri_end = tv.tri_cur + (code & 7u) + 1u;
-    }
+    tv.node = sc.n_triangles != 0 ? sc.root : kTravDone;      /* the root may itself be a leaf link */
 }
 
 /* pop the next subtree or finish */
 template <class Stack>
 NORI_HD void trav_pop(Stack &stack, Trav &tv) {
-    if (stack.empty()) { tv.active = false; return; }
-    tv.node = stack.pop();
-    if (tv.node < 0) {
-        const uint32_t code = ~(uint32_t) tv.node;
-        tv.tri_cur = code >> 3; tv.tri_end = tv.tri_cur + (code & 7u) + 1u;
-    }
+    tv.node = stack.pop_or(kTravDone);
 }
 
 /* one inner-node step: both child boxes from one 64-B record */
@@ -123,8 +121,8 @@ NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, Travers
     float nl, fl, nr, fr;
     slab_two(q0, q1, q2, tv.o, tv.rcp, nl, fl, nr, fr);
     fl *= 1.0000004f; fr *= 1.0000004f;
-    const bool hl = (nl <= fl) && (fl >= tv.mint) && (nl <= tv.best_t);
-    const bool hr = (nr <= fr) && (fr >= tv.mint) && (nr <= tv.best_t);
+    const bool hl = (nl <= fl) && (fl >= tv.mint) && (nl <= tv.hit.t);
+    const bool hr = (nr <= fr) && (fr >= tv.mint) && (nr <= tv.hit.t);
     const int cl = (int) f2u(q3.x), cr = (int) f2u(q3.y);
     if (hl && hr) {
         const bool leftFirst = nl <= nr;
@@ -136,32 +134,28 @@ NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, Travers
         tv.node = cr;
     } else {
         trav_pop(stack, tv);
-        return;
-    }
-    if (tv.node < 0) {
-        const uint32_t code = ~(uint32_t) tv.node;
-        tv.tri_cur = code >> 3; tv.tri_end = tv.tri_cur + (code & 7u) + 1u;
     }
 }
 
 /* one leaf step: ONE triangle (mesh.cpp:39-76), then advance within the leaf */
 template <bool COUNT, class Stack>
 NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt) {
-    const f4 *tq = sc.tris + (size_t) tv.tri_cur * kTriQuads;
+    const uint32_t cursor = ~(uint32_t) tv.node;
+    const f4 *tq = sc.tris + (size_t) (cursor >> 3) * kTriQuads;
     const f4 a = tq[0], b = tq[1], c = tq[2];
     if (COUNT) cnt.tris++;
     float u, v, t;
     if (tri_test(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tv.o, tv.d, u, v, t) &&
-        t >= tv.mint && t <= tv.best_t) {
+        t >= tv.mint && t <= tv.hit.t) {
         const uint32_t gid = f2u(c.y);
-        if (tv.any) { tv.hit.tri = gid; tv.hit.t = t; tv.active = false; return; }
+        if (tv.any) { tv.hit.tri = gid; tv.hit.t = t; tv.node = kTravDone; return; }
         /* tie rule of the linear scan: a later triangle with equal t replaces an earlier one */
-        if (!(t == tv.best_t && tv.hit.tri != kNoHit && gid < tv.hit.tri)) {
-            tv.best_t = t;
+        if (!(t == tv.hit.t && tv.hit.tri != kNoHit && gid < tv.hit.tri)) {
             tv.hit.t = t; tv.hit.u = u; tv.hit.v = v; tv.hit.tri = gid; tv.hit.mesh = f2u(c.z);
         }
     }
-    if (++tv.tri_cur >= tv.tri_end) trav_pop(stack, tv);
+    if ((cursor & 7u) == 0u) trav_pop(stack, tv);
+    else tv.node = (int) ~(cursor + 7u);          /* next triangle, one fewer left */
 }
 
 /* Run a traversal to completion (batch kernels, tests).
@@ -170,8 +164,8 @@ template <bool COUNT, class Stack>
 NORI_HD bool traverse(const DevScene &sc, const RayIn &ray, bool any, Stack &stack, Hit &hit, TraversalCounters &cnt) {
     Trav tv;
     trav_begin(sc, ray, any, stack, tv);
-    while (tv.active) {
-        if (tv.node >= 0) trav_inner_step<COUNT>(sc, stack, tv, cnt);
+    while (trav_active(tv)) {
+        if (trav_at_inner(tv)) trav_inner_step<COUNT>(sc, stack, tv, cnt);
         else trav_leaf_step<COUNT>(sc, stack, tv, cnt);
     }
     hit = tv.hit;

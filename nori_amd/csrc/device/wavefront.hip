@@ -87,26 +87,47 @@ struct WfBatch {
     int32_t tile_w;
 };
 
-/* Per-lane traversal stack: the first DEPTH entries in LDS ([entry][thread], bank = lane), deeper
-   ones -- rare, and only in trees deeper than DEPTH -- in a per-lane column of a global buffer.  A
-   small DEPTH keeps wf_extend at 8 waves/SIMD however deep the tree is (a 64-entry LDS stack would
-   allow 2), which is what hides the HBM latency of scenes that do not fit in L2. */
+/* Per-lane traversal stack in LDS ([entry][thread], bank = lane -> conflict free).
+   Trees no deeper than DEPTH: one register (the address of the next free slot); entry 0 holds the
+   "finished" marker, so popping the empty stack ends the traversal without an emptiness test.
+   Deeper trees (SPILL): the first DEPTH entries in LDS, the rest -- rare -- in a per-lane column of
+   a global buffer.  A small DEPTH keeps wf_extend at 8 waves/SIMD however deep the tree is (a
+   64-entry LDS stack would allow 2), which is what hides the HBM latency of scenes that do not fit
+   in L2. */
 template <int DEPTH, bool SPILL>
 struct LdsStackW {
     int *base; int sp;
     int *spill; uint32_t spill_stride;      /* wave-uniform base, lanes in flight */
+    __device__ __forceinline__ void init(char *smem, int *spill_, uint32_t stride_) {
+        base = reinterpret_cast<int *>(smem) + threadIdx.x; sp = 0; spill = spill_; spill_stride = stride_;
+    }
     __device__ __forceinline__ void reset() { sp = 0; }
-    __device__ __forceinline__ bool empty() const { return sp == 0; }
     __device__ __forceinline__ void push(int v) {
         if (sp < DEPTH) base[sp * kB] = v;
-        else if (SPILL) spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * kB + threadIdx.x] = v;
+        else spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * kB + threadIdx.x] = v;
         sp++;
     }
-    __device__ __forceinline__ int pop() {
+    __device__ __forceinline__ int pop_or(int empty_value) {
+        if (sp == 0) return empty_value;
         sp--;
         if (sp < DEPTH) return base[sp * kB];
-        return SPILL ? spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * kB + threadIdx.x] : 0;
+        return spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * kB + threadIdx.x];
     }
+    static constexpr int kLdsEntries = DEPTH;
+};
+
+template <int DEPTH>
+struct LdsStackW<DEPTH, false> {
+    int *top;       /* next free slot */
+    char *smem_;
+    __device__ __forceinline__ void init(char *smem, int *, uint32_t) { smem_ = smem; top = reinterpret_cast<int *>(smem) + threadIdx.x; }
+    __device__ __forceinline__ void reset() {
+        int *b = reinterpret_cast<int *>(smem_) + threadIdx.x;
+        b[0] = kTravDone; top = b + kB;
+    }
+    __device__ __forceinline__ void push(int v) { *top = v; top += kB; }
+    __device__ __forceinline__ int pop_or(int) { top -= kB; return *top; }
+    static constexpr int kLdsEntries = DEPTH + 1;
 };
 
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
@@ -160,15 +181,14 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStackW<STACK, SPILL> stack;
-    stack.base = reinterpret_cast<int *>(smem) + threadIdx.x; stack.sp = 0;
-    stack.spill = b.stack_spill; stack.spill_stride = gridDim.x * kB;
+    stack.init(smem, b.stack_spill, gridDim.x * kB);
     const WfState S = b.st[cur];
     const uint32_t n = b.ctr[C_N + cur];
     /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
        reset them for the wf_shade that follows this kernel and for the next wf_extend */
     if (blockIdx.x == 0 && threadIdx.x == 0) { b.ctr[C_N + (cur ^ 1)] = 0u; b.ctr[C_HEAD + (cur ^ 1)] = 0u; }
     const int lane = lane_id();
-    Trav tv; tv.active = false; tv.node = 0; tv.any = false;
+    Trav tv; trav_idle(tv);
     uint32_t rid = 0;            /* path << 2 | continuation pending << 1 | shadow ray occluded */
     bool exhausted = n == 0;
     /* Paths are handed to waves in chunks: every wave starts with a static chunk (no atomic), the
@@ -187,8 +207,8 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
     while (true) {
         /* a lane is idle when it has no ray in flight: either it needs a new path, or its path's
            shadow ray is answered and the continuation ray is still to be traced (rid bit 1) */
-        const bool pend = !tv.active && (rid & 2u) != 0u;
-        const unsigned long long idle = __ballot(!tv.active), pending = __ballot(pend);
+        const bool pend = !trav_active(tv) && (rid & 2u) != 0u;
+        const unsigned long long idle = __ballot(!trav_active(tv)), pending = __ballot(pend);
         const int nIdle = __popcll(idle);
         if ((!exhausted || pending != 0ull) && (nIdle >= refill_threshold || nIdle == 64)) {
             /* the wave owns [chunk_pos, chunk_end) and hands it out to its idle lanes */
@@ -204,7 +224,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
             const unsigned long long fresh = idle & ~pending;
             const uint32_t avail = chunk_end - chunk_pos;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (fresh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) fresh, 0u));   /* set bits below this lane */
-            if (pend || (!tv.active && rank < avail)) {
+            if (pend || (!trav_active(tv) && rank < avail)) {
                 const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
                 const uint32_t fl = pend ? F_HAS_A : S.flags[i];
                 if (fl & (F_HAS_A | F_HAS_B)) {      /* 0: empty slot */
@@ -216,7 +236,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
                     rid = pend ? (rid & ~2u) : ((i << 2) | ((any && (fl & F_HAS_A)) ? 2u : 0u));
                     trav_begin(sc, ray, any, stack, tv);
                     if (any) ++nShadow; else ++nClosest;
-                    if (!tv.active) {            /* empty scene: nothing occludes, nothing is hit */
+                    if (!trav_active(tv)) {            /* empty scene: nothing occludes, nothing is hit */
                         if (rid & 2u) { ++nClosest; rid &= ~2u; }
                         f4 h; h.x = kInf; h.y = h.z = 0.0f; h.w = __uint_as_float(kMissA);
                         b.hit[i] = h;
@@ -225,19 +245,19 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
             }
             chunk_pos += min(avail, (uint32_t) __popcll(fresh));
         }
-        if (__ballot(tv.active) == 0ull) {
-            if (exhausted && __ballot(!tv.active && (rid & 2u) != 0u) == 0ull) break;
+        if (__ballot(trav_active(tv)) == 0ull) {
+            if (exhausted && __ballot((rid & 2u) != 0u) == 0ull) break;
             continue;
         }
-        const bool was = tv.active;
+        const bool was = trav_active(tv);
         /* inner-node steps run every trip; the (rarer) triangle step only when enough lanes
            wait at a leaf or nobody has an inner node to test */
-        if (tv.active && tv.node >= 0) trav_inner_step<COUNT>(sc, stack, tv, tc);
-        const bool atLeaf = tv.active && tv.node < 0;
+        if (trav_at_inner(tv)) trav_inner_step<COUNT>(sc, stack, tv, tc);
+        const bool atLeaf = trav_at_leaf(tv);
         const int nLeaf = __popcll(__ballot(atLeaf));
-        const bool innerLeft = __ballot(tv.active && tv.node >= 0) != 0ull;
+        const bool innerLeft = __ballot(trav_at_inner(tv)) != 0ull;
         if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT>(sc, stack, tv, tc);
-        if (was && !tv.active) {
+        if (was && !trav_active(tv)) {
             if (rid & 2u) {      /* the shadow ray is answered; the continuation ray of the same vertex is next */
                 rid |= tv.hit.tri != kNoHit ? 1u : 0u;
             } else {
@@ -446,7 +466,8 @@ std::string ensure_pool(size_t records) {
 
 template <int STACK, bool SPILL, bool COUNT>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT>), dim3(grid), dim3(kB), STACK * kB * sizeof(int), s, sc, b, cur, refill);
+    const size_t lds = (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int);
+    hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill);
 }
 
 /* lds_stack: entries kept in LDS (16 / 24 / 32); spill: the tree is deeper than that */
@@ -569,7 +590,7 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     int lds_stack = L.stack_depth <= 16 ? 16 : 24;
     if (const char *e = getenv("NORI_HIP_WF_STACK")) lds_stack = atoi(e) <= 16 ? 16 : atoi(e) <= 24 ? 24 : 32;
     const bool spill = L.stack_depth > lds_stack;
-    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / (lds_stack * kB * sizeof(int) + 64))));
+    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + 64))));
     if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(8, std::max(1, atoi(e)));
     const int extend_grid = 256 * per_cu;

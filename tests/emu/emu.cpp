@@ -31,6 +31,7 @@ struct ArrayStack {
     int high = 0;
     void reset() { sp = 0; }
     bool empty() const { return sp == 0; }
+    int pop_or(int empty_value) { return sp == 0 ? empty_value : pop(); }
     void push(int v) { data[sp++] = v; if (sp > high) high = sp; }
     int pop() { return data[--sp]; }
 };
