@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -206,11 +207,13 @@ struct BuildNode {
 
 constexpr int kBins = 32;
 constexpr uint32_t kLeafTarget = 4;
-constexpr float kCostNode = 1.0f, kCostTri = 1.0f;
+constexpr float kCostNode = 1.0f;
+static float kCostTri = 1.0f;      /* relative cost of one triangle test; NORI_HIP_SAH_TRI_COST overrides (experiments) */
 
 } // namespace
 
 std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh &out) {
+    if (const char *e = std::getenv("NORI_HIP_SAH_TRI_COST")) kCostTri = std::max(0.1f, (float) std::atof(e));
     const auto t0 = std::chrono::steady_clock::now();
     out = HostBvh();
     const uint32_t n = (uint32_t) sc.tri_mesh.size();
