@@ -9,8 +9,8 @@
  * state copies, 2^28 paths = 70 GB in flight) and every kernel runs with all lanes doing the SAME kind
  * of work:
  *
- *   wf_generate  camera samples -> path state + first ray          (src/main.cpp:41-46)
- *   loop until no path is alive:
+ *   loop until no path is alive (the first pass computes the camera sample of src/main.cpp:41-46
+ *   in the kernels instead of reading path state):
  *     wf_extend  persistent waves pull paths from the dense state array; a lane traces
  *                the path's shadow ray, then its continuation ray, writes one hit
  *                record, and is refilled as soon as enough lanes of its wave are idle
@@ -132,58 +132,36 @@ struct LdsStackW<DEPTH, false> {
 
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
 
-__global__ __launch_bounds__(kB) void wf_generate(DevScene sc, WfBuf b, WfBatch bt) {
-    const WfState S = b.st[0];
+/* The first vertex of the batch's path p is never stored: its camera sample (renderBlock,
+   src/main.cpp:41-46) is recomputed where it is needed -- by the first wf_extend (ray) and the first
+   wf_shade (direction, pcg32 state) -- which costs ~100 instructions twice and saves writing and
+   re-reading 80 B of state per path.  Returns false for pixels of edge tiles outside the image. */
+__device__ __forceinline__ bool first_vertex(const DevScene &sc, const WfBatch &bt, uint32_t p, f2 &ps, RayIn &cam, Rng &rng) {
     const uint32_t per_tile = 256u * bt.n_spp;
-    const uint32_t n = bt.n_tiles * per_tile;
-    uint32_t n_live = 0;        /* per wave */
-    for (uint32_t base = blockIdx.x * kB; base < n; base += gridDim.x * kB) {
-        const uint32_t p = base + threadIdx.x;
-        bool live = p < n;
-        if (live) {
-            const uint32_t tsel = p / per_tile, rem = p - tsel * per_tile;
-            const uint32_t sl = rem >> 8, pix = rem & 255u;
-            const uint32_t tile_id = bt.tile_rem + (bt.tile_first + tsel) * bt.tile_mod;
-            const int x0 = (int) (tile_id % bt.tiles_x) * kTile, y0 = (int) (tile_id / bt.tiles_x) * kTile;
-            int px, py; film_tile_pixel((int) pix, x0, y0, px, py);
-            live = px < sc.camera.width && py < sc.camera.height;
-            if (live) {
-                /* renderBlock, src/main.cpp:41-46 */
-                Rng rng;
-                rng_seed(rng, (uint64_t) py * (uint64_t) sc.camera.width + (uint64_t) px, (uint64_t) (bt.s_first + sl));
-                const f2 j = rng_next_2d(rng);
-                const f2 ps = mk2((float) px + j.x, (float) py + j.y);
-                (void) rng_next_2d(rng);          /* apertureSample: drawn, unused */
-                RayIn cam; camera_sample_ray(sc.camera, ps, cam);
-                b.samp_pos[p] = ps;
-                f4 o; o.x = cam.o.x; o.y = cam.o.y; o.z = cam.o.z; o.w = cam.mint;
-                f4 d; d.x = cam.d.x; d.y = cam.d.y; d.z = cam.d.z; d.w = cam.maxt;
-                S.o[p] = o; S.dA[p] = d;
-                f4 t; t.x = t.y = t.z = 1.0f; t.w = 1.0f;      /* T = 1, eta = 1 */
-                f4 l; l.x = l.y = l.z = 0.0f; l.w = 0.0f;      /* L = 0, pdf_mat = 0 */
-                S.T_eta[p] = t; S.L_pdf[p] = l;
-                S.rng[p] = rng.state;
-                S.sidx[p] = p;
-            }
-        }
-        /* pixels of edge tiles that fall outside the image: empty slots, dropped by the first wf_shade */
-        if (p < n) S.flags[p] = live ? (F_HAS_A | (2u << 4)) : 0u;      /* prev_measure = discrete, depth 0 */
-        n_live += (uint32_t) __popcll(__ballot(live));
-    }
-    if (threadIdx.x == 0) b.ctr[C_N + 0] = n;      /* same value from every block */
-    if (lane_id() == 0 && n_live) atomicAdd(&b.stats[S_CAM], (unsigned long long) n_live);
+    const uint32_t tsel = p / per_tile, rem = p - tsel * per_tile;
+    const uint32_t sl = rem >> 8, pix = rem & 255u;
+    const uint32_t tile_id = bt.tile_rem + (bt.tile_first + tsel) * bt.tile_mod;
+    const int x0 = (int) (tile_id % bt.tiles_x) * kTile, y0 = (int) (tile_id / bt.tiles_x) * kTile;
+    int px, py; film_tile_pixel((int) pix, x0, y0, px, py);
+    if (px >= sc.camera.width || py >= sc.camera.height) return false;
+    rng_seed(rng, (uint64_t) py * (uint64_t) sc.camera.width + (uint64_t) px, (uint64_t) (bt.s_first + sl));
+    const f2 j = rng_next_2d(rng);
+    ps = mk2((float) px + j.x, (float) py + j.y);
+    (void) rng_next_2d(rng);          /* apertureSample: drawn, unused */
+    camera_sample_ray(sc.camera, ps, cam);
+    return true;
 }
 
 /* Accel::rayIntersect for every path of copy `cur`: the shadow ray (if any) first, then the
    continuation ray, by the same lane; one 16-B hit record per path. */
-template <int STACK, bool SPILL, bool COUNT>
-__global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds) {
+template <int STACK, bool SPILL, bool COUNT, bool FIRST>
+__global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStackW<STACK, SPILL> stack;
     stack.init(smem, b.stack_spill, gridDim.x * kB);
     const WfState S = b.st[cur];
-    const uint32_t n = b.ctr[C_N + cur];
+    const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
     /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
        reset them for the wf_shade that follows this kernel and for the next wf_extend */
     if (blockIdx.x == 0 && threadIdx.x == 0) { b.ctr[C_N + (cur ^ 1)] = 0u; b.ctr[C_HEAD + (cur ^ 1)] = 0u; }
@@ -202,7 +180,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
                                                  : min(1024u, max(64u, (n / (n_waves * 2u)) & ~63u));
     const uint32_t dyn0 = n_waves * kChunk;        /* first dynamically claimed path */
     uint32_t chunk_pos = min(wave_id * kChunk, n), chunk_end = min(chunk_pos + kChunk, n);       /* wave-uniform */
-    uint32_t nClosest = 0, nShadow = 0;
+    uint32_t nClosest = 0, nShadow = 0, nCam = 0;
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
     while (true) {
         /* a lane is idle when it has no ray in flight: either it needs a new path, or its path's
@@ -224,7 +202,22 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
             const unsigned long long fresh = idle & ~pending;
             const uint32_t avail = chunk_end - chunk_pos;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (fresh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) fresh, 0u));   /* set bits below this lane */
-            if (pend || (!trav_active(tv) && rank < avail)) {
+            if (FIRST) {
+                if (!trav_active(tv) && rank < avail) {      /* path i = camera sample i of the batch */
+                    const uint32_t i = chunk_pos + rank;
+                    f2 ps; RayIn ray; Rng rng;
+                    if (first_vertex(sc, bt, i, ps, ray, rng)) {
+                        b.samp_pos[i] = ps;
+                        rid = i << 2;
+                        trav_begin(sc, ray, false, stack, tv);
+                        ++nClosest; ++nCam;
+                        if (!trav_active(tv)) {
+                            f4 h; h.x = kInf; h.y = h.z = 0.0f; h.w = __uint_as_float(kMissA);
+                            b.hit[i] = h;
+                        }
+                    }
+                }
+            } else if (pend || (!trav_active(tv) && rank < avail)) {
                 const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
                 const uint32_t fl = pend ? F_HAS_A : S.flags[i];
                 if (fl & (F_HAS_A | F_HAS_B)) {      /* 0: empty slot */
@@ -274,11 +267,13 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
     for (int off = 32; off > 0; off >>= 1) {
         nClosest += (uint32_t) __shfl_down((int) nClosest, off);
         nShadow += (uint32_t) __shfl_down((int) nShadow, off);
+        if (FIRST) nCam += (uint32_t) __shfl_down((int) nCam, off);
         if (COUNT) { tc.nodes += (uint32_t) __shfl_down((int) tc.nodes, off); tc.tris += (uint32_t) __shfl_down((int) tc.tris, off); }
     }
     if (lane == 0) {
         if (nClosest) atomicAdd(&b.stats[S_CLOSEST], (unsigned long long) nClosest);
         if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
+        if (FIRST && nCam) atomicAdd(&b.stats[S_CAM], (unsigned long long) nCam);
         if (COUNT) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
     }
 }
@@ -288,10 +283,11 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
    A workgroup owns a contiguous range of rounds (256 paths each) and reserves output space in
    chunks of <= kShadeChunk records with one atomic per chunk, sized by the survival rate it sees;
    what it leaves unused of its last chunk is marked empty (flags = 0) and dropped by the next pass. */
-template <int INTEG>
-__global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, uint32_t s_first, uint32_t n_spp) {
+template <int INTEG, bool FIRST>
+__global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
     const WfState S = b.st[cur], D = b.st[cur ^ 1];
-    const uint32_t n = b.ctr[C_N + cur];
+    const uint32_t s_first = bt.s_first, n_spp = bt.n_spp;
+    const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
     const uint32_t rounds_total = (n + kB - 1) / kB;
     const uint32_t rounds_per_block = (rounds_total + gridDim.x - 1) / gridDim.x;
     const uint32_t r0 = blockIdx.x * rounds_per_block, r1 = min(rounds_total, r0 + rounds_per_block);
@@ -308,12 +304,22 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
         uint32_t n_fl = 0u, sidx = 0u;
         unsigned long long n_rng = 0ull;
         if (i < n) {
-            const uint32_t fl = S.flags[i];
+            /* the path's state: from HBM, or -- first vertex -- recomputed from the sample index */
+            uint32_t fl; f4 L4, d4, t4; Rng rng0; rng0.state = 0; rng0.inc = 0;
+            if (FIRST) {
+                f2 ps; RayIn cam;
+                fl = first_vertex(sc, bt, i, ps, cam, rng0) ? (F_HAS_A | (2u << 4)) : 0u;      /* prev_measure = discrete, depth 0 */
+                sidx = i;
+                L4.x = L4.y = L4.z = L4.w = 0.0f;                  /* L = 0, pdf_mat = 0 */
+                t4.x = t4.y = t4.z = t4.w = 1.0f;                  /* T = 1, eta = 1 */
+                d4.x = cam.d.x; d4.y = cam.d.y; d4.z = cam.d.z; d4.w = cam.maxt;
+            } else {
+                fl = S.flags[i];
+            }
             if (fl & (F_HAS_A | F_HAS_B)) {
-                sidx = S.sidx[i];
+                if (!FIRST) { sidx = S.sidx[i]; L4 = S.L_pdf[i]; }
                 const f4 h = b.hit[i];
                 const uint32_t hw = __float_as_uint(h.w);
-                f4 L4 = S.L_pdf[i];
                 bool done = false;
                 if (fl & F_HAS_B) {                       /* path_on_shadow: add the emitter sample if unoccluded */
                     if (!(hw & kOccludedB)) {
@@ -325,8 +331,7 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
                 PathState st;
                 st.L = mk3(L4.x, L4.y, L4.z);
                 if (!done) {
-                    const f4 d4 = S.dA[i];
-                    const f4 t4 = S.T_eta[i];
+                    if (!FIRST) { d4 = S.dA[i]; t4 = S.T_eta[i]; }
                     Hit hit; hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = hw & kMissA;
                     const bool found = hit.tri != kMissA;
                     if (!found) hit.tri = kNoHit;
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
                     /* pcg32 stream of this camera sample: inc from the sample index, state from HBM */
                     const uint32_t sl = (sidx % per_tile) >> 8;
                     st.rng.inc = ((uint64_t) (s_first + sl) << 1u) | 1u;
-                    st.rng.state = S.rng[i];
+                    st.rng.state = FIRST ? rng0.state : S.rng[i];
                     done = path_on_closest<INTEG>(sc, st, hit, found, mk3(d4.x, d4.y, d4.z));
                     if (!done) {
                         survive = true;
@@ -464,25 +469,30 @@ std::string ensure_pool(size_t records) {
     return std::string();
 }
 
-template <int STACK, bool SPILL, bool COUNT>
-void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, hipStream_t s) {
+template <int STACK, bool SPILL, bool COUNT, bool FIRST>
+void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, const WfBatch &bt, hipStream_t s) {
     const size_t lds = (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int);
-    hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill);
+    hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill, bt);
 }
 
-/* lds_stack: entries kept in LDS (16 / 24 / 32); spill: the tree is deeper than that */
-void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int lds_stack, bool spill, bool count, int grid, hipStream_t s) {
-#define E(S, P) if (count) launch_extend<S, P, true>(sc, b, cur, refill, grid, s); else launch_extend<S, P, false>(sc, b, cur, refill, grid, s)
+/* lds_stack: entries kept in LDS (16 / 24 / 32); spill: the tree is deeper than that;
+   first: the batch's first pass (camera rays computed in the kernel) */
+void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int lds_stack, bool spill, bool count, bool first,
+                       int grid, const WfBatch &bt, hipStream_t s) {
+#define G(S, P, C) if (first) launch_extend<S, P, C, true>(sc, b, cur, refill, grid, bt, s); else launch_extend<S, P, C, false>(sc, b, cur, refill, grid, bt, s)
+#define E(S, P) if (count) { G(S, P, true); } else { G(S, P, false); }
 #define F(S) if (spill) { E(S, true); } else { E(S, false); }
     if (lds_stack <= 16) { F(16); } else if (lds_stack <= 24) { F(24); } else { F(32); }
 #undef F
 #undef E
+#undef G
 }
 
-void launch_shade(const DevScene &sc, const WfBuf &b, int cur, uint32_t s_first, uint32_t n_spp, int grid_, hipStream_t s) {
+void launch_shade(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &bt, bool first, int grid_, hipStream_t s) {
     const dim3 grid(grid_), block(kB);
     switch (sc.integrator.type) {
-#define SH(I) case I: hipLaunchKernelGGL((wf_shade<I>), grid, block, 0, s, sc, b, cur, s_first, n_spp); break;
+#define SH(I) case I: if (first) hipLaunchKernelGGL((wf_shade<I, true>), grid, block, 0, s, sc, b, cur, bt); \
+                      else hipLaunchKernelGGL((wf_shade<I, false>), grid, block, 0, s, sc, b, cur, bt); break;
         SH(0) SH(1) SH(2) SH(3) SH(4) SH(5) SH(6)
 #undef SH
     }
@@ -505,7 +515,7 @@ struct Pipe {
     uint32_t tile_lo = 0, tile_hi = 0;      /* selected-tile ordinals owned by this pipe */
     uint32_t tiles_b = 0, spp_b = 0;        /* batch geometry */
     uint32_t t0 = 0, s0 = 0;                /* next batch */
-    bool active = false, finished = false;
+    bool active = false, finished = false, first = false;
     WfBatch bt;
     int cur = 0;
 };
@@ -622,18 +632,17 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             P.bt.tile_first = P.t0; P.bt.n_tiles = nt; P.bt.s_first = L.spp_begin + P.s0; P.bt.n_spp = ns;
             P.bt.tile_mod = L.tile_mod; P.bt.tile_rem = L.tile_rem; P.bt.tiles_x = L.tiles_x; P.bt.tile_w = L.tile_w;
             WF_TRY(hipMemsetAsync(P.b.ctr, 0, C_COUNT * sizeof(uint32_t), P.stream));
-            const size_t n = (size_t) nt * 256 * ns;
-            hipLaunchKernelGGL(wf_generate, dim3((unsigned) std::min<size_t>((n + kB - 1) / kB, 8192)), dim3(kB), 0, P.stream, sc, P.b, P.bt);
-            stats.n_launches++; stats.n_batches++;
-            P.cur = 0; P.active = true; any = true;
+            stats.n_batches++;
+            P.cur = 0; P.first = true; P.active = true; any = true;
         }
         if (!any) break;
         for (int it = 0; it < sync_every; ++it)
             for (int k = 0; k < n_pipes; ++k) {
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
-                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, extend_grid, P.stream);
-                launch_shade(sc, P.b, P.cur, P.bt.s_first, P.bt.n_spp, sh_grid, P.stream);
+                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, extend_grid, P.bt, P.stream);
+                launch_shade(sc, P.b, P.cur, P.bt, P.first, sh_grid, P.stream);
+                P.first = false;
                 P.cur ^= 1;
                 stats.n_launches += 2;
                 if (k == 0) stats.n_iterations++;
