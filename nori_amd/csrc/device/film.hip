@@ -11,19 +11,23 @@ namespace {
 
 constexpr int kB = 256;
 
-/* ImageBlock::put(pos, value) as a gather.  For the tile's bordered block (tile_w^2 pixels) each
- * thread owns <= 2 output pixels and, sample round by sample round, adds the contributions of the
- * tile's 256 current samples (staged in LDS) that reach them.  Weights follow src/block.cpp:70-90
- * in the coordinates of the reference's 32x32 block containing the tile, so every filter-table
- * index is the one Nori computes:
+constexpr int kMaxBorder = 8;                  /* (16 + 2 * 8)^2 / 256 = 4 output pixels per thread */
+
+/* ImageBlock::put(pos, value) as a gather.  Sample round by sample round, the tile's 256 current
+ * samples are staged in LDS together with their 1-D filter weights; then every pixel of the tile's
+ * bordered block (tile_w^2 pixels, <= 4 per thread) adds the samples that can reach it.  Weights follow
+ * src/block.cpp:70-90 in the coordinates of the reference's 32x32 block containing the tile, so every
+ * filter-table index is the one Nori computes:
  *     pos   = p - 0.5 - (block_offset - border)
  *     pixel x is touched iff ceil(pos.x - r) <= x <= floor(pos.x + r)   <=>  pos.x - r <= x <= pos.x + r
- *     w     = filter[(int)(|x - pos.x| * lookupFactor)] * filter[(int)(|y - pos.y| * lookupFactor)]
- *     px   += (r, g, b, 1) * wx * wy */
+ *     wx[x] = filter[(int)(|x - pos.x| * lookupFactor)],  wy[y] likewise       (block.cpp:79-84)
+ *     px   += (r, g, b, 1) * (wx[x] * wy[y])                                    (block.cpp:86-88)
+ * A sample of tile pixel (sx, sy) reaches the output pixels (sx + k, sy + m), k, m in [0, 2 border]
+ * of the bordered tile frame: 2 border + 1 taps per axis, zero where out of the filter's reach or
+ * for samples the isValid() guard (block.cpp:63-67) rejects. */
 __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, FilterRec fr, const float *__restrict__ filter_table,
                                                          FilmStore st, FilmLaunch fl) {
-    __shared__ float s_px[256], s_py[256];
-    __shared__ f4 s_L[256];                 /* w = 1: valid sample of a pixel inside the image */
+    extern __shared__ float s_dyn[];                          /* [taps][256] wx, [taps][256] wy, r, g, b */
     __shared__ float ftab[kFilterRes + 1];
     __shared__ unsigned int s_invalid;
     const int tid = threadIdx.x;
@@ -33,7 +37,9 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
     const uint32_t ord = fl.tile_first + blockIdx.x;
     const uint32_t tile_id = fl.tile_rem + ord * fl.tile_mod;
     const int x0 = (int) (tile_id % fl.tiles_x) * kTile, y0 = (int) (tile_id / fl.tiles_x) * kTile;
-    const int border = fr.border, tile_w = fl.tile_w;
+    const int border = fr.border, tile_w = fl.tile_w, taps = 2 * border + 1;
+    float (*s_wx)[256] = reinterpret_cast<float (*)[256]>(s_dyn), (*s_wy)[256] = s_wx + taps;
+    float *s_Lr = s_dyn + 2 * taps * 256, *s_Lg = s_Lr + 256, *s_Lb = s_Lg + 256;
     const float radius = fr.radius, lookup = fr.lookup_factor;
     const int bx0 = x0 & ~31, by0 = y0 & ~31;                 /* NORI_BLOCK_SIZE = 32 */
     const int offx = x0 - bx0, offy = y0 - by0;               /* tile frame -> block frame */
@@ -41,59 +47,66 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
     /* this thread's sample slot (pixel of the tile) */
     int px, py; film_tile_pixel(tid, x0, y0, px, py);
     const bool live = px < width && py < height;
-    const int raster = (py - y0) * kTile + (px - x0);
+    const int sxl = px - x0, syl = py - y0, raster = syl * kTile + sxl;
 
     /* this thread's output pixels in the bordered tile frame */
     const int n_out = tile_w * tile_w;
-    constexpr int kMaxOut = 4;                                /* (16 + 2 * 8)^2 / 256: borders up to 8 */
-    int out_i[kMaxOut];
+    constexpr int kMaxOut = 4;
+    int out_x[kMaxOut], out_y[kMaxOut];
     f4 acc[kMaxOut];
-    for (int o = 0; o < kMaxOut; ++o) { out_i[o] = tid + o * kB; acc[o].x = acc[o].y = acc[o].z = acc[o].w = 0.0f; }
+    for (int o = 0; o < kMaxOut; ++o) {
+        const int i = tid + o * kB;
+        out_y[o] = i < n_out ? i / tile_w : -1000; out_x[o] = i - (i / tile_w) * tile_w;
+        acc[o].x = acc[o].y = acc[o].z = acc[o].w = 0.0f;
+    }
 
     const size_t first = (size_t) (ord - fl.store_tile_first) * fl.n_spp * 256u;
     unsigned int invalid = 0;
+    __syncthreads();
     for (uint32_t s = 0; s < fl.n_spp; ++s) {
-        __syncthreads();                                       /* previous round consumed */
         {
             const size_t idx = first + (size_t) s * 256u + (size_t) tid;
-            f4 L; L.x = L.y = L.z = L.w = 0.0f;
+            f4 L; L.x = L.y = L.z = 0.0f;
+            bool ok = false;
             float bpx = 0.0f, bpy = 0.0f;
             if (live) {
                 const f2 p = st.pos[idx];
                 L = st.L[idx];
-                const bool ok = color_valid(mk3(L.x, L.y, L.z));
-                if (!ok) ++invalid;
-                L.w = ok ? 1.0f : 0.0f;
+                ok = color_valid(mk3(L.x, L.y, L.z));
+                if (!ok) { ++invalid; L.x = L.y = L.z = 0.0f; }
                 bpx = p.x - 0.5f - (float) (bx0 - border);
                 bpy = p.y - 0.5f - (float) (by0 - border);
             }
-            s_px[raster] = bpx; s_py[raster] = bpy; s_L[raster] = L;
+            s_Lr[raster] = L.x; s_Lg[raster] = L.y; s_Lb[raster] = L.z;
+            for (int k = 0; k < taps; ++k) {
+                const float xb = (float) (sxl + k + offx), yb = (float) (syl + k + offy);
+                const bool inx = ok && xb >= bpx - radius && xb <= bpx + radius;
+                const bool iny = ok && yb >= bpy - radius && yb <= bpy + radius;
+                s_wx[k][raster] = inx ? ftab[(int) (fabsf(xb - bpx) * lookup)] : 0.0f;
+                s_wy[k][raster] = iny ? ftab[(int) (fabsf(yb - bpy) * lookup)] : 0.0f;
+            }
         }
         __syncthreads();
         for (int o = 0; o < kMaxOut; ++o) {
-            const int i = out_i[o];
-            if (i >= n_out) break;
-            const int oy = i / tile_w, ox = i - oy * tile_w;
-            const float xb = (float) (ox + offx), yb = (float) (oy + offy);
-            const int sx0 = max(0, ox - 2 * border), sx1 = min(kTile - 1, ox);       /* source pixels within reach */
-            const int sy0 = max(0, oy - 2 * border), sy1 = min(kTile - 1, oy);
-            for (int sy = sy0; sy <= sy1; ++sy) {
-                for (int sx = sx0; sx <= sx1; ++sx) {
+            const int oy = out_y[o], ox = out_x[o];
+            if (oy < 0) break;
+            for (int m = 0; m < taps; ++m) {
+                const int sy = oy - m;
+                if (sy < 0 || sy >= kTile) continue;
+                for (int k = 0; k < taps; ++k) {
+                    const int sx = ox - k;
+                    if (sx < 0 || sx >= kTile) continue;
                     const int r = sy * kTile + sx;
-                    const f4 L = s_L[r];
-                    if (L.w == 0.0f) continue;
-                    const float bx = s_px[r], by = s_py[r];
-                    if (!(xb >= bx - radius && xb <= bx + radius && yb >= by - radius && yb <= by + radius)) continue;
-                    const float wx = ftab[(int) (fabsf(xb - bx) * lookup)];
-                    const float wy = ftab[(int) (fabsf(yb - by) * lookup)];
-                    acc[o].x += L.x * wx * wy; acc[o].y += L.y * wx * wy; acc[o].z += L.z * wx * wy; acc[o].w += 1.0f * wx * wy;
+                    const float w = s_wx[k][r] * s_wy[m][r];
+                    acc[o].x += s_Lr[r] * w; acc[o].y += s_Lg[r] * w; acc[o].z += s_Lb[r] * w; acc[o].w += w;
                 }
             }
         }
+        __syncthreads();                                       /* round consumed */
     }
     f4 *dst = reinterpret_cast<f4 *>(st.tile_acc) + (size_t) ord * n_out;
     for (int o = 0; o < kMaxOut; ++o) {
-        const int i = out_i[o];
+        const int i = tid + o * kB;
         if (i >= n_out) break;
         f4 v = dst[i];
         v.x += acc[o].x; v.y += acc[o].y; v.z += acc[o].z; v.w += acc[o].w;
@@ -174,7 +187,8 @@ std::string film_prepare(size_t n_samples, size_t n_sel_tiles, int tile_w, void 
 
 void film_gather(const DevScene &sc, const float *d_filter_table, const FilmStore &st, const FilmLaunch &fl, void *stream) {
     if (fl.n_tiles == 0 || fl.n_spp == 0) return;
-    hipLaunchKernelGGL(film_gather_kernel, dim3(fl.n_tiles), dim3(kB), 0, (hipStream_t) stream, sc.camera.width, sc.camera.height,
+    const size_t lds = (size_t) (2 * (2 * sc.filter.border + 1) + 3) * 256 * sizeof(float);
+    hipLaunchKernelGGL(film_gather_kernel, dim3(fl.n_tiles), dim3(kB), lds, (hipStream_t) stream, sc.camera.width, sc.camera.height,
                        sc.filter, d_filter_table, st, fl);
 }
 

@@ -252,3 +252,24 @@ def test_gpu_lbvh_large_scene_build(renderer_factory):
     a, b = r0.intersect(rays), r1.intersect(rays)
     for k in ITS_FIELDS:
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("radius,engine", [(0.5, "megakernel"), (3.4, "megakernel"), (4.6, "wavefront"), (8.4, "megakernel"), (8.4, "wavefront")])
+def test_film_wide_filters(renderer_factory, radius, engine):
+    """ImageBlock::put with borders 0 .. 8 (film_gather keeps 2*border+1 taps per axis per sample);
+    image size not a multiple of the 16-px tile nor of Nori's 32-px block."""
+    sc = scenes.cornell_box(45, 37, 3, "normals", rfilter=RFilter("gaussian", radius=radius, stddev=radius / 4))
+    r, o = renderer_factory(sc), Oracle(sc, use_bvh=True)
+    r.set_option("engine", engine)
+    A, _ = o.render_host()
+    B, sb = r.render_host()
+    assert sb["n_invalid"] == 0 and A.shape == B.shape
+    np.testing.assert_allclose(B[..., 3], A[..., 3], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(B[..., :3], A[..., :3], rtol=1e-3, atol=1e-4)
+
+
+def test_film_radius_beyond_limit_fails_loudly(renderer_factory):
+    sc = scenes.cornell_box(32, 32, 1, "normals", rfilter=RFilter("gaussian", radius=9.6, stddev=2.0))
+    r = renderer_factory(sc)
+    with pytest.raises(NoriError, match="UNSUPPORTED|radius"):
+        r.render_host()
