@@ -436,6 +436,7 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
     if ((rc = upload(ctx, ctx->allocs_scene, h.emitter_cdf, &d.emitter_cdf))) return rc;
     if ((rc = upload(ctx, ctx->allocs_scene, h.emitters, &d.emitters))) return rc;
     if ((rc = upload(ctx, ctx->allocs_scene, h.tri_mesh, &ctx->d_tri_mesh))) return rc;
+    if ((rc = upload(ctx, ctx->allocs_scene, h.shade_tris, &d.shade_tris))) return rc;
     std::vector<float> ft(h.filter.table, h.filter.table + kFilterRes + 1);
     const float *dft = nullptr;
     if ((rc = upload(ctx, ctx->allocs_scene, ft, &dft))) return rc;

@@ -82,13 +82,12 @@ NORI_HD bool sample_direct(const DevScene &sc, Rng &rng, const Surface &s, const
     const float su = sqrtf(1.0f - xi.x);
     const float alpha = 1.0f - su, beta = xi.y * su;
     const float gamma = 1.0f - alpha - beta;
-    const uint32_t *idx = sc.indices + 3 * (size_t) (m.tri_offset + tri);
-    const uint32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
-    const f3 p0 = xyz(sc.positions[i0]), p1 = xyz(sc.positions[i1]), p2 = xyz(sc.positions[i2]);
+    const f4 *rec = sc.shade_tris + (size_t) (m.tri_offset + tri) * kShadeQuads;
+    const f3 p0 = xyz(rec[0]), p1 = xyz(rec[1]), p2 = xyz(rec[2]);
     const f3 p = (alpha * p0 + beta * p1) + gamma * p2;
     f3 n;
     if (m.flags & kMeshHasNormals)
-        n = normalized((alpha * xyz(sc.normals[i0]) + beta * xyz(sc.normals[i1])) + gamma * xyz(sc.normals[i2]));
+        n = normalized((alpha * xyz(rec[3]) + beta * xyz(rec[4])) + gamma * xyz(rec[5]));
     else
         n = normalized(cross(p1 - p0, p2 - p0));
     const f3 dvec = p - s.p;

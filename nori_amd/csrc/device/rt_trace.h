@@ -178,12 +178,12 @@ struct Surface {
     f3 ns;       /* its.shFrame.n, accel.cpp:82-95 */
 };
 
-/* src/accel.cpp:45-96 -- barycentric position and shading normal */
+/* src/accel.cpp:45-96 -- barycentric position and shading normal, from the triangle's
+ * pre-gathered shading record (rt_types.h) */
 NORI_HD void surface_fill(const DevScene &sc, const Hit &h, Surface &s, f3 *geo_n, f2 *uv_out) {
     const MeshRec &m = sc.meshes[h.mesh];
-    const uint32_t *idx = sc.indices + 3 * (size_t) h.tri;
-    const uint32_t i0 = idx[0], i1 = idx[1], i2 = idx[2];
-    const f3 p0 = xyz(sc.positions[i0]), p1 = xyz(sc.positions[i1]), p2 = xyz(sc.positions[i2]);
+    const f4 *rec = sc.shade_tris + (size_t) h.tri * kShadeQuads;
+    const f3 p0 = xyz(rec[0]), p1 = xyz(rec[1]), p2 = xyz(rec[2]);
     const float b0 = 1.0f - (h.u + h.v), b1 = h.u, b2 = h.v;
     s.p = (b0 * p0 + b1 * p1) + b2 * p2;
     const bool needGeo = geo_n != nullptr || !(m.flags & kMeshHasNormals);
@@ -191,14 +191,15 @@ NORI_HD void surface_fill(const DevScene &sc, const Hit &h, Surface &s, f3 *geo_
     if (needGeo) ng = normalized(cross(p1 - p0, p2 - p0));
     if (geo_n) *geo_n = ng;
     if (m.flags & kMeshHasNormals) {
-        const f3 n0 = xyz(sc.normals[i0]), n1 = xyz(sc.normals[i1]), n2 = xyz(sc.normals[i2]);
+        const f3 n0 = xyz(rec[3]), n1 = xyz(rec[4]), n2 = xyz(rec[5]);
         s.ns = normalized((b0 * n0 + b1 * n1) + b2 * n2);
     } else {
         s.ns = ng;
     }
     if (uv_out) {
         if (m.flags & kMeshHasUV) {
-            const f2 a = sc.texcoords[i0], b = sc.texcoords[i1], c = sc.texcoords[i2];
+            const uint32_t *idx = sc.indices + 3 * (size_t) h.tri;
+            const f2 a = sc.texcoords[idx[0]], b = sc.texcoords[idx[1]], c = sc.texcoords[idx[2]];
             *uv_out = mk2((b0 * a.x + b1 * b.x) + b2 * c.x, (b0 * a.y + b1 * b.y) + b2 * c.y);
         } else {
             *uv_out = mk2(h.u, h.v);

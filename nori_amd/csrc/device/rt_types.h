@@ -118,6 +118,13 @@ constexpr int kMaxLeafTris = 8;
  */
 constexpr int kTriQuads = 3;
 
+/* Shading record of one global triangle = 96 B = 6 x dwordx4: what accel.cpp:58-95 fetches through
+ * the index buffer after the closest hit is known (and what the area light samples), gathered once
+ * at upload so that shading costs ONE dependent fetch instead of index -> vertex:
+ *   q0..q2 = (p0, bits mesh), (p1, 0), (p2, 0)      q3..q5 = (n0, 0), (n1, 0), (n2, 0) (zero without normals)
+ * Same values as positions[indices[..]] / normals[indices[..]]: bit-identical results. */
+constexpr int kShadeQuads = 6;
+
 struct MeshRec {
     uint32_t tri_offset;      /* first global triangle                */
     uint32_t vtx_offset;      /* first global vertex                  */
@@ -165,6 +172,7 @@ struct DevScene {
     const float *emitter_cdf;
     const uint32_t *emitters;   /* mesh ids of emitters */
     const uint32_t *tri_mesh;   /* mesh id per global triangle */
+    const f4 *shade_tris;       /* kShadeQuads per global triangle: the shading data pre-gathered */
     uint32_t n_emitters;
     uint32_t n_meshes;
     uint32_t n_triangles;

@@ -79,7 +79,7 @@ std::string prepare_scene(const nori_scene_desc &desc, HostScene &out) {
     for (uint32_t i = 0; i < desc.n_meshes; ++i) { nV += desc.meshes[i].n_vertices; nT += desc.meshes[i].n_triangles; }
     if (nT >= (1ull << 28)) return "too many triangles (limit 2^28)";
     out.positions.resize(nV); out.normals.resize(nV); out.texcoords.resize(nV);
-    out.indices.resize(3 * nT); out.tri_mesh.resize(nT);
+    out.indices.resize(3 * nT); out.tri_mesh.resize(nT); out.shade_tris.resize(nT * kShadeQuads);
 
     uint32_t vOff = 0, tOff = 0;
     for (uint32_t mi = 0; mi < desc.n_meshes; ++mi) {
@@ -110,6 +110,13 @@ std::string prepare_scene(const nori_scene_desc &desc, HostScene &out) {
                 out.indices[3 * (size_t) (tOff + t) + k] = vOff + id;
             }
             out.tri_mesh[tOff + t] = mi;
+            f4 *q = &out.shade_tris[(size_t) (tOff + t) * kShadeQuads];
+            for (int k = 0; k < 3; ++k) {
+                const uint32_t g = out.indices[3 * (size_t) (tOff + t) + k];
+                q[k] = out.positions[g]; q[k].w = 0.0f;
+                q[3 + k] = out.normals[g]; q[3 + k].w = 0.0f;
+            }
+            q[0].w = u2f(mi);
         }
         if (m.is_emitter) {
             if (m.n_triangles == 0) return "area emitter attached to an empty mesh";

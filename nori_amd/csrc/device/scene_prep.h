@@ -17,6 +17,7 @@ struct HostScene {
     std::vector<f2> texcoords;
     std::vector<uint32_t> indices;      /* 3 per triangle, global vertex ids */
     std::vector<uint32_t> tri_mesh;     /* mesh id per global triangle       */
+    std::vector<f4> shade_tris;         /* kShadeQuads per global triangle   */
     std::vector<MeshRec> meshes;
     std::vector<float> emitter_cdf;
     std::vector<uint32_t> emitters;

@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
                     Hit hit; hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = hw & kMissA;
                     const bool found = hit.tri != kMissA;
                     if (!found) hit.tri = kNoHit;
-                    hit.mesh = found ? sc.tri_mesh[hit.tri] : kNoHit;
+                    hit.mesh = found ? f2u(sc.shade_tris[(size_t) hit.tri * kShadeQuads].w) : kNoHit;      /* same fetch as p0 */
                     st.T = mk3(t4.x, t4.y, t4.z); st.eta = t4.w; st.pdf_mat = L4.w;
                     st.Ld = mk3(0.0f); st.cont_d = mk3(0.0f);
                     st.prev_measure = (int32_t) ((fl >> 4) & 3u); st.depth = (int32_t) (fl >> 8);

@@ -51,6 +51,7 @@ static void bind(emu_ctx *c) {
     d.positions = h.positions.data(); d.normals = h.normals.data(); d.texcoords = h.texcoords.data();
     d.indices = h.indices.data(); d.meshes = h.meshes.data(); d.emitter_cdf = h.emitter_cdf.data();
     d.emitters = h.emitters.data(); d.tri_mesh = h.tri_mesh.data();
+    d.shade_tris = h.shade_tris.data();
     d.n_emitters = (uint32_t) h.emitters.size(); d.n_meshes = (uint32_t) h.meshes.size();
     d.n_triangles = (uint32_t) h.tri_mesh.size();
     d.root = c->bvh.root;
