@@ -42,20 +42,23 @@ def load_workload(name: str, width: int, height: int, spp: int):
 def algorithmic_bytes(stats: dict, info: dict, tile_w: int, n_tiles: int, engine: str) -> dict:
     """Algorithmic bytes of one render pass:
       traversal  N_node * 64 + N_tri * 48                     (both engines; from the COUNT pass)
-      surface    108 B per closest hit (3 indices + 3 positions + 3 normals as 16-B records)
+      surface    96 B per closest-hit ray: the triangle's pre-gathered shading record (3 positions +
+                 3 normals as 16-B records)
       film       24 B written + 24 B read per camera sample (sample store), plus one
                  read-modify-write of every tile accumulator and one frame read-modify-write
       state      wavefront only (dense ping-pong path state, wavefront.hip): per path vertex
                  (= closest-hit ray) wf_extend reads 36 B + writes the 16-B hit, wf_shade reads 80 B
-                 and the surviving path is written back as 80 B (wf_generate writes the first 80 B);
-                 per shadow ray another 64 B (direction + emitter sample, written and read twice):
-                 212 B * closest + 64 B * shadow.  0 for the megakernel, whose paths live in registers."""
+                 and the surviving path is written back as 80 B; per shadow ray another 64 B
+                 (direction + emitter sample, written and read once each); the first vertex of
+                 every path is recomputed, not stored (-180 B per camera sample):
+                 212 B * closest + 64 B * shadow - 180 B * camera samples.
+                 0 for the megakernel, whose paths live in registers."""
     trav = stats["n_node_tests"] * info["node_bytes"] + stats["n_tri_tests"] * info["tri_bytes"]
-    surface = stats["n_closest_rays"] * (12 + 48 + 48)
+    surface = stats["n_closest_rays"] * 96
     film = stats["n_camera_samples"] * 48 + n_tiles * 2 * 16 * tile_w * tile_w
     state = 0
     if engine == "wavefront":
-        state = stats["n_closest_rays"] * 212 + stats["n_shadow_rays"] * 64
+        state = stats["n_closest_rays"] * 212 + stats["n_shadow_rays"] * 64 - stats["n_camera_samples"] * 180
     return {"traversal": int(trav), "surface": int(surface), "film": int(film), "state": int(state),
             "total": int(trav + surface + film + state)}
 

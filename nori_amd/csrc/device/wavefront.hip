@@ -278,6 +278,48 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
     }
 }
 
+/* state record <-> PathState (rt_path.h) */
+__device__ __forceinline__ void vertex_unpack(PathState &st, uint32_t fl, const f4 &L4, const f4 &t4, uint64_t rng_state, uint64_t rng_inc) {
+    st.L = mk3(L4.x, L4.y, L4.z);
+    st.T = mk3(t4.x, t4.y, t4.z); st.eta = t4.w; st.pdf_mat = L4.w;
+    st.Ld = mk3(0.0f); st.cont_d = mk3(0.0f);
+    st.prev_measure = (int32_t) ((fl >> 4) & 3u); st.depth = (int32_t) (fl >> 8);
+    st.phase = PH_CLOSEST; st.end_after_shadow = 0;
+    st.ray.o = st.ray.d = mk3(0.0f); st.ray.mint = st.ray.maxt = 0.0f;
+    st.rng.inc = rng_inc; st.rng.state = rng_state;
+}
+
+/* the surviving path's next record: origin, continuation ray (slot A), shadow ray (slot B) */
+__device__ __forceinline__ void vertex_pack(const PathState &st, f4 &o, f4 &dA, f4 &dB, f4 &T, f4 &L, f4 &Ld, uint32_t &fl) {
+    o.x = st.ray.o.x; o.y = st.ray.o.y; o.z = st.ray.o.z;
+    fl = ((uint32_t) st.prev_measure << 4) | ((uint32_t) st.depth << 8);
+    if (st.phase == PH_SHADOW) {
+        dB.x = st.ray.d.x; dB.y = st.ray.d.y; dB.z = st.ray.d.z; dB.w = st.ray.maxt;
+        Ld.x = st.Ld.x; Ld.y = st.Ld.y; Ld.z = st.Ld.z; Ld.w = 0.0f;
+        fl |= F_HAS_B;
+        o.w = kEpsilon;
+        if (st.end_after_shadow) fl |= F_END_AFTER_B;
+        else {
+            dA.x = st.cont_d.x; dA.y = st.cont_d.y; dA.z = st.cont_d.z; dA.w = kInf;
+            fl |= F_HAS_A;
+        }
+    } else {
+        dA.x = st.ray.d.x; dA.y = st.ray.d.y; dA.z = st.ray.d.z; dA.w = st.ray.maxt;
+        fl |= F_HAS_A;
+        o.w = st.ray.mint;
+    }
+    T.x = st.T.x; T.y = st.T.y; T.z = st.T.z; T.w = st.eta;
+    L.x = st.L.x; L.y = st.L.y; L.z = st.L.z; L.w = st.pdf_mat;
+}
+
+__device__ __forceinline__ void hit_unpack(const DevScene &sc, const f4 &h, Hit &hit, bool &found) {
+    const uint32_t hw = __float_as_uint(h.w);
+    hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = hw & kMissA;
+    found = hit.tri != kMissA;
+    if (!found) hit.tri = kNoHit;
+    hit.mesh = found ? f2u(sc.shade_tris[(size_t) hit.tri * kShadeQuads].w) : kNoHit;      /* same fetch as p0 */
+}
+
 /* Integrator::Li, one vertex: consume the shadow result, shade the closest hit, write the surviving
    path -- with its next shadow / continuation rays -- compacted into the other state copy.
    A workgroup owns a contiguous range of rounds (256 paths each) and reserves output space in
@@ -332,41 +374,15 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
                 st.L = mk3(L4.x, L4.y, L4.z);
                 if (!done) {
                     if (!FIRST) { d4 = S.dA[i]; t4 = S.T_eta[i]; }
-                    Hit hit; hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = hw & kMissA;
-                    const bool found = hit.tri != kMissA;
-                    if (!found) hit.tri = kNoHit;
-                    hit.mesh = found ? f2u(sc.shade_tris[(size_t) hit.tri * kShadeQuads].w) : kNoHit;      /* same fetch as p0 */
-                    st.T = mk3(t4.x, t4.y, t4.z); st.eta = t4.w; st.pdf_mat = L4.w;
-                    st.Ld = mk3(0.0f); st.cont_d = mk3(0.0f);
-                    st.prev_measure = (int32_t) ((fl >> 4) & 3u); st.depth = (int32_t) (fl >> 8);
-                    st.phase = PH_CLOSEST; st.end_after_shadow = 0;
-                    st.ray.o = st.ray.d = mk3(0.0f); st.ray.mint = st.ray.maxt = 0.0f;
+                    Hit hit; bool found;
+                    hit_unpack(sc, h, hit, found);
                     /* pcg32 stream of this camera sample: inc from the sample index, state from HBM */
                     const uint32_t sl = (sidx % per_tile) >> 8;
-                    st.rng.inc = ((uint64_t) (s_first + sl) << 1u) | 1u;
-                    st.rng.state = FIRST ? rng0.state : S.rng[i];
+                    vertex_unpack(st, fl, L4, t4, FIRST ? rng0.state : S.rng[i], ((uint64_t) (s_first + sl) << 1u) | 1u);
                     done = path_on_closest<INTEG>(sc, st, hit, found, mk3(d4.x, d4.y, d4.z));
                     if (!done) {
                         survive = true;
-                        n_o.x = st.ray.o.x; n_o.y = st.ray.o.y; n_o.z = st.ray.o.z;
-                        n_fl = ((uint32_t) st.prev_measure << 4) | ((uint32_t) st.depth << 8);
-                        if (st.phase == PH_SHADOW) {
-                            n_dB.x = st.ray.d.x; n_dB.y = st.ray.d.y; n_dB.z = st.ray.d.z; n_dB.w = st.ray.maxt;
-                            n_Ld.x = st.Ld.x; n_Ld.y = st.Ld.y; n_Ld.z = st.Ld.z; n_Ld.w = 0.0f;
-                            n_fl |= F_HAS_B;
-                            n_o.w = kEpsilon;
-                            if (st.end_after_shadow) n_fl |= F_END_AFTER_B;
-                            else {
-                                n_dA.x = st.cont_d.x; n_dA.y = st.cont_d.y; n_dA.z = st.cont_d.z; n_dA.w = kInf;
-                                n_fl |= F_HAS_A;
-                            }
-                        } else {
-                            n_dA.x = st.ray.d.x; n_dA.y = st.ray.d.y; n_dA.z = st.ray.d.z; n_dA.w = st.ray.maxt;
-                            n_fl |= F_HAS_A;
-                            n_o.w = st.ray.mint;
-                        }
-                        n_T.x = st.T.x; n_T.y = st.T.y; n_T.z = st.T.z; n_T.w = st.eta;
-                        n_L.x = st.L.x; n_L.y = st.L.y; n_L.z = st.L.z; n_L.w = st.pdf_mat;
+                        vertex_pack(st, n_o, n_dA, n_dB, n_T, n_L, n_Ld, n_fl);
                         n_rng = st.rng.state;
                     }
                 }
@@ -406,6 +422,61 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
     }
     for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kB) D.flags[out_base + k] = 0u;
     if (overflow && threadIdx.x == 0) b.ctr[C_OVERFLOW] = 1u;
+}
+
+/* The long tail of a batch: once only a few thousand paths are alive, every wf_extend / wf_shade pair
+   is a launch that lasts as long as ONE path vertex takes (~0.1 ms) however few paths there are.
+   wf_finish ends it with one launch: each lane takes a path and walks it to its end -- shadow ray,
+   continuation ray, Li vertex, repeat -- the megakernel's loop started from stored path state. */
+template <int INTEG>
+__global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, WfBatch bt, int count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LdsStackW<16, true> stack;
+    stack.init(smem, b.stack_spill, gridDim.x * kB);
+    const WfState S = b.st[cur];
+    const uint32_t n = b.ctr[C_N + cur];
+    const uint32_t per_tile = 256u * bt.n_spp;
+    uint32_t nClosest = 0, nShadow = 0;
+    TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
+    for (uint32_t i = blockIdx.x * kB + threadIdx.x; i < n; i += gridDim.x * kB) {
+        uint32_t fl = S.flags[i];
+        if (!(fl & (F_HAS_A | F_HAS_B))) continue;
+        const uint32_t sidx = S.sidx[i];
+        f4 o = S.o[i], dA = S.dA[i], dB = S.dB[i], T = S.T_eta[i], L = S.L_pdf[i], Ld = S.Ld[i];
+        unsigned long long rng_state = S.rng[i];
+        const uint64_t inc = ((uint64_t) (bt.s_first + ((sidx % per_tile) >> 8)) << 1u) | 1u;
+        while (true) {
+            if (fl & F_HAS_B) {
+                RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(dB.x, dB.y, dB.z); ray.mint = kEpsilon; ray.maxt = dB.w;
+                Hit sh; ++nShadow;
+                if (!traverse<true>(sc, ray, true, stack, sh, tc)) { L.x = L.x + Ld.x; L.y = L.y + Ld.y; L.z = L.z + Ld.z; }
+                if (fl & F_END_AFTER_B) break;
+            }
+            RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(dA.x, dA.y, dA.z); ray.mint = o.w; ray.maxt = dA.w;
+            Hit hit; ++nClosest;
+            const bool found = traverse<true>(sc, ray, false, stack, hit, tc);
+            if (found) hit.mesh = f2u(sc.shade_tris[(size_t) hit.tri * kShadeQuads].w);
+            PathState st;
+            vertex_unpack(st, fl, L, T, rng_state, inc);
+            const bool done = path_on_closest<INTEG>(sc, st, hit, found, ray.d);
+            L.x = st.L.x; L.y = st.L.y; L.z = st.L.z;
+            if (done) break;
+            vertex_pack(st, o, dA, dB, T, L, Ld, fl);
+            rng_state = st.rng.state;
+        }
+        f4 out; out.x = L.x; out.y = L.y; out.z = L.z; out.w = 0.0f;
+        b.samp_L[sidx] = out;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        nClosest += (uint32_t) __shfl_down((int) nClosest, off);
+        nShadow += (uint32_t) __shfl_down((int) nShadow, off);
+        tc.nodes += (uint32_t) __shfl_down((int) tc.nodes, off); tc.tris += (uint32_t) __shfl_down((int) tc.tris, off);
+    }
+    if (lane_id() == 0) {
+        if (nClosest) atomicAdd(&b.stats[S_CLOSEST], (unsigned long long) nClosest);
+        if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
+        if (count) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
+    }
 }
 
 /* ----------------------------------------------------------- host driver */
@@ -495,6 +566,16 @@ void launch_shade(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &bt
                       else hipLaunchKernelGGL((wf_shade<I, false>), grid, block, 0, s, sc, b, cur, bt); break;
         SH(0) SH(1) SH(2) SH(3) SH(4) SH(5) SH(6)
 #undef SH
+    }
+}
+
+void launch_finish(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &bt, bool count, int grid_, hipStream_t s) {
+    const dim3 grid(grid_), block(kB);
+    const size_t lds = (size_t) LdsStackW<16, true>::kLdsEntries * kB * sizeof(int);
+    switch (sc.integrator.type) {
+#define FN(I) case I: hipLaunchKernelGGL((wf_finish<I>), grid, block, lds, s, sc, b, cur, bt, (int) count); break;
+        FN(0) FN(1) FN(2) FN(3) FN(4) FN(5) FN(6)
+#undef FN
     }
 }
 
@@ -600,12 +681,15 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     int lds_stack = L.stack_depth <= 16 ? 16 : 24;
     if (const char *e = getenv("NORI_HIP_WF_STACK")) lds_stack = atoi(e) <= 16 ? 16 : atoi(e) <= 24 ? 24 : 32;
     const bool spill = L.stack_depth > lds_stack;
+    int finish_paths = 524288;           /* fewer live paths than this: wf_finish ends the batch */
+    if (const char *e = getenv("NORI_HIP_WF_FINISH_PATHS")) finish_paths = std::max(256, atoi(e)) & ~255;
+    const int finish_grid = finish_paths / kB;
     int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + 64))));
     if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(8, std::max(1, atoi(e)));
     const int extend_grid = 256 * per_cu;
-    if (spill) {
-        const size_t per_pipe_ints = (size_t) (L.stack_depth - lds_stack) * extend_grid * kB, ints = per_pipe_ints * n_pipes;
+    if (L.stack_depth > 16) {      /* wf_finish keeps 16 entries in LDS */
+        const size_t per_pipe_ints = (size_t) (L.stack_depth - 16) * std::max(extend_grid, finish_grid) * kB, ints = per_pipe_ints * n_pipes;
         if (g_pool.spill_ints < ints) {
             if (g_pool.spill) (void) hipFree(g_pool.spill);
             g_pool.spill = nullptr; g_pool.spill_ints = 0;
@@ -618,6 +702,8 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     int sync_every = 6;      /* path-loop iterations between two readbacks of the path count */
     if (const char *e = getenv("NORI_HIP_WF_SYNC_EVERY")) sync_every = std::min(64, std::max(1, atoi(e)));
     const bool census = getenv("NORI_HIP_CENSUS") != nullptr;
+    bool use_finish = true;
+    if (const char *e = getenv("NORI_HIP_WF_FINISH")) use_finish = atoi(e) != 0;
 
     FilmLaunch fl;
     fl.tile_mod = L.tile_mod; fl.tile_rem = L.tile_rem; fl.tiles_x = L.tiles_x; fl.tiles_y = L.tiles_y; fl.tile_w = L.tile_w;
@@ -636,7 +722,12 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             P.cur = 0; P.first = true; P.active = true; any = true;
         }
         if (!any) break;
-        for (int it = 0; it < sync_every; ++it)
+        /* the path count is read back every sync_every iterations, more often once it is small
+           (the readback costs ~20 us, an iteration on a few paths ~100 us) */
+        uint32_t n_max = 0;
+        for (int k = 0; k < n_pipes; ++k) if (pipes[k].active) n_max = std::max(n_max, pipes[k].first ? 0xffffffffu : pipes[k].h_ctr[C_N + pipes[k].cur]);
+        const int iters = n_max > (16u << 20) ? sync_every : std::min(sync_every, 2);
+        for (int it = 0; it < iters; ++it)
             for (int k = 0; k < n_pipes; ++k) {
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
@@ -655,6 +746,11 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             Pipe &P = pipes[k];
             if (P.active && P.h_ctr[C_OVERFLOW] != 0) return "wavefront: path state pool overflow";
             if (census && P.active) fprintf(stderr, "[wavefront] pipe %d iteration %u: %u path slots\n", k, stats.n_iterations, P.h_ctr[C_N + P.cur]);
+            if (P.active && P.h_ctr[C_N + P.cur] != 0 && P.h_ctr[C_N + P.cur] <= (uint32_t) finish_paths && use_finish) {
+                launch_finish(sc, P.b, P.cur, P.bt, L.count_traversal, finish_grid, P.stream);
+                stats.n_launches++;
+                P.h_ctr[C_N + P.cur] = 0;
+            }
             if (!P.active || P.h_ctr[C_N + P.cur] != 0) continue;
             /* batch done: splat its samples (each pipe owns its tiles' accumulators) */
             fl.tile_first = P.bt.tile_first; fl.store_tile_first = P.bt.tile_first; fl.n_tiles = P.bt.n_tiles; fl.n_spp = P.bt.n_spp;
