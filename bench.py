@@ -115,10 +115,10 @@ def main():
 
     from nori_amd import dist as ndist
 
-    def step(want_stats=False, count=False):
+    def step(want_stats=False, count=False, time_kernels=False):
         # tile split over ranks + one RCCL SUM-reduce of the RGBW frame to rank 0
         return ndist.render_distributed(r.render_into, frame, "tile", args.spp, rank, world, stream=stream,
-                                        want_stats=want_stats, count_traversal=count)
+                                        want_stats=want_stats, count_traversal=count, time_kernels=time_kernels)
 
     # one instrumented pass: traversal counters for the roofline (untimed)
     counted = step(want_stats=True, count=True)
@@ -126,11 +126,13 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = []
+    kernel_ms, trace_ms, shade_ms, film_ms, trace_launches = [], [], [], [], 0
     last = None
     for _ in range(args.steps):
-        last = step(want_stats=True)        # stats: HIP-event kernel time on the launch stream
-        kernel_ms.append(last["kernel_ms"])
+        # stats: HIP-event times on the launch stream -- whole pass and per kernel class
+        last = step(want_stats=True, time_kernels=True)
+        kernel_ms.append(last["kernel_ms"]); trace_ms.append(last["trace_ms"]); shade_ms.append(last["shade_ms"])
+        film_ms.append(last["film_ms"]); trace_launches = last["n_trace_launches"]
     barrier()
     dt = time.perf_counter() - t0
 
@@ -146,12 +148,20 @@ def main():
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
         mrays = rays_total / (ms_per_step * 1e-3) / 1e6
-        # roofline of the dominant kernel on this rank
+        # roofline of the dominant kernel on this rank: the ray-query kernel (wf_extend, all its launches
+        # of one pass; render_kernel for the megakernel, which also contains the shading)
         tile_w = 16 + 2 * r.border
         parts = algorithmic_bytes(counted, info, tile_w, my_tiles, engine)
-        alg = parts["total"]
-        k_ms = float(np.mean(kernel_ms))
-        achieved = alg / (k_ms * 1e-3) / 1e9
+        k_ms, t_ms = float(np.mean(kernel_ms)), float(np.mean(trace_ms))
+        if engine == "wavefront":
+            dom_name = "wf_extend (all launches of one render pass)"
+            dom_bytes = parts["traversal"] + counted["n_closest_rays"] * 52 + counted["n_shadow_rays"] * 16 - counted["n_camera_samples"] * 36
+        else:
+            dom_name = "render_kernel (all launches of one render pass)"
+            dom_bytes = parts["traversal"] + parts["surface"] + counted["n_camera_samples"] * 24
+        achieved = dom_bytes / (t_ms * 1e-3) / 1e9
+        traffic = measured_traffic(args, sc, engine)
+        compulsory = info["total_bytes"] + parts["state"] + parts["film"]       # each byte that has to cross HBM at least once
         out = {
             "metric": "Mrays/sec (primary+secondary) at 1024x1024 256spp",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -161,12 +171,21 @@ def main():
                        "height": args.height, "spp": args.spp, "triangles": info["n_triangles"],
                        "parallelism": f"tile-split x{world} + RCCL reduce" if world > 1 else "single GPU",
                        "rays_per_step": int(rays_total), "seed_mode": "per_sample", "engine": engine},
-            "roofline": {"bound": "hbm", "kernel": "render pass: wf_generate + (wf_extend, wf_shade)* + film_gather + film_resolve" if engine == "wavefront" else "render pass: render_kernel + film_gather + film_resolve", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": measured_traffic(args, sc, engine),
-                         "kernel_ms": round(k_ms, 3), "algorithmic_bytes": int(alg), "algorithmic_bytes_parts": parts,
-                         "launches_or_workgroups": int(last["n_workgroups"]),
-                         "node_tests": int(counted["n_node_tests"]), "tri_tests": int(counted["n_tri_tests"])},
+                         "traffic": traffic.get("dominant_kernel_bytes") if traffic else None,
+                         "kernel_ms": round(t_ms, 3), "launches": int(trace_launches), "algorithmic_bytes": int(dom_bytes),
+                         "node_tests": int(counted["n_node_tests"]), "tri_tests": int(counted["n_tri_tests"]),
+                         "note": "algorithmic bytes per SURVEY.md 8(d): N_node*64 + N_tri*48 + ray/hit records; "
+                                 "this scene's BVH (%.1f MB) is L2-resident, so the node/triangle bytes are served by L2 and "
+                                 "'achieved' can exceed the HBM peak -- see 'pass' for what HBM has to carry" % (info["total_bytes"] / 1e6)},
+            "pass": {"kernel_ms": round(k_ms, 3), "trace_ms": round(t_ms, 3), "shade_ms": round(float(np.mean(shade_ms)), 3),
+                     "film_ms": round(float(np.mean(film_ms)), 3), "launches": int(last["n_workgroups"]) if engine == "wavefront" else None,
+                     "algorithmic_bytes_parts": parts,
+                     "hbm_compulsory_bytes": int(compulsory),
+                     "hbm_compulsory_gbs": round(compulsory / (k_ms * 1e-3) / 1e9, 2),
+                     "hbm_compulsory_frac": round(compulsory / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     "hbm_measured_bytes": traffic.get("hbm_bytes_per_launch") if traffic else None},
             "accel": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in info.items()},
         }
         if not args.no_cpu_baseline and world == 1:
@@ -187,7 +206,7 @@ def measured_traffic(args, sc, engine):
         return None
     t = json.load(open(path))
     key = f"{args.workload}:{args.width}x{args.height}:{args.spp}:{engine}"
-    return t.get(key, {}).get("hbm_bytes_per_launch")
+    return t.get(key)
 
 
 def usable_cores() -> int:

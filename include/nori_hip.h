@@ -205,6 +205,8 @@ typedef struct nori_render_params {
     uint32_t tile_rem;      /* <  tile_mod */
     int32_t seed_mode;      /* nori_seed_mode; the device supports PER_SAMPLE */
     int32_t count_traversal;/* != 0: also count node/triangle tests (slower) */
+    int32_t time_kernels;   /* != 0: HIP events around every kernel launch, summed per
+                               kernel class into nori_render_stats.*_ms          */
     void *stream;           /* hipStream_t or NULL for the default stream   */
 } nori_render_params;
 
@@ -226,6 +228,11 @@ typedef struct nori_render_stats {
     uint32_t n_workgroups;   /* launch geometry of the render kernel: one
                                 workgroup per (tile, spp chunk)              */
     uint32_t lds_bytes;      /* dynamic LDS per workgroup                    */
+    /* time_kernels != 0: summed HIP-event durations, on the launch stream, of
+       the ray-query kernels (wf_extend; render_kernel for the megakernel, which
+       also shades), the Li kernels (wf_shade, wf_finish) and the film kernels */
+    float trace_ms, shade_ms, film_ms;
+    uint32_t n_trace_launches;
 } nori_render_stats;
 
 typedef struct nori_accel_info {

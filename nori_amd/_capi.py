@@ -71,7 +71,7 @@ class SceneDesc(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("spp_begin", C.c_uint32), ("spp_count", C.c_uint32),
                 ("tile_mod", C.c_uint32), ("tile_rem", C.c_uint32),
-                ("seed_mode", C.c_int32), ("count_traversal", C.c_int32),
+                ("seed_mode", C.c_int32), ("count_traversal", C.c_int32), ("time_kernels", C.c_int32),
                 ("stream", C.c_void_p)]
 
 
@@ -79,7 +79,8 @@ class RenderStats(C.Structure):
     _fields_ = [("n_camera_samples", C.c_uint64), ("n_closest_rays", C.c_uint64),
                 ("n_shadow_rays", C.c_uint64), ("n_node_tests", C.c_uint64),
                 ("n_tri_tests", C.c_uint64), ("n_invalid", C.c_uint64),
-                ("kernel_ms", C.c_float), ("n_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32)]
+                ("kernel_ms", C.c_float), ("n_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("trace_ms", C.c_float), ("shade_ms", C.c_float), ("film_ms", C.c_float), ("n_trace_launches", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -32,6 +32,7 @@
 
 #include "../../../include/nori_hip.h"
 #include "film.h"
+#include "ktimer.h"
 #include "rt_path.h"
 #include "scene_prep.h"
 #include "lbvh.h"
@@ -800,6 +801,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         HIP_TRY(ctx, hipEventRecord(ev0, s));
     }
     WfStats wst;
+    KernelTimer timer(stats && params->time_kernels != 0);
     int engine = ctx->engine;
     if (const char *e = getenv("NORI_HIP_ENGINE")) engine = std::string(e) == "wavefront" ? 1 : (std::string(e) == "megakernel" ? 0 : -1);
     /* auto: the wavefront engine wins once there are enough paths to keep its kernels full
@@ -812,6 +814,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         const uint32_t need = ctx->bvh.max_depth + 1;
         wl.stack_depth = (int) need;
         wl.count_traversal = params->count_traversal != 0;
+        wl.time_kernels = stats && params->time_kernels != 0;
         wl.max_paths = ctx->wavefront_paths;
         std::string err = wavefront_render(ctx->dev, ctx->d_filter, wl, (float *) d_rgbw, s, wst);
         if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
@@ -835,17 +838,23 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
             a2.spp_begin = a.spp_begin + sb; a2.spp_count = std::min(spp_per_launch, a.spp_count - sb);
             plan_chunks(a2);
             hipError_t e;
+            timer.begin(KC_TRACE, s);
             /* the LDS stack is sized to the tree: fewer entries -> more workgroups per CU */
             if (need <= 16) e = count ? launch_render<16, true>(ctx, a2, film, s) : launch_render<16, false>(ctx, a2, film, s);
             else if (need <= 24) e = count ? launch_render<24, true>(ctx, a2, film, s) : launch_render<24, false>(ctx, a2, film, s);
             else if (need <= 32) e = count ? launch_render<32, true>(ctx, a2, film, s) : launch_render<32, false>(ctx, a2, film, s);
             else e = count ? launch_render<64, true>(ctx, a2, film, s) : launch_render<64, false>(ctx, a2, film, s);
+            timer.end(s);
             HIP_TRY(ctx, e);
             fl.n_spp = a2.spp_count;
+            timer.begin(KC_FILM, s);
             if (!(a.debug_flags & 1u)) film_gather(ctx->dev, ctx->d_filter, film, fl, s);
+            timer.end(s);
             n_workgroups += a2.n_sel_tiles * a2.n_chunks;
         }
+        timer.begin(KC_FILM, s);
         film_resolve(ctx->dev, film, fl, (float *) d_rgbw, s);
+        timer.end(s);
         HIP_TRY(ctx, hipGetLastError());
         if (stats) n_invalid = film_invalid_count(film, s);
     }
@@ -864,6 +873,10 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         if (getenv("NORI_HIP_CENSUS") && h[8])
             fprintf(stderr, "[census] shade runs %llu lanes %.1f | inner runs %llu lanes %.1f | leaf runs %llu lanes %.1f\n", h[8], (double) h[9] / h[8], h[10], (double) h[11] / std::max(1ull, h[10]), h[12], (double) h[13] / std::max(1ull, h[12]));
         stats->n_workgroups = n_workgroups;
+        float cms[KC_COUNT]; unsigned int cl[KC_COUNT];
+        timer.collect(cms, cl);
+        if (engine == 1) { for (int c = 0; c < KC_COUNT; ++c) { cms[c] = wst.class_ms[c]; cl[c] = wst.class_launches[c]; } }
+        stats->trace_ms = cms[KC_TRACE]; stats->shade_ms = cms[KC_SHADE]; stats->film_ms = cms[KC_FILM]; stats->n_trace_launches = cl[KC_TRACE];
         if (engine == 1) {
             stats->n_camera_samples = wst.n_camera; stats->n_closest_rays = wst.n_closest; stats->n_shadow_rays = wst.n_shadow;
             stats->n_node_tests = wst.n_nodes; stats->n_tri_tests = wst.n_tris; stats->n_invalid = wst.n_invalid;

@@ -14,6 +14,7 @@ struct WfLaunch {
     int32_t tile_w;
     int stack_depth;            /* traversal stack entries the tree needs: max_depth + 1 */
     bool count_traversal;
+    bool time_kernels;          /* HIP events around every launch (ktimer.h) */
     size_t max_paths;           /* paths in flight per batch */
 };
 
@@ -21,6 +22,8 @@ struct WfStats {
     unsigned long long n_camera = 0, n_closest = 0, n_shadow = 0, n_nodes = 0, n_tris = 0, n_invalid = 0;
     uint32_t n_batches = 0, n_iterations = 0, n_launches = 0;
     size_t state_bytes = 0;
+    float class_ms[3] = {0.0f, 0.0f, 0.0f};      /* KernelClass: trace, shade, film */
+    uint32_t class_launches[3] = {0, 0, 0};
 };
 
 /* Renders the selected tiles / samples into d_rgbw (accumulating), on `stream`.

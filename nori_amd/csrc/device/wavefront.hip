@@ -37,6 +37,7 @@
 #include <vector>
 
 #include "film.h"
+#include "ktimer.h"
 #include "rt_path.h"
 #include "wavefront.h"
 
@@ -705,6 +706,7 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     bool use_finish = true;
     if (const char *e = getenv("NORI_HIP_WF_FINISH")) use_finish = atoi(e) != 0;
 
+    KernelTimer timer(L.time_kernels);
     FilmLaunch fl;
     fl.tile_mod = L.tile_mod; fl.tile_rem = L.tile_rem; fl.tiles_x = L.tiles_x; fl.tiles_y = L.tiles_y; fl.tile_w = L.tile_w;
 
@@ -731,8 +733,12 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             for (int k = 0; k < n_pipes; ++k) {
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
+                timer.begin(KC_TRACE, P.stream);
                 launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, extend_grid, P.bt, P.stream);
+                timer.end(P.stream);
+                timer.begin(KC_SHADE, P.stream);
                 launch_shade(sc, P.b, P.cur, P.bt, P.first, sh_grid, P.stream);
+                timer.end(P.stream);
                 P.first = false;
                 P.cur ^= 1;
                 stats.n_launches += 2;
@@ -747,14 +753,18 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             if (P.active && P.h_ctr[C_OVERFLOW] != 0) return "wavefront: path state pool overflow";
             if (census && P.active) fprintf(stderr, "[wavefront] pipe %d iteration %u: %u path slots\n", k, stats.n_iterations, P.h_ctr[C_N + P.cur]);
             if (P.active && P.h_ctr[C_N + P.cur] != 0 && P.h_ctr[C_N + P.cur] <= (uint32_t) finish_paths && use_finish) {
+                timer.begin(KC_SHADE, P.stream);
                 launch_finish(sc, P.b, P.cur, P.bt, L.count_traversal, finish_grid, P.stream);
+                timer.end(P.stream);
                 stats.n_launches++;
                 P.h_ctr[C_N + P.cur] = 0;
             }
             if (!P.active || P.h_ctr[C_N + P.cur] != 0) continue;
             /* batch done: splat its samples (each pipe owns its tiles' accumulators) */
             fl.tile_first = P.bt.tile_first; fl.store_tile_first = P.bt.tile_first; fl.n_tiles = P.bt.n_tiles; fl.n_spp = P.bt.n_spp;
+            timer.begin(KC_FILM, P.stream);
             film_gather(sc, d_filter_table, P.film, fl, P.stream);
+            timer.end(P.stream);
             stats.n_launches++;
             P.active = false;
             P.s0 += P.bt.n_spp;
@@ -767,7 +777,9 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             WF_TRY(hipEventRecord(g_events[k], pipes[k].stream));
             WF_TRY(hipStreamWaitEvent(s, g_events[k], 0));
         }
+    timer.begin(KC_FILM, s);
     film_resolve(sc, film, fl, d_rgbw, s);
+    timer.end(s);
     stats.n_launches++;
     WF_TRY(hipGetLastError());
     unsigned long long h[2 * S_COUNT];
@@ -778,6 +790,7 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
         stats.n_nodes += h[k * S_COUNT + S_NODES]; stats.n_tris += h[k * S_COUNT + S_TRIS];
     }
     stats.n_invalid = film_invalid_count(film, s);
+    timer.collect(stats.class_ms, stats.class_launches);
     return std::string();
 }
 

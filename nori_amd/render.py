@@ -171,12 +171,13 @@ class Renderer:
 
     # ------------------------------------------------------------ hot path
     @staticmethod
-    def _params(spp_begin, spp_count, tile_mod, tile_rem, count_traversal, stream):
+    def _params(spp_begin, spp_count, tile_mod, tile_rem, count_traversal, stream, time_kernels=False):
         p = capi.RenderParams()
         p.spp_begin, p.spp_count = int(spp_begin), int(spp_count)
         p.tile_mod, p.tile_rem = int(tile_mod), int(tile_rem)
         p.seed_mode = capi.SEED_PER_SAMPLE
         p.count_traversal = int(bool(count_traversal))
+        p.time_kernels = int(bool(time_kernels))
         p.stream = stream
         return p
 
@@ -190,7 +191,7 @@ class Renderer:
         return rgbw, st.as_dict()
 
     def render_into(self, rgbw_tensor, spp_count=None, spp_begin=0, tile_mod=1, tile_rem=0,
-                    count_traversal=False, stream=None, want_stats=True):
+                    count_traversal=False, stream=None, want_stats=True, time_kernels=False):
         """Accumulate into a torch CUDA float32 tensor of shape frame_shape().
 
         `stream`: a torch.cuda.Stream (its raw hipStream_t is handed to the
@@ -198,7 +199,7 @@ class Renderer:
         assert rgbw_tensor.is_cuda and rgbw_tensor.is_contiguous() and tuple(rgbw_tensor.shape) == tuple(self.frame_shape())
         spp = self.scene.sample_count if spp_count is None else spp_count
         raw = C.c_void_p(stream.cuda_stream) if stream is not None else None
-        p = self._params(spp_begin, spp, tile_mod, tile_rem, count_traversal, raw)
+        p = self._params(spp_begin, spp, tile_mod, tile_rem, count_traversal, raw, time_kernels)
         st = capi.RenderStats() if want_stats else None
         self._check(self._lib.nori_hip_render(self._h, C.byref(p), C.c_void_p(rgbw_tensor.data_ptr()),
                                               C.byref(st) if st is not None else None), "render")
