@@ -3,18 +3,21 @@
  *
  * Kernel shapes (wave64, 256-thread workgroups = 4 waves):
  *
- *  render_kernel   one workgroup per (16x16 pixel tile, spp chunk); thread <->
- *                  pixel, each wave an 8x8 quad of the tile.  Every lane runs
- *                  the path state machine of rt_path.h persistently: one ray
- *                  query per loop trip, a finished path is splatted and the lane
- *                  regenerates the next camera sample of its pixel in place.
- *                  LDS holds (a) the per-lane traversal stacks, [depth][thread]
- *                  so that bank = lane (conflict free), (b) the RGBW
- *                  accumulation tile incl. filter border -- ImageBlock::put
- *                  (src/block.cpp:62-91) becomes ds_add_f32 into this tile --
- *                  and (c) the 33-entry filter table.  The tile is merged into
- *                  the frame buffer once per workgroup with global float
- *                  atomics: ImageBlock::put(ImageBlock&) (src/block.cpp:93-102).
+ *  render_kernel   the megakernel engine (default for small jobs): one workgroup per
+ *                  (16x16 pixel tile, spp chunk); thread <-> pixel, each wave an 8x8
+ *                  quad of the tile.  Every lane runs the path state machine of
+ *                  rt_path.h persistently; each loop trip the wave votes (__ballot)
+ *                  over what its lanes want -- shade / node test / triangle test --
+ *                  and runs a kind only when enough lanes want it.  A finished
+ *                  sample goes to the film's sample store (film.h) and the lane
+ *                  regenerates the next camera sample of its pixel in place.  LDS
+ *                  holds the per-lane traversal stacks, [depth][thread] so that
+ *                  bank = lane (conflict free).
+ *  wavefront.hip   the wavefront engine (default for >= 2^24 samples per call):
+ *                  path state in HBM, wf_extend / wf_shade / wf_finish.
+ *  film.hip        ImageBlock::put (src/block.cpp:62-102) for both engines: sample
+ *                  store -> gather splat per tile -> block merge, no atomics.
+ *  lbvh.hip        Accel::build on the GPU (NORI_ACCEL_GPU_LBVH).
  *  intersect_kernel / li_kernel / bsdf_* / warp_* / camera / pcg32 / splat
  *                  batch twins of the reference's virtual calls for parity tests
  *                  and for the host-side plugin classes.
