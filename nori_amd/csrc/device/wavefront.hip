@@ -177,8 +177,9 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
        touches the counter (a single hot word sustains only ~90 atomics/us --
        MI355X_MICROARCH.md, row "dequeue" -- which used to cost 0.2 ms per tail iteration). */
     const uint32_t n_waves = gridDim.x * (kB / 64u), wave_id = blockIdx.x * (kB / 64u) + (threadIdx.x >> 6);
-    const uint32_t kChunk = n <= n_waves * 1024u ? (((n + n_waves - 1u) / n_waves + 63u) & ~63u)      /* all static */
-                                                 : min(1024u, max(64u, (n / (n_waves * 2u)) & ~63u));
+    const uint32_t static_limit = (uint32_t) ((thresholds >> 16) & 0xfff) * n_waves;
+    const uint32_t kChunk = n <= static_limit ? (((n + n_waves - 1u) / n_waves + 63u) & ~63u)      /* all static */
+                                              : min(1024u, max(64u, (n / (n_waves * (uint32_t) ((thresholds >> 28) & 0xf))) & ~63u));
     const uint32_t dyn0 = n_waves * kChunk;        /* first dynamically claimed path */
     uint32_t chunk_pos = min(wave_id * kChunk, n), chunk_end = min(chunk_pos + kChunk, n);       /* wave-uniform */
     uint32_t nClosest = 0, nShadow = 0, nCam = 0;
@@ -675,7 +676,10 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     if (const char *e = getenv("NORI_HIP_WF_REFILL")) refill = std::min(64, std::max(1, atoi(e)));
     int leaf_th = 16;
     if (const char *e = getenv("NORI_HIP_WF_LEAF")) leaf_th = std::min(64, std::max(1, atoi(e)));
-    const int thresholds = refill | (leaf_th << 8);
+    int static_per_wave = 1024, dyn_div = 8;      /* chunking of wf_extend: all-static below static_per_wave paths per wave, else n / (waves * dyn_div) per claim */
+    if (const char *e = getenv("NORI_HIP_WF_STATIC")) static_per_wave = std::min(4095, std::max(0, atoi(e)));
+    if (const char *e = getenv("NORI_HIP_WF_DYNDIV")) dyn_div = std::min(15, std::max(1, atoi(e)));
+    const int thresholds = refill | (leaf_th << 8) | (static_per_wave << 16) | (dyn_div << 28);
     /* persistent extend grid: fill the CUs, but with two pipes leave half of the wave slots to
        the other pipe's kernels */
     /* traversal stack: what the tree needs, at most `lds_stack` entries of it in LDS */

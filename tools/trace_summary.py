@@ -15,7 +15,7 @@ for r in rows:
 for k, (c, t) in sorted(tot.items(), key=lambda kv: -kv[1][1])[:12]:
     print(f"{k:50s} calls {c:5d} total {t/1e6:9.3f} ms avg {t/c/1e3:9.1f} us")
 # last full pass: from the last wf_generate on
-gi = [i for i, r in enumerate(rows) if "wf_generate" in r["Kernel_Name"]]
+gi = [i for i, r in enumerate(rows) if "wf_generate" in r["Kernel_Name"] or re.search(r"wf_extend<[^>]*true>\(", r["Kernel_Name"])]
 if gi:
     seq = rows[gi[-1]:]
     t0 = int(seq[0]["Start_Timestamp"])

@@ -9,5 +9,5 @@ r.set_option("engine", os.environ.get("ENGINE", "wavefront"))
 r.set_option("wavefront_paths", int(os.environ.get("PATHS", 1 << 28)))
 f = torch.zeros(r.frame_shape(), device="cuda")
 for i in range(int(os.environ.get("REPS", 3))):
-    f.zero_(); st = r.render_into(f)
+    f.zero_(); st = r.render_into(f, tile_mod=int(os.environ.get("TILE_MOD", 1)))
     print(round(st["kernel_ms"], 1), "ms", round((st["n_closest_rays"] + st["n_shadow_rays"]) / st["kernel_ms"] / 1e3, 1), "Mrays/s")
