@@ -102,3 +102,69 @@ def test_gpu_large_scene_lbvh_both_engines():
     assert a["max_depth"] < 64 and a["build_ms"] < 2000
     assert a["rays"] == b["rays"] and a["node_tests_per_ray"] == b["node_tests_per_ray"]
     assert abs(a["mean_w"] - b["mean_w"]) < 1e-6
+
+
+def _with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_wavefront_schedule_knobs_do_not_change_the_frame(renderer_factory):
+    """wf_finish on/off, readback cadence, chunking, thresholds and pipes only reschedule the same
+    per-sample work: every camera sample carries the same radiance, and the film adds the samples of a
+    pixel in sample order, so the frames are bit-identical."""
+    sc = scenes.cornell_box(96, 64, 9, "path_mis", sphere_bsdfs=[Bsdf("mirror"), Bsdf("dielectric")])
+    wf = renderer_factory(sc)
+    wf.set_option("engine", "wavefront")
+    ref, sr = wf.render_host(count_traversal=True)
+    for env in ({"NORI_HIP_WF_FINISH": 0}, {"NORI_HIP_WF_FINISH_PATHS": 256}, {"NORI_HIP_WF_SYNC_EVERY": 1},
+                {"NORI_HIP_WF_STATIC": 0, "NORI_HIP_WF_DYNDIV": 1}, {"NORI_HIP_WF_REFILL": 1, "NORI_HIP_WF_LEAF": 64},
+                {"NORI_HIP_WF_PIPES": 2}, {"NORI_HIP_WF_EXTEND_WGS_PER_CU": 1}):
+        b, sb = _with_env(env, lambda: wf.render_host(count_traversal=True))
+        for k in ("n_camera_samples", "n_closest_rays", "n_shadow_rays", "n_node_tests", "n_tri_tests"):
+            assert sr[k] == sb[k], (env, k)
+        assert np.array_equal(b, ref), env
+
+
+def test_wavefront_deep_tree_spills_the_stack(renderer_factory):
+    """LBVH over a triangle soup is deeper than 16: with NORI_HIP_WF_STACK=16 wf_extend keeps 16 stack
+    entries in LDS and the rest in its global spill columns; same frame and counts as the megakernel
+    (64-entry LDS stack)."""
+    sc = scenes.soup_scene(30000, seed=3, width=80, height=56, integrator="path_mis")
+    sc.sample_count = 4
+    from nori_amd.scene import Mesh
+    v, f = scenes.quad((-3, 3, -3), (3, 3, -3), (3, 3, 3), (-3, 3, 3))
+    sc.meshes.append(Mesh(v, f, bsdf=Bsdf("diffuse", (0, 0, 0)), radiance=(5.0, 5.0, 5.0), name="light"))
+    mk = renderer_factory(sc, builder=1)
+    wf = renderer_factory(sc, builder=1)
+    wf.set_option("engine", "wavefront")
+    assert mk.accel_info()["max_depth"] + 1 > 16
+    a, sa = mk.render_host(count_traversal=True)
+    for stack in (16, 24):
+        b, sb = _with_env({"NORI_HIP_WF_STACK": stack}, lambda: wf.render_host(count_traversal=True))
+        for k in ("n_closest_rays", "n_shadow_rays", "n_node_tests", "n_tri_tests"):
+            assert sa[k] == sb[k], (stack, k)
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-5)
+
+
+def test_kernel_class_timing(renderer_factory):
+    import torch
+    sc = scenes.cornell_box(128, 128, 16, "path_mis")
+    for engine in ("megakernel", "wavefront"):
+        r = renderer_factory(sc)
+        r.set_option("engine", engine)
+        frame = torch.zeros(r.frame_shape(), device="cuda")
+        st = r.render_into(frame, time_kernels=True)
+        assert st["trace_ms"] > 0 and st["film_ms"] > 0 and st["n_trace_launches"] >= 1
+        assert (st["shade_ms"] > 0) == (engine == "wavefront")
+        assert st["trace_ms"] + st["shade_ms"] + st["film_ms"] <= st["kernel_ms"] * 1.02 + 0.05
+        st0 = r.render_into(frame)
+        assert st0["trace_ms"] == 0 and st0["n_trace_launches"] == 0
