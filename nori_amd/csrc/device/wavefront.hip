@@ -50,6 +50,8 @@ constexpr int kB = 256;
 /* counters: path count and dynamic-chunk head per state copy (index + copy), overflow flag */
 enum { C_N = 0, C_HEAD = 2, C_OVERFLOW = 4, C_COUNT = 8 };
 enum { S_CAM = 0, S_CLOSEST = 1, S_SHADOW = 2, S_NODES = 3, S_TRIS = 4, S_INVALID = 5, S_COUNT = 8 };
+/* census (COUNT builds, NORI_HIP_CENSUS): wave-level trips of wf_extend's loop and the lanes they used */
+enum { Z_TRIPS = 0, Z_INNER_TRIPS = 1, Z_INNER_LANES = 2, Z_LEAF_TRIPS = 3, Z_LEAF_LANES = 4, Z_REFILLS = 5, Z_REFILL_LANES = 6, Z_COUNT = 8 };
 
 /* path flags */
 constexpr uint32_t F_HAS_A = 1u, F_HAS_B = 2u, F_END_AFTER_B = 4u;
@@ -79,6 +81,7 @@ struct WfBuf {
     unsigned long long *stats;
     uint32_t capacity; /* records per copy */
     int *stack_spill;  /* [entry beyond the LDS stack][lane of the wf_extend grid] */
+    unsigned long long *census;   /* Z_* counters or null */
 };
 
 struct WfBatch {
@@ -183,6 +186,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
     const uint32_t dyn0 = n_waves * kChunk;        /* first dynamically claimed path */
     uint32_t chunk_pos = min(wave_id * kChunk, n), chunk_end = min(chunk_pos + kChunk, n);       /* wave-uniform */
     uint32_t nClosest = 0, nShadow = 0, nCam = 0;
+    uint32_t zc[Z_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};      /* wave-uniform census */
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
     while (true) {
         /* a lane is idle when it has no ray in flight: either it needs a new path, or its path's
@@ -202,6 +206,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
                 if (base >= n) { exhausted = true; chunk_pos = chunk_end = 0u; }
             }
             const unsigned long long fresh = idle & ~pending;
+            if (COUNT) { zc[Z_REFILLS]++; zc[Z_REFILL_LANES] += (uint32_t) nIdle; }
             const uint32_t avail = chunk_end - chunk_pos;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (fresh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) fresh, 0u));   /* set bits below this lane */
             if (FIRST) {
@@ -247,10 +252,12 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
         const bool was = trav_active(tv);
         /* inner-node steps run every trip; the (rarer) triangle step only when enough lanes
            wait at a leaf or nobody has an inner node to test */
+        if (COUNT) { const int ni = __popcll(__ballot(trav_at_inner(tv))); zc[Z_TRIPS]++; if (ni) { zc[Z_INNER_TRIPS]++; zc[Z_INNER_LANES] += (uint32_t) ni; } }
         if (trav_at_inner(tv)) trav_inner_step<COUNT>(sc, stack, tv, tc);
         const bool atLeaf = trav_at_leaf(tv);
         const int nLeaf = __popcll(__ballot(atLeaf));
         const bool innerLeft = __ballot(trav_at_inner(tv)) != 0ull;
+        if (COUNT && nLeaf && (nLeaf >= leaf_threshold || !innerLeft)) { zc[Z_LEAF_TRIPS]++; zc[Z_LEAF_LANES] += (uint32_t) nLeaf; }
         if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT>(sc, stack, tv, tc);
         if (was && !trav_active(tv)) {
             if (rid & 2u) {      /* the shadow ray is answered; the continuation ray of the same vertex is next */
@@ -277,6 +284,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
         if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
         if (FIRST && nCam) atomicAdd(&b.stats[S_CAM], (unsigned long long) nCam);
         if (COUNT) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
+        if (COUNT && b.census) for (int k = 0; k < Z_COUNT; ++k) if (zc[k]) atomicAdd(&b.census[k], (unsigned long long) zc[k]);
     }
 }
 
@@ -711,6 +719,12 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     if (const char *e = getenv("NORI_HIP_WF_FINISH")) use_finish = atoi(e) != 0;
 
     KernelTimer timer(L.time_kernels);
+    unsigned long long *d_census = nullptr;
+    if (census && L.count_traversal) {
+        WF_TRY(hipMalloc((void **) &d_census, Z_COUNT * sizeof(unsigned long long)));
+        WF_TRY(hipMemsetAsync(d_census, 0, Z_COUNT * sizeof(unsigned long long), s));
+    }
+    for (int k = 0; k < n_pipes; ++k) pipes[k].b.census = d_census;
     FilmLaunch fl;
     fl.tile_mod = L.tile_mod; fl.tile_rem = L.tile_rem; fl.tiles_x = L.tiles_x; fl.tiles_y = L.tiles_y; fl.tile_w = L.tile_w;
 
@@ -795,6 +809,14 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     }
     stats.n_invalid = film_invalid_count(film, s);
     timer.collect(stats.class_ms, stats.class_launches);
+    if (d_census) {
+        unsigned long long z[Z_COUNT];
+        WF_TRY(hipMemcpy(z, d_census, sizeof(z), hipMemcpyDeviceToHost));
+        (void) hipFree(d_census);
+        fprintf(stderr, "[wavefront census] trips %llu | node steps %llu, lanes/step %.1f | triangle steps %llu, lanes/step %.1f | refills %llu, idle lanes/refill %.1f\n",
+                z[Z_TRIPS], z[Z_INNER_TRIPS], (double) z[Z_INNER_LANES] / std::max(1ull, z[Z_INNER_TRIPS]), z[Z_LEAF_TRIPS],
+                (double) z[Z_LEAF_LANES] / std::max(1ull, z[Z_LEAF_TRIPS]), z[Z_REFILLS], (double) z[Z_REFILL_LANES] / std::max(1ull, z[Z_REFILLS]));
+    }
     return std::string();
 }
 
