@@ -10,7 +10,7 @@ struct LbvhDeviceResult {
     f4 *d_nodes = nullptr;     /* hipMalloc'ed; ownership passes to the caller */
     f4 *d_tris = nullptr;
     int32_t root = 0;
-    uint32_t n_nodes = 0, n_leaves = 0, max_depth = 0;
+    uint32_t n_nodes = 0, n_leaves = 0, max_depth = 0, n_pairs = 0;
     float build_ms = 0.0f;
 };
 

@@ -22,7 +22,7 @@
  *                       inter-workgroup visibility hazards
  *   6. k_emit_nodes     64-B two-child-box node records; a child covering <= 4
  *                       triangles becomes a leaf (contiguous in sorted order)
- *   7. k_emit_tris      48-B de-indexed leaf triangle records in sorted order
+ *   7. k_mark_leaves / scan / k_emit_pairs   96-B de-indexed triangle-pair records, leaf by leaf
  *   8. k_depth          longest root-to-leaf chain (sizes the LDS stack)
  *
  * Any valid BVH returns the same hits as the linear scan (conservative node
@@ -178,23 +178,40 @@ __device__ __forceinline__ void range_box(const f4 *tmin, const f4 *tmax, uint32
     }
 }
 
-__device__ __forceinline__ int32_t child_link(const RadixNode *nodes, uint32_t child, uint32_t &lo, uint32_t &hi) {
-    if (child & kLeafBit) {
-        lo = hi = child & ~kLeafBit;
-        return (int32_t) ~((lo << 3) | 0u);
-    }
+/* A child of a reachable inner node is a leaf when it is a single primitive or a subtree of <= 4
+   triangles (contiguous in sorted order).  Leaves store their triangles in pairs (rt_types.h); the
+   first pair of the leaf starting at sorted position lo is pair_start[lo] (exclusive scan of the
+   per-leaf pair counts). */
+__device__ __forceinline__ bool child_range(const RadixNode *nodes, uint32_t child, uint32_t &lo, uint32_t &hi) {
+    if (child & kLeafBit) { lo = hi = child & ~kLeafBit; return true; }
     lo = nodes[child].lo; hi = nodes[child].hi;
-    const uint32_t cnt = hi - lo + 1;
-    if (cnt <= 4u) return (int32_t) ~((lo << 3) | (cnt - 1u));
-    return (int32_t) child;
+    return hi - lo + 1 <= 4u;
 }
 
-__global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N, f4 *out) {
+__device__ __forceinline__ int32_t child_link(const RadixNode *nodes, const uint32_t *pair_start, uint32_t child, uint32_t &lo, uint32_t &hi) {
+    if (!child_range(nodes, child, lo, hi)) return (int32_t) child;
+    const uint32_t cnt = hi - lo + 1;
+    return (int32_t) ~((pair_start[lo] << 3) | ((cnt + 1u) / 2u - 1u));
+}
+
+/* leaf_cnt[lo] = triangles of the leaf that starts at sorted position lo, leaf_pairs[lo] = its pairs */
+__global__ void k_mark_leaves(const RadixNode *nodes, uint32_t n_inner, uint32_t *leaf_cnt, uint32_t *leaf_pairs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    const RadixNode nd = nodes[i];
+    if (nd.hi - nd.lo + 1 <= 4u) return;          /* inside a collapsed subtree: unreachable */
+    uint32_t lo, hi;
+    if (child_range(nodes, nd.left, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
+    if (child_range(nodes, nd.right, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
+}
+
+__global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N,
+                             const uint32_t *pair_start, f4 *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_inner) return;
     const RadixNode nd = nodes[i];
     uint32_t llo, lhi, rlo, rhi;
-    const int32_t cl = child_link(nodes, nd.left, llo, lhi), cr = child_link(nodes, nd.right, rlo, rhi);
+    const int32_t cl = child_link(nodes, pair_start, nd.left, llo, lhi), cr = child_link(nodes, pair_start, nd.right, rlo, rhi);
     f3 lmn, lmx, rmn, rmx;
     range_box(tmin, tmax, N, llo, lhi, lmn, lmx);
     range_box(tmin, tmax, N, rlo, rhi, rmn, rmx);
@@ -205,18 +222,30 @@ __global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 
     dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
 }
 
-__global__ void k_emit_tris(const f4 *pos, const uint32_t *idx, const uint32_t *tri_mesh, const uint32_t *order, uint32_t n, f4 *out) {
+/* one thread per leaf start: the leaf's triangles, de-indexed, as pair records */
+__global__ void k_emit_pairs(const f4 *pos, const uint32_t *idx, const uint32_t *tri_mesh, const uint32_t *order, uint32_t n,
+                             const uint32_t *leaf_cnt, const uint32_t *pair_start, f4 *out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    const uint32_t g = order[k];
-    const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
-    const f3 e1 = p1 - p0, e2 = p2 - p0;      /* the subtraction mesh.cpp:43 performs per ray */
-    f4 a, b, c;
-    a.x = p0.x; a.y = p0.y; a.z = p0.z; a.w = e1.x;
-    b.x = e1.y; b.y = e1.z; b.z = e2.x; b.w = e2.y;
-    c.x = e2.z; c.y = __uint_as_float(g); c.z = __uint_as_float(tri_mesh[g]); c.w = 0.0f;
-    f4 *q = out + (size_t) k * kTriQuads;
-    q[0] = a; q[1] = b; q[2] = c;
+    const uint32_t cnt = leaf_cnt[k];
+    if (cnt == 0u) return;
+    for (uint32_t t = 0; t < ((cnt + 1u) / 2u) * 2u; ++t) {
+        f4 q[kPairQuads];
+        f4 *dst = out + (size_t) (pair_start[k] + t / 2u) * kPairQuads;
+        if ((t & 1u) == 0u) for (int j = 0; j < kPairQuads; ++j) q[j].x = q[j].y = q[j].z = q[j].w = 0.0f;
+        else for (int j = 0; j < kPairQuads; ++j) q[j] = dst[j];
+        if (t < cnt) {
+            const uint32_t g = order[k + t];
+            const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
+            const f3 e1 = p1 - p0, e2 = p2 - p0;      /* the subtraction mesh.cpp:43 performs per ray */
+            const float a0[3] = {p0.x, p0.y, p0.z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
+            pair_pack(q, (int) (t & 1u), a0, a1, a2, g, tri_mesh[g]);
+        } else {
+            const float z[3] = {0.0f, 0.0f, 0.0f};
+            pair_pack(q, (int) (t & 1u), z, z, z, kNoTriangle, kNoTriangle);
+        }
+        for (int j = 0; j < kPairQuads; ++j) dst[j] = q[j];
+    }
 }
 
 __global__ void k_depth(const uint32_t *parent_inner, const uint32_t *parent_leaf, uint32_t n, unsigned int *max_depth) {
@@ -279,23 +308,47 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     const unsigned long long *keys = keys_b.as<unsigned long long>();
     const uint32_t *order = vals_b.as<uint32_t>();      /* sorted position -> global triangle */
 
+    /* leaves: start positions, triangle counts, pair counts -> first pair of every leaf */
+    Buf leaf_cnt, leaf_pairs, pair_start, rnodes, pin, plf;
+    LB_TRY(leaf_cnt.alloc((size_t) n * 4)); LB_TRY(leaf_pairs.alloc((size_t) n * 4)); LB_TRY(pair_start.alloc((size_t) n * 4));
+    LB_TRY(hipMemset(leaf_cnt.p, 0, (size_t) n * 4)); LB_TRY(hipMemset(leaf_pairs.p, 0, (size_t) n * 4));
+    if (n <= 4) {
+        const uint32_t one[2] = {n, (n + 1) / 2};
+        LB_TRY(hipMemcpy(leaf_cnt.p, &one[0], 4, hipMemcpyHostToDevice));
+        LB_TRY(hipMemcpy(leaf_pairs.p, &one[1], 4, hipMemcpyHostToDevice));
+    } else {
+        /* 4. radix tree */
+        LB_TRY(rnodes.alloc((size_t) (n - 1) * sizeof(RadixNode)));
+        LB_TRY(pin.alloc((size_t) n * 4)); LB_TRY(plf.alloc((size_t) n * 4));
+        hipLaunchKernelGGL(k_hierarchy, dim3(gridN), dim3(B), 0, 0, keys, (int) n, rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());
+        hipLaunchKernelGGL(k_mark_leaves, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, leaf_cnt.as<uint32_t>(), leaf_pairs.as<uint32_t>());
+    }
+    {
+        size_t scan_bytes = 0;
+        LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, leaf_pairs.as<uint32_t>(), pair_start.as<uint32_t>(), (int) n));
+        Buf scan_tmp; LB_TRY(scan_tmp.alloc(scan_bytes));
+        LB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, leaf_pairs.as<uint32_t>(), pair_start.as<uint32_t>(), (int) n));
+    }
+    uint32_t last[2] = {0, 0};
+    LB_TRY(hipMemcpy(&last[0], pair_start.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost));
+    LB_TRY(hipMemcpy(&last[1], leaf_pairs.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost));
+    const uint32_t n_pairs = last[0] + last[1];
+    out.n_pairs = n_pairs;
+
+    /* 7. pair records */
     f4 *d_tris = nullptr;
-    LB_TRY(hipMalloc((void **) &d_tris, (size_t) n * kTriQuads * sizeof(f4)));
+    LB_TRY(hipMalloc((void **) &d_tris, (size_t) std::max<uint32_t>(n_pairs, 1) * kPairQuads * sizeof(f4)));
     out.d_tris = d_tris;
-    hipLaunchKernelGGL(k_emit_tris, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, d_tri_mesh, order, n, d_tris);
+    hipLaunchKernelGGL(k_emit_pairs, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, d_tri_mesh, order, n,
+                       leaf_cnt.as<uint32_t>(), pair_start.as<uint32_t>(), d_tris);
 
     if (n <= 4) {
         f4 *d_nodes = nullptr;
         LB_TRY(hipMalloc((void **) &d_nodes, kNodeQuads * sizeof(f4)));
         LB_TRY(hipMemset(d_nodes, 0, kNodeQuads * sizeof(f4)));
-        out.d_nodes = d_nodes; out.root = (int32_t) ~((0u << 3) | (n - 1u));
+        out.d_nodes = d_nodes; out.root = (int32_t) ~((0u << 3) | ((n + 1u) / 2u - 1u));
         out.n_nodes = 0; out.n_leaves = 1; out.max_depth = 0;
     } else {
-        /* 4. radix tree */
-        Buf rnodes, pin, plf;
-        LB_TRY(rnodes.alloc((size_t) (n - 1) * sizeof(RadixNode)));
-        LB_TRY(pin.alloc((size_t) n * 4)); LB_TRY(plf.alloc((size_t) n * 4));
-        hipLaunchKernelGGL(k_hierarchy, dim3(gridN), dim3(B), 0, 0, keys, (int) n, rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());
         /* 5. segment tree of boxes */
         uint32_t N = 1; while (N < n) N <<= 1;
         Buf tmin, tmax;
@@ -309,7 +362,8 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         f4 *d_nodes = nullptr;
         LB_TRY(hipMalloc((void **) &d_nodes, (size_t) (n - 1) * kNodeQuads * sizeof(f4)));
         out.d_nodes = d_nodes;
-        hipLaunchKernelGGL(k_emit_nodes, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, tmin.as<f4>(), tmax.as<f4>(), N, d_nodes);
+        hipLaunchKernelGGL(k_emit_nodes, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, tmin.as<f4>(), tmax.as<f4>(), N,
+                           pair_start.as<uint32_t>(), d_nodes);
         /* 8. depth */
         Buf md; LB_TRY(md.alloc(4)); LB_TRY(hipMemset(md.p, 0, 4));
         hipLaunchKernelGGL(k_depth, dim3(gridN), dim3(B), 0, 0, pin.as<uint32_t>(), plf.as<uint32_t>(), n, md.as<unsigned int>());

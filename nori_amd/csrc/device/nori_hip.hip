@@ -472,7 +472,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
         ctx->bvh.root = res.root; ctx->bvh.n_nodes = res.n_nodes; ctx->bvh.n_leaves = res.n_leaves;
         ctx->bvh.max_depth = res.max_depth; ctx->bvh.build_ms = res.build_ms; ctx->bvh.sah_cost = 0.0f;
         ctx->dev.nodes = res.d_nodes; ctx->dev.tris = res.d_tris;
-        ctx->lbvh_bytes = (uint64_t) std::max<uint32_t>(res.n_nodes, 1) * kNodeQuads * 16 + (uint64_t) ctx->dev.n_triangles * kTriQuads * 16;
+        ctx->lbvh_bytes = (uint64_t) std::max<uint32_t>(res.n_nodes, 1) * kNodeQuads * 16 + (uint64_t) res.n_pairs * kPairQuads * 16;
     } else {
         std::string err = build_bvh_sah(ctx->host, 64, ctx->bvh);
         if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
@@ -485,7 +485,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     ctx->stack_depth = ctx->bvh.max_depth + 1 <= 32 ? 32 : 64;
     nori_accel_info &in = ctx->info;
     in.n_triangles = ctx->dev.n_triangles; in.n_nodes = ctx->bvh.n_nodes; in.n_leaves = ctx->bvh.n_leaves;
-    in.max_depth = ctx->bvh.max_depth; in.node_bytes = kNodeQuads * 16; in.tri_bytes = kTriQuads * 16;
+    in.max_depth = ctx->bvh.max_depth; in.node_bytes = kNodeQuads * 16; in.tri_bytes = kPairQuads * 16 / 2;
     in.total_bytes = ctx->lbvh_bytes ? ctx->lbvh_bytes : (uint64_t) ctx->bvh.nodes.size() * 16 + (uint64_t) ctx->bvh.tris.size() * 16;
     in.build_ms = ctx->bvh.build_ms; in.sah_cost = ctx->bvh.sah_cost;
     ctx->have_accel = true;

@@ -137,25 +137,67 @@ NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, Travers
     }
 }
 
-/* one leaf step: ONE triangle (mesh.cpp:39-76), then advance within the leaf */
+/* Moeller-Trumbore (src/mesh.cpp:39-76) on TWO triangles at once: every quantity is a 2-wide vector
+ * (triangle a, triangle b), so the ~60 multiplies / adds of the test run as packed-f32 instructions --
+ * two triangles for the issue slots of one.  Each lane of the vector performs the scalar test's
+ * operations in the scalar test's order (element-wise IEEE): same bits as tri_test. */
+struct TriPairHit { v2f u, v, t; bool ok[2]; };
+
+NORI_HD v2f splat2(float x) { const v2f r = {x, x}; return r; }
+
+NORI_HD void tri_pair_test(const f4 &q0, const f4 &q1, const f4 &q2, const f4 &q3, const f4 &q4, f3 o, f3 d,
+                           float mint, float maxt, TriPairHit &r) {
+    const v2f p0x = {q0.x, q0.y}, p0y = {q0.z, q0.w}, p0z = {q1.x, q1.y};
+    const v2f e1x = {q1.z, q1.w}, e1y = {q2.x, q2.y}, e1z = {q2.z, q2.w};
+    const v2f e2x = {q3.x, q3.y}, e2y = {q3.z, q3.w}, e2z = {q4.x, q4.y};
+    const v2f dx = splat2(d.x), dy = splat2(d.y), dz = splat2(d.z);
+    /* pvec = cross(d, edge2); det = dot(edge1, pvec) */
+    const v2f pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
+    const v2f det = e1x * pvx + (e1y * pvy + e1z * pvz);
+    v2f inv;
+    inv[0] = 1.0f / det[0]; inv[1] = 1.0f / det[1];
+    /* tvec = o - p0; u = dot(tvec, pvec) * inv_det */
+    const v2f tx = splat2(o.x) - p0x, ty = splat2(o.y) - p0y, tz = splat2(o.z) - p0z;
+    r.u = (tx * pvx + (ty * pvy + tz * pvz)) * inv;
+    /* qvec = cross(tvec, edge1); v = dot(d, qvec) * inv_det; t = dot(edge2, qvec) * inv_det */
+    const v2f qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+    r.v = (dx * qx + (dy * qy + dz * qz)) * inv;
+    r.t = (e2x * qx + (e2y * qy + e2z * qz)) * inv;
+    for (int k = 0; k < 2; ++k) {
+        const float dk = det[k], uk = r.u[k], vk = r.v[k], tk = r.t[k];
+        r.ok[k] = !(dk > -1e-8f && dk < 1e-8f) && !(uk < 0.0f || uk > 1.0f) && !(vk < 0.0f || uk + vk > 1.0f) &&
+                  tk >= mint && tk <= maxt;
+    }
+}
+
+/* one leaf step: ONE PAIR of triangles, then advance within the leaf */
 template <bool COUNT, class Stack>
 NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt) {
     const uint32_t cursor = ~(uint32_t) tv.node;
-    const f4 *tq = sc.tris + (size_t) (cursor >> 3) * kTriQuads;
-    const f4 a = tq[0], b = tq[1], c = tq[2];
-    if (COUNT) cnt.tris++;
-    float u, v, t;
-    if (tri_test(mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), tv.o, tv.d, u, v, t) &&
-        t >= tv.mint && t <= tv.hit.t) {
-        const uint32_t gid = f2u(c.y);
-        if (tv.any) { tv.hit.tri = gid; tv.hit.t = t; tv.node = kTravDone; return; }
-        /* tie rule of the linear scan: a later triangle with equal t replaces an earlier one */
-        if (!(t == tv.hit.t && tv.hit.tri != kNoHit && gid < tv.hit.tri)) {
-            tv.hit.t = t; tv.hit.u = u; tv.hit.v = v; tv.hit.tri = gid; tv.hit.mesh = f2u(c.z);
+    const f4 *tq = sc.tris + (size_t) (cursor >> 3) * kPairQuads;
+    const f4 q0 = tq[0], q1 = tq[1], q2 = tq[2], q3 = tq[3], q4 = tq[4];
+    if (COUNT) cnt.tris += 2;
+    TriPairHit r;
+    tri_pair_test(q0, q1, q2, q3, q4, tv.o, tv.d, tv.mint, tv.hit.t, r);
+    if (r.ok[0] || r.ok[1]) {
+        const f4 q5 = tq[5];
+        if (tv.any) {
+            const int k = r.ok[0] ? 0 : 1;
+            tv.hit.tri = f2u(k == 0 ? q4.z : q4.w); tv.hit.t = r.t[k]; tv.node = kTravDone;
+            return;
+        }
+        /* candidates in order a, b; tie rule of the linear scan: a later triangle (larger global id) with
+           equal t replaces an earlier one */
+        for (int k = 0; k < 2; ++k) {
+            const float t = r.t[k];
+            const uint32_t gid = f2u(k == 0 ? q4.z : q4.w);
+            if (r.ok[k] && t <= tv.hit.t && !(t == tv.hit.t && tv.hit.tri != kNoHit && gid < tv.hit.tri)) {
+                tv.hit.t = t; tv.hit.u = r.u[k]; tv.hit.v = r.v[k]; tv.hit.tri = gid; tv.hit.mesh = f2u(k == 0 ? q5.x : q5.y);
+            }
         }
     }
     if ((cursor & 7u) == 0u) trav_pop(stack, tv);
-    else tv.node = (int) ~(cursor + 7u);          /* next triangle, one fewer left */
+    else tv.node = (int) ~(cursor + 7u);          /* next pair, one fewer left */
 }
 
 /* Run a traversal to completion (batch kernels, tests).

@@ -108,15 +108,29 @@ NORI_HD void node_pack(const float lmn[3], const float lmx[3], const float rmn[3
     q[2].x = lmn[2]; q[2].y = lmx[2]; q[2].z = rmn[2]; q[2].w = rmx[2];
     q[3].x = u2f((uint32_t) left); q[3].y = u2f((uint32_t) right); q[3].z = 0.0f; q[3].w = 0.0f;
 }
-constexpr int kMaxLeafTris = 8;
+constexpr int kMaxLeafTris = 8;      /* = 4 pairs */
 
-/* One leaf triangle = 48 B = 3 x dwordx4, de-indexed and pre-gathered in leaf
- * order so a leaf test is one contiguous read:
- *   q0 = (p0.x, p0.y, p0.z, e1.x)   e1 = p1 - p0, e2 = p2 - p0 (same IEEE
- *   q1 = (e1.y, e1.z, e2.x, e2.y)   subtraction mesh.cpp:43 performs per ray)
- *   q2 = (e2.z, bits global_tri, bits mesh, 0)
+/* Leaf triangles are stored in PAIRS, 96 B = 6 x dwordx4 per pair, de-indexed and pre-gathered in leaf
+ * order, so that one leaf step is one contiguous read and tests two triangles (a, b) with packed-f32
+ * math (rt_trace.h, tri_pair_test).  e1 = p1 - p0, e2 = p2 - p0: the IEEE subtraction mesh.cpp:43
+ * performs per ray.
+ *   q0 = (p0.x a, p0.x b, p0.y a, p0.y b)     q3 = (e2.x a, e2.x b, e2.y a, e2.y b)
+ *   q1 = (p0.z a, p0.z b, e1.x a, e1.x b)     q4 = (e2.z a, e2.z b, bits global_tri a, bits global_tri b)
+ *   q2 = (e1.y a, e1.y b, e1.z a, e1.z b)     q5 = (bits mesh a, bits mesh b, 0, 0)
+ * A leaf with an odd number of triangles pads its last pair with an all-zero triangle (det = 0: never
+ * hit) whose global id is kNoHit.  Leaf link: ~link = (first_pair << 3) | (n_pairs - 1).
  */
-constexpr int kTriQuads = 3;
+constexpr int kPairQuads = 6;
+constexpr uint32_t kNoTriangle = 0xffffffffu;
+
+/* slot k (0 = a, 1 = b) of a pair record */
+NORI_HD void pair_pack(f4 q[6], int k, const float p0[3], const float e1[3], const float e2[3], uint32_t gid, uint32_t mesh) {
+    float *f = &q[0].x;      /* 24 consecutive floats */
+    f[0 + k] = p0[0]; f[2 + k] = p0[1]; f[4 + k] = p0[2];
+    f[6 + k] = e1[0]; f[8 + k] = e1[1]; f[10 + k] = e1[2];
+    f[12 + k] = e2[0]; f[14 + k] = e2[1]; f[16 + k] = e2[2];
+    f[18 + k] = u2f(gid); f[20 + k] = u2f(mesh);
+}
 
 /* Shading record of one global triangle = 96 B = 6 x dwordx4: what accel.cpp:58-95 fetches through
  * the index buffer after the closest hit is known (and what the area light samples), gathered once

@@ -226,9 +226,9 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
     const uint32_t n = (uint32_t) sc.tri_mesh.size();
     if (n == 0) {
         /* traversal returns before touching nodes when there are no triangles */
-        out.nodes.resize(kNodeQuads); out.tris.resize(kTriQuads);
+        out.nodes.resize(kNodeQuads); out.tris.resize(kPairQuads);
         std::memset(out.nodes.data(), 0, sizeof(f4) * kNodeQuads);
-        std::memset(out.tris.data(), 0, sizeof(f4) * kTriQuads);
+        std::memset(out.tris.data(), 0, sizeof(f4) * kPairQuads);
         out.root = 0; out.n_nodes = 1;
         return std::string();
     }
@@ -335,23 +335,37 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
         todo.push_back((uint32_t) r); todo.push_back((uint32_t) l);
     }
 
-    /* leaf triangle records, in prim order */
-    out.tris.resize((size_t) n * kTriQuads);
-    for (uint32_t i = 0; i < n; ++i) {
-        const uint32_t g = prim[i];
-        const uint32_t *id = &sc.indices[3 * (size_t) g];
-        const f3 p0 = xyz(sc.positions[id[0]]), p1 = xyz(sc.positions[id[1]]), p2 = xyz(sc.positions[id[2]]);
-        const f3 e1 = p1 - p0, e2 = p2 - p0;
-        f4 *q = &out.tris[(size_t) i * kTriQuads];
-        q[0].x = p0.x; q[0].y = p0.y; q[0].z = p0.z; q[0].w = e1.x;
-        q[1].x = e1.y; q[1].y = e1.z; q[1].z = e2.x; q[1].w = e2.y;
-        q[2].x = e2.z; q[2].y = u2f(g); q[2].z = u2f(sc.tri_mesh[g]); q[2].w = 0.0f;
+    /* leaf triangle records: pairs, leaf by leaf in prim order (rt_types.h) */
+    auto isLeaf = [&](int32_t b) { return bn[b].left < 0; };
+    std::vector<uint32_t> firstPair(bn.size(), 0);
+    {
+        std::vector<int32_t> leaves;
+        for (size_t b = 0; b < bn.size(); ++b) if (isLeaf((int32_t) b)) leaves.push_back((int32_t) b);
+        std::sort(leaves.begin(), leaves.end(), [&](int32_t a, int32_t b) { return bn[a].first < bn[b].first; });
+        uint32_t nPairs = 0;
+        for (int32_t b : leaves) { firstPair[b] = nPairs; nPairs += (bn[b].count + 1) / 2; }
+        out.tris.assign((size_t) std::max<uint32_t>(nPairs, 1) * kPairQuads, f4{0.0f, 0.0f, 0.0f, 0.0f});
+        for (int32_t b : leaves)
+            for (uint32_t k = 0; k < ((bn[b].count + 1) / 2) * 2; ++k) {
+                f4 *q = &out.tris[(size_t) (firstPair[b] + k / 2) * kPairQuads];
+                if (k >= bn[b].count) {      /* padding: all-zero triangle, never hit */
+                    const float z[3] = {0.0f, 0.0f, 0.0f};
+                    pair_pack(q, (int) (k & 1u), z, z, z, kNoTriangle, kNoTriangle);
+                    continue;
+                }
+                const uint32_t g = prim[bn[b].first + k];
+                const uint32_t *id = &sc.indices[3 * (size_t) g];
+                const f3 p0 = xyz(sc.positions[id[0]]), p1 = xyz(sc.positions[id[1]]), p2 = xyz(sc.positions[id[2]]);
+                const f3 e1 = p1 - p0, e2 = p2 - p0;
+                const float a0[3] = {p0.x, p0.y, p0.z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
+                pair_pack(q, (int) (k & 1u), a0, a1, a2, g, sc.tri_mesh[g]);
+            }
+        out.n_pairs = nPairs;
     }
 
     /* flatten: one device node per inner build node, DFS pre-order */
-    auto isLeaf = [&](int32_t b) { return bn[b].left < 0; };
     auto leafCode = [&](int32_t b) -> int32_t {
-        return (int32_t) ~((bn[b].first << 3) | (bn[b].count - 1));
+        return (int32_t) ~((firstPair[b] << 3) | ((bn[b].count + 1) / 2 - 1));
     };
     for (size_t b = 0; b < bn.size(); ++b)
         if (isLeaf((int32_t) b) && bn[b].count > (uint32_t) kMaxLeafTris) return "internal: leaf exceeds kMaxLeafTris";

@@ -30,7 +30,8 @@ struct HostScene {
 
 struct HostBvh {
     std::vector<f4> nodes;              /* kNodeQuads per node   */
-    std::vector<f4> tris;               /* kTriQuads per triangle, leaf order */
+    std::vector<f4> tris;               /* kPairQuads per triangle pair, leaf order */
+    uint32_t n_pairs = 0;
     int32_t root = 0;
     uint32_t n_nodes = 0, n_leaves = 0, max_depth = 0;
     float sah_cost = 0.0f;

@@ -103,7 +103,7 @@ void emu_destroy(emu_ctx *c) { delete c; }
 int emu_accel_info(const emu_ctx *c, nori_accel_info *in) {
     std::memset(in, 0, sizeof(*in));
     in->n_triangles = c->dev.n_triangles; in->n_nodes = c->bvh.n_nodes; in->n_leaves = c->bvh.n_leaves;
-    in->max_depth = c->bvh.max_depth; in->node_bytes = kNodeQuads * 16; in->tri_bytes = kTriQuads * 16;
+    in->max_depth = c->bvh.max_depth; in->node_bytes = kNodeQuads * 16; in->tri_bytes = kPairQuads * 16 / 2;
     in->total_bytes = (uint64_t) (c->bvh.nodes.size() + c->bvh.tris.size()) * 16;
     in->build_ms = c->bvh.build_ms; in->sah_cost = c->bvh.sah_cost;
     return NORI_OK;
