@@ -213,7 +213,7 @@ struct BuildNode {
 };
 
 constexpr int kBins = 32;
-constexpr uint32_t kLeafTarget = 4;
+static uint32_t kLeafTarget = 4;      /* NORI_HIP_SAH_LEAF overrides (experiments) */
 constexpr float kCostNode = 1.0f;
 static float kCostTri = 1.0f;      /* relative cost of one triangle test; NORI_HIP_SAH_TRI_COST overrides (experiments) */
 
@@ -221,6 +221,7 @@ static float kCostTri = 1.0f;      /* relative cost of one triangle test; NORI_H
 
 std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh &out) {
     if (const char *e = std::getenv("NORI_HIP_SAH_TRI_COST")) kCostTri = std::max(0.1f, (float) std::atof(e));
+    if (const char *e = std::getenv("NORI_HIP_SAH_LEAF")) kLeafTarget = (uint32_t) std::min(kMaxLeafTris, std::max(1, std::atoi(e)));
     const auto t0 = std::chrono::steady_clock::now();
     out = HostBvh();
     const uint32_t n = (uint32_t) sc.tri_mesh.size();
