@@ -188,17 +188,19 @@ __device__ __forceinline__ bool child_range(const RadixNode *nodes, uint32_t chi
     return hi - lo + 1 <= 4u;
 }
 
-__device__ __forceinline__ int32_t child_link(const RadixNode *nodes, const uint32_t *pair_start, uint32_t child, uint32_t &lo, uint32_t &hi) {
-    if (!child_range(nodes, child, lo, hi)) return (int32_t) child;
+__device__ __forceinline__ int32_t child_link(const RadixNode *nodes, const uint32_t *pair_start, const uint32_t *node_index, uint32_t child, uint32_t &lo, uint32_t &hi) {
+    if (!child_range(nodes, child, lo, hi)) return (int32_t) node_index[child];
     const uint32_t cnt = hi - lo + 1;
     return (int32_t) ~((pair_start[lo] << 3) | ((cnt + 1u) / 2u - 1u));
 }
 
-/* leaf_cnt[lo] = triangles of the leaf that starts at sorted position lo, leaf_pairs[lo] = its pairs */
-__global__ void k_mark_leaves(const RadixNode *nodes, uint32_t n_inner, uint32_t *leaf_cnt, uint32_t *leaf_pairs) {
+/* leaf_cnt[lo] = triangles of the leaf that starts at sorted position lo, leaf_pairs[lo] = its pairs;
+   keep[i] = 1 for the radix nodes that survive as BVH nodes (the others sit inside collapsed subtrees) */
+__global__ void k_mark_leaves(const RadixNode *nodes, uint32_t n_inner, uint32_t *leaf_cnt, uint32_t *leaf_pairs, uint32_t *keep) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_inner) return;
     const RadixNode nd = nodes[i];
+    keep[i] = nd.hi - nd.lo + 1 > 4u ? 1u : 0u;
     if (nd.hi - nd.lo + 1 <= 4u) return;          /* inside a collapsed subtree: unreachable */
     uint32_t lo, hi;
     if (child_range(nodes, nd.left, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
@@ -206,19 +208,19 @@ __global__ void k_mark_leaves(const RadixNode *nodes, uint32_t n_inner, uint32_t
 }
 
 __global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N,
-                             const uint32_t *pair_start, f4 *out) {
+                             const uint32_t *pair_start, const uint32_t *keep, const uint32_t *node_index, f4 *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_inner) return;
+    if (i >= n_inner || !keep[i]) return;
     const RadixNode nd = nodes[i];
     uint32_t llo, lhi, rlo, rhi;
-    const int32_t cl = child_link(nodes, pair_start, nd.left, llo, lhi), cr = child_link(nodes, pair_start, nd.right, rlo, rhi);
+    const int32_t cl = child_link(nodes, pair_start, node_index, nd.left, llo, lhi), cr = child_link(nodes, pair_start, node_index, nd.right, rlo, rhi);
     f3 lmn, lmx, rmn, rmx;
     range_box(tmin, tmax, N, llo, lhi, lmn, lmx);
     range_box(tmin, tmax, N, rlo, rhi, rmn, rmx);
     const float a0[3] = {lmn.x, lmn.y, lmn.z}, a1[3] = {lmx.x, lmx.y, lmx.z}, b0[3] = {rmn.x, rmn.y, rmn.z}, b1[3] = {rmx.x, rmx.y, rmx.z};
     f4 q[4];
     node_pack(a0, a1, b0, b1, cl, cr, q);
-    f4 *dst = out + (size_t) i * kNodeQuads;
+    f4 *dst = out + (size_t) node_index[i] * kNodeQuads;      /* dense: only the surviving nodes, in radix-tree order */
     dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
 }
 
@@ -309,7 +311,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     const uint32_t *order = vals_b.as<uint32_t>();      /* sorted position -> global triangle */
 
     /* leaves: start positions, triangle counts, pair counts -> first pair of every leaf */
-    Buf leaf_cnt, leaf_pairs, pair_start, rnodes, pin, plf;
+    Buf leaf_cnt, leaf_pairs, pair_start, rnodes, pin, plf, keep, node_index;
     LB_TRY(leaf_cnt.alloc((size_t) n * 4)); LB_TRY(leaf_pairs.alloc((size_t) n * 4)); LB_TRY(pair_start.alloc((size_t) n * 4));
     LB_TRY(hipMemset(leaf_cnt.p, 0, (size_t) n * 4)); LB_TRY(hipMemset(leaf_pairs.p, 0, (size_t) n * 4));
     if (n <= 4) {
@@ -321,7 +323,9 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         LB_TRY(rnodes.alloc((size_t) (n - 1) * sizeof(RadixNode)));
         LB_TRY(pin.alloc((size_t) n * 4)); LB_TRY(plf.alloc((size_t) n * 4));
         hipLaunchKernelGGL(k_hierarchy, dim3(gridN), dim3(B), 0, 0, keys, (int) n, rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());
-        hipLaunchKernelGGL(k_mark_leaves, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, leaf_cnt.as<uint32_t>(), leaf_pairs.as<uint32_t>());
+        LB_TRY(keep.alloc((size_t) n * 4)); LB_TRY(node_index.alloc((size_t) n * 4));
+        hipLaunchKernelGGL(k_mark_leaves, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, leaf_cnt.as<uint32_t>(), leaf_pairs.as<uint32_t>(),
+                           keep.as<uint32_t>());
     }
     {
         size_t scan_bytes = 0;
@@ -358,18 +362,29 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
             hipLaunchKernelGGL(k_tree_level, dim3((first + B - 1) / B), dim3(B), 0, 0, first, first, tmin.as<f4>(), tmax.as<f4>());
             if (first == 1) break;
         }
-        /* 6. nodes */
+        /* 6. nodes: the radix nodes that are not inside a collapsed subtree, renumbered densely (root stays 0) */
+        uint32_t n_nodes = 0;
+        {
+            size_t scan_bytes = 0;
+            LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, keep.as<uint32_t>(), node_index.as<uint32_t>(), (int) (n - 1)));
+            Buf scan_tmp; LB_TRY(scan_tmp.alloc(scan_bytes));
+            LB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, keep.as<uint32_t>(), node_index.as<uint32_t>(), (int) (n - 1)));
+            uint32_t tail[2] = {0, 0};
+            LB_TRY(hipMemcpy(&tail[0], node_index.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost));
+            LB_TRY(hipMemcpy(&tail[1], keep.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost));
+            n_nodes = tail[0] + tail[1];
+        }
         f4 *d_nodes = nullptr;
-        LB_TRY(hipMalloc((void **) &d_nodes, (size_t) (n - 1) * kNodeQuads * sizeof(f4)));
+        LB_TRY(hipMalloc((void **) &d_nodes, (size_t) std::max<uint32_t>(n_nodes, 1) * kNodeQuads * sizeof(f4)));
         out.d_nodes = d_nodes;
         hipLaunchKernelGGL(k_emit_nodes, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, tmin.as<f4>(), tmax.as<f4>(), N,
-                           pair_start.as<uint32_t>(), d_nodes);
+                           pair_start.as<uint32_t>(), keep.as<uint32_t>(), node_index.as<uint32_t>(), d_nodes);
         /* 8. depth */
         Buf md; LB_TRY(md.alloc(4)); LB_TRY(hipMemset(md.p, 0, 4));
         hipLaunchKernelGGL(k_depth, dim3(gridN), dim3(B), 0, 0, pin.as<uint32_t>(), plf.as<uint32_t>(), n, md.as<unsigned int>());
         unsigned int depth = 0;
         LB_TRY(hipMemcpy(&depth, md.p, 4, hipMemcpyDeviceToHost));
-        out.root = 0; out.n_nodes = n - 1; out.n_leaves = 0; out.max_depth = depth;
+        out.root = 0; out.n_nodes = n_nodes; out.n_leaves = 0; out.max_depth = depth;
         LB_TRY(hipGetLastError());
     }
     LB_TRY(hipEventRecord(e1, 0));
