@@ -140,13 +140,18 @@ __global__ void k_hierarchy(const unsigned long long *keys, int n, RadixNode *no
 }
 
 /* segment tree over the sorted, padded triangle boxes: entries [N + k] */
-__global__ void k_leaf_boxes(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, uint32_t N, float pad,
-                             f4 *tmin, f4 *tmax) {
+__global__ void k_leaf_boxes(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, uint32_t N, float pad0,
+                             f3 smin, f3 smax, f4 *tmin, f4 *tmax) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     f4 mn4, mx4;
     if (k < n) {
-        f3 mn, mx; tri_box(pos, idx, order[k], mn, mx);
+        const uint32_t g = order[k];
+        f3 mn, mx; tri_box(pos, idx, g, mn, mx);
+        const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
+        bool unbounded;
+        const float pad = tri_box_pad(p1 - p0, p2 - p0, pad0, unbounded);      /* slivers: rt_types.h */
+        if (unbounded) { mn = smin; mx = smax; }
         mn4.x = mn.x - pad; mn4.y = mn.y - pad; mn4.z = mn.z - pad; mx4.x = mx.x + pad; mx4.y = mx.y + pad; mx4.z = mx.z + pad;
     } else {
         mn4.x = mn4.y = mn4.z = kInf; mx4.x = mx4.y = mx4.z = -kInf;
@@ -357,7 +362,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         uint32_t N = 1; while (N < n) N <<= 1;
         Buf tmin, tmax;
         LB_TRY(tmin.alloc((size_t) 2 * N * sizeof(f4))); LB_TRY(tmax.alloc((size_t) 2 * N * sizeof(f4)));
-        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, order, n, N, pad, tmin.as<f4>(), tmax.as<f4>());
+        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, order, n, N, pad, smin, smax, tmin.as<f4>(), tmax.as<f4>());
         for (uint32_t first = N >> 1; first >= 1; first >>= 1) {
             hipLaunchKernelGGL(k_tree_level, dim3((first + B - 1) / B), dim3(B), 0, 0, first, first, tmin.as<f4>(), tmax.as<f4>());
             if (first == 1) break;

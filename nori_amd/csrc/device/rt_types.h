@@ -91,6 +91,25 @@ NORI_HD f3 to_world(const Frame &f, f3 v) { return (f.s * v.x + f.t * v.y) + f.n
 
 /* ------------------------------------------------------------ scene in HBM */
 
+/* Padding of a triangle's box in the BVH builders.  The node test must never cull a triangle whose
+ * Moeller-Trumbore test (src/mesh.cpp:39-76, float arithmetic) would accept the ray.  For a well-shaped
+ * triangle the accepted region exceeds the exact triangle by rounding only, covered by `pad`
+ * (2e-5 x scene diagonal).  The rounding error of det = e1 . (d x e2) is ~2^-23 |e1||e2|, so relative
+ * to det it grows like 1 / sin(angle between the edges): a sliver's accepted region is wider by that
+ * factor, and for (numerically) collinear vertices u, v, t are noise and the reference's linear scan
+ * can report a hit for a ray that passes nowhere near the triangle.  The pad therefore scales with
+ * 1 / sin; below 1e-4 the triangle is given the whole scene as its box (`unbounded`): every ray tests
+ * it, exactly as the scan does.  Triangles with a zero-length edge have det == 0 and are never hit. */
+NORI_HD float tri_box_pad(f3 e1, f3 e2, float pad, bool &unbounded) {
+    unbounded = false;
+    const float l1 = dot(e1, e1), l2 = dot(e2, e2);
+    if (!(l1 > 0.0f) || !(l2 > 0.0f)) return pad;
+    const f3 c = cross(e1, e2);
+    const float s2 = dot(c, c) / (l1 * l2);             /* sin^2 */
+    if (!(s2 >= 1e-8f)) { unbounded = true; return pad; }
+    return s2 >= 1.0f ? pad : pad / sqrtf(s2);
+}
+
 /* One BVH2 node = 64 B = 4 x dwordx4: both child boxes + both child links, so
  * one fetch decides both children.
  *   q0 = (lmin.x, lmin.y, lmax.x, lmax.y)      x/y planes pair up with (o.x, o.y), the z planes of a

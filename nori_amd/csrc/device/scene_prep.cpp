@@ -247,11 +247,17 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
     {
         const float dx = sceneBox.mx[0] - sceneBox.mn[0], dy = sceneBox.mx[1] - sceneBox.mn[1], dz = sceneBox.mx[2] - sceneBox.mn[2];
         const float pad = 2e-5f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f;
-        for (uint32_t t = 0; t < n; ++t)
+        for (uint32_t t = 0; t < n; ++t) {
+            const uint32_t *id = &sc.indices[3 * (size_t) t];
+            const f3 p0 = xyz(sc.positions[id[0]]), p1 = xyz(sc.positions[id[1]]), p2 = xyz(sc.positions[id[2]]);
+            bool unbounded;
+            const float padT = tri_box_pad(p1 - p0, p2 - p0, pad, unbounded);      /* slivers: rt_types.h */
             for (int k = 0; k < 3; ++k) {
-                boxes[t].mn[k] -= pad; boxes[t].mx[k] += pad;
+                if (unbounded) { boxes[t].mn[k] = sceneBox.mn[k]; boxes[t].mx[k] = sceneBox.mx[k]; }
+                boxes[t].mn[k] -= padT; boxes[t].mx[k] += padT;
                 cent[3 * (size_t) t + k] = 0.5f * (boxes[t].mn[k] + boxes[t].mx[k]);
             }
+        }
     }
 
     std::vector<uint32_t> prim(n);

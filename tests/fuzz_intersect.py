@@ -1,0 +1,136 @@
+"""Randomised bit-exactness sweep of Accel::rayIntersect on the device against the oracle's linear scan
+(the reference's algorithm, src/accel.cpp:23-99): many seeds x scene shapes x both BVH builders.
+
+    python tests/fuzz_intersect.py [--seconds 60] [--seed 0]
+
+Scene shapes exercise what the fixed tests do not: odd / even leaf sizes (triangle pairs and their padding),
+duplicated triangles (ties), degenerate triangles, axis-aligned sheets (rays in the plane of a box face),
+coincident centroids (equal Morton codes), huge and tiny coordinate scales, several meshes, rays with
+zero direction components, rays starting on surfaces, finite maxt.  Exits non-zero at the first mismatch.
+`tests/test_gpu_parity.py::test_fuzz_intersect_short` runs a few rounds of it."""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from nori_amd._capi import RAY_DTYPE  # noqa: E402
+from nori_amd.scene import Camera, Integrator, Mesh, RFilter, Scene  # noqa: E402
+from tests.backends import Oracle  # noqa: E402
+from tests.scenes import lookat  # noqa: E402
+
+FIELDS = ("p", "t", "uv", "sh_s", "sh_t", "sh_n", "geo_s", "geo_t", "geo_n", "mesh", "tri")
+
+
+def make_meshes(rng, kind, n, scale):
+    def soup(m, size):
+        c = rng.uniform(-1, 1, (m, 1, 3))
+        return (c + rng.uniform(-size, size, (m, 3, 3))).reshape(-1, 3)
+
+    if kind == "soup":
+        v = soup(n, rng.choice([0.02, 0.1, 0.4]))
+    elif kind == "dups":                       # every triangle twice or three times: ties resolved by index
+        base = soup(max(1, n // 3), 0.2).reshape(-1, 3, 3)
+        v = np.concatenate([base] * 3).reshape(-1, 3)
+    elif kind == "degenerate":                 # zero-area and needle triangles among normal ones
+        v = soup(n, 0.2).reshape(-1, 3, 3)
+        v[::3, 1] = v[::3, 0]
+        v[1::7, 2] = 0.5 * (v[1::7, 0] + v[1::7, 1])
+        v = v.reshape(-1, 3)
+    elif kind == "sheets":                     # axis-aligned quads on a few planes (flat boxes)
+        m = max(1, n // 2)
+        axis = rng.integers(0, 3, m)
+        plane = rng.choice([-0.5, 0.0, 0.25, 1.0], m)
+        a = rng.uniform(-1, 1, (m, 2)); b = a + rng.uniform(0.05, 0.6, (m, 2))
+        tris = []
+        for i in range(m):
+            u, w = [k for k in range(3) if k != axis[i]]
+            q = np.zeros((4, 3)); q[:, axis[i]] = plane[i]
+            q[:, u] = [a[i, 0], b[i, 0], b[i, 0], a[i, 0]]; q[:, w] = [a[i, 1], a[i, 1], b[i, 1], b[i, 1]]
+            tris += [q[[0, 1, 2]], q[[0, 2, 3]]]
+        v = np.array(tris).reshape(-1, 3)
+    elif kind == "stacked":                    # many triangles with the same centroid
+        m = n
+        ang = rng.uniform(0, 2 * np.pi, (m, 1)); r = rng.uniform(0.05, 0.8, (m, 1))
+        k = np.array([0, 2 * np.pi / 3, 4 * np.pi / 3])
+        v = np.stack([r * np.cos(ang + k), r * np.sin(ang + k), np.repeat(rng.uniform(-0.3, 0.3, (m, 1)), 3, 1)], -1).reshape(-1, 3)
+    else:
+        raise ValueError(kind)
+    v = (v * scale).astype(np.float32)
+    nt = v.shape[0] // 3
+    cuts = sorted(set(rng.integers(0, nt + 1, rng.integers(0, 3)).tolist() + [0, nt]))
+    meshes = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        if b > a:
+            meshes.append(Mesh(v[3 * a:3 * b].copy(), np.arange(3 * (b - a), dtype=np.uint32).reshape(-1, 3), name=f"m{a}"))
+    return meshes
+
+
+def make_rays(rng, n, scale, meshes):
+    o = rng.normal(size=(n, 3)); o = o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(0.0, 2.5, (n, 1))
+    d = rng.uniform(-1, 1, (n, 3)) - o
+    k = n // 8
+    d[:k, rng.integers(0, 3)] = 0.0                                  # a zero direction component
+    d[k:2 * k] = np.eye(3)[rng.integers(0, 3, k)] * rng.choice([-1.0, 1.0], (k, 1))   # axis-parallel
+    allv = np.concatenate([m.positions for m in meshes]) / scale
+    pick = allv[rng.integers(0, len(allv), k)]
+    o[2 * k:3 * k] = pick                                             # starts exactly on a vertex
+    o[3 * k:4 * k, 2] = rng.choice([-0.5, 0.0, 0.25, 1.0], k)         # starts in a sheet's plane
+    d /= np.maximum(np.linalg.norm(d, axis=1, keepdims=True), 1e-12)
+    rays = np.zeros(n, dtype=RAY_DTYPE)
+    rays["o"], rays["d"] = (o * scale).astype(np.float32), d.astype(np.float32)
+    rays["mint"] = np.float32(1e-4 * scale)
+    rays["maxt"] = np.inf
+    rays["maxt"][4 * k:5 * k] = (rng.uniform(0.05, 3.0, k) * scale).astype(np.float32)
+    return rays
+
+
+def one_round(seed, renderer_cls, n_rays=20000, verbose=False):
+    rng = np.random.default_rng(seed)
+    kind = ["soup", "dups", "degenerate", "sheets", "stacked"][seed % 5]
+    n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 33, 500, 5000]))
+    scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3, 37.5]))
+    meshes = make_meshes(rng, kind, n, scale)
+    sc = Scene(meshes, Camera(16, 16, 45.0, to_world=lookat((0, 0, 4), (0, 0, 0), (0, 1, 0))), RFilter(), Integrator("normals"), 1)
+    rays = make_rays(rng, n_rays, scale, meshes)
+    o = Oracle(sc)
+    a, sa = o.intersect(rays), o.intersect(rays, True)
+    for builder in (0, 1):
+        r = renderer_cls(0).upload(sc, builder=builder)
+        b, sb = r.intersect(rays), r.intersect(rays, True)
+        r.close()
+        for f in FIELDS:
+            # NaN frames (coordinateSystem of a zero normal on a collinear triangle) compare equal to NaN
+            if not np.array_equal(a[f], b[f], equal_nan=a[f].dtype.kind == "f"):
+                bad = np.nonzero(((a[f] != b[f]) & ~((a[f] != a[f]) & (b[f] != b[f]))).reshape(len(rays), -1).any(1))[0]
+                raise AssertionError(f"seed {seed} kind {kind} n {n} scale {scale} builder {builder}: field {f} differs on "
+                                     f"{len(bad)} rays, first {bad[0]}: oracle {a[bad[0]]} device {b[bad[0]]}")
+        if not np.array_equal(sa["mesh"] != 0xFFFFFFFF, sb["mesh"] != 0xFFFFFFFF):
+            raise AssertionError(f"seed {seed} kind {kind} n {n} builder {builder}: shadow-ray answers differ")
+    o.close()
+    if verbose:
+        print(f"seed {seed}: {kind} x{n} scale {scale}: {int((a['mesh'] != 0xFFFFFFFF).sum())}/{len(rays)} hits ok")
+    return int((a["mesh"] != 0xFFFFFFFF).sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("-v", action="store_true")
+    a = ap.parse_args()
+    from nori_amd.render import Renderer
+    t0, n, hits = time.time(), 0, 0
+    while time.time() - t0 < a.seconds:
+        hits += one_round(a.seed + n, Renderer, verbose=a.v)
+        n += 1
+    print(f"fuzz_intersect: {n} rounds from seed {a.seed}, {hits} hits compared, all bit-identical")
+
+
+if __name__ == "__main__":
+    main()

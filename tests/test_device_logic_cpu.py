@@ -134,3 +134,28 @@ def test_bsdf_and_warp_twins_bitwise():
         assert np.array_equal(Oracle.bsdf_pdf(b, wi, wo), Emu.bsdf_pdf(b, wi, wo), equal_nan=True)
     st = rng.integers(0, 2 ** 63, 100, dtype=np.uint64)
     assert np.array_equal(Oracle.pcg32_floats(st, st[::-1].copy(), 64), Emu.pcg32_floats(st, st[::-1].copy(), 64))
+
+
+def test_fuzz_intersect_on_emulated_device_code():
+    """tests/fuzz_intersect.py (random scene shapes incl. slivers, duplicates, coincident centroids, big
+    and tiny scales; special rays) through the device's traversal code compiled for the CPU + the SAH
+    builder, against the oracle's linear scan: bit-identical intersection records."""
+    from tests import fuzz_intersect
+    from tests.backends import Emu
+
+    class EmuRenderer:
+        def __init__(self, device):
+            self.e = None
+
+        def upload(self, sc, builder=0):
+            self.e = Emu(sc)
+            return self
+
+        def intersect(self, rays, shadow=False):
+            return self.e.intersect(rays, shadow)
+
+        def close(self):
+            self.e.close()
+
+    hits = sum(fuzz_intersect.one_round(seed, EmuRenderer, n_rays=5000) for seed in list(range(60)) + [542])
+    assert hits > 10000

@@ -273,3 +273,11 @@ def test_film_radius_beyond_limit_fails_loudly(renderer_factory):
     r = renderer_factory(sc)
     with pytest.raises(NoriError, match="UNSUPPORTED|radius"):
         r.render_host()
+
+
+def test_fuzz_intersect_short():
+    """A few rounds of tests/fuzz_intersect.py (randomised scene shapes, both BVH builders, bit-exact hits)."""
+    from nori_amd.render import Renderer
+    from tests import fuzz_intersect
+    for seed in range(1000, 1015):
+        fuzz_intersect.one_round(seed, Renderer, n_rays=8000)
