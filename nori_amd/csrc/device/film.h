@@ -27,7 +27,9 @@ struct FilmStore {
     f2 *pos = nullptr;          /* pixelSample */
     f4 *L = nullptr;            /* radiance rgb, w unused */
     size_t capacity = 0;        /* samples */
-    float *tile_acc = nullptr;  /* n_tiles x tile_w^2 x 4 */
+    float *tile_acc = nullptr;  /* n_tiles x n_parts x tile_w^2 x 4 */
+    uint32_t n_parts = 1;       /* workgroups per tile in film_gather: each sums its share of the samples per pixel
+                                   into its own accumulator (few tiles per GPU: keeps all CUs busy); fixed per render */
     size_t acc_floats = 0;
     unsigned long long *d_invalid = nullptr;
 };

@@ -34,7 +34,8 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
     if (tid <= kFilterRes) ftab[tid] = filter_table[tid];
     if (tid == 0) s_invalid = 0u;
 
-    const uint32_t ord = fl.tile_first + blockIdx.x;
+    const uint32_t part = blockIdx.x % st.n_parts;
+    const uint32_t ord = fl.tile_first + blockIdx.x / st.n_parts;
     const uint32_t tile_id = fl.tile_rem + ord * fl.tile_mod;
     const int x0 = (int) (tile_id % fl.tiles_x) * kTile, y0 = (int) (tile_id / fl.tiles_x) * kTile;
     const int border = fr.border, tile_w = fl.tile_w, taps = 2 * border + 1;
@@ -63,7 +64,9 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
     const size_t first = (size_t) (ord - fl.store_tile_first) * fl.n_spp * 256u;
     unsigned int invalid = 0;
     __syncthreads();
-    for (uint32_t s = 0; s < fl.n_spp; ++s) {
+    /* this workgroup's share of the samples per pixel */
+    const uint32_t s_lo = (uint32_t) ((uint64_t) fl.n_spp * part / st.n_parts), s_hi = (uint32_t) ((uint64_t) fl.n_spp * (part + 1) / st.n_parts);
+    for (uint32_t s = s_lo; s < s_hi; ++s) {
         {
             const size_t idx = first + (size_t) s * 256u + (size_t) tid;
             f4 L; L.x = L.y = L.z = 0.0f;
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
         }
         __syncthreads();                                       /* round consumed */
     }
-    f4 *dst = reinterpret_cast<f4 *>(st.tile_acc) + (size_t) ord * n_out;
+    f4 *dst = reinterpret_cast<f4 *>(st.tile_acc) + ((size_t) ord * st.n_parts + part) * n_out;
     for (int o = 0; o < kMaxOut; ++o) {
         const int i = tid + o * kB;
         if (i >= n_out) break;
@@ -120,7 +123,7 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
 /* ImageBlock::put(ImageBlock&): every frame pixel gathers the (at most four) tile accumulators
    whose bordered area covers it, in a fixed order */
 __global__ void film_resolve_kernel(int width, int height, int border, int tile_w, uint32_t tiles_x, uint32_t tiles_y,
-                                    uint32_t tile_mod, uint32_t tile_rem, const float *tile_acc, float *rgbw) {
+                                    uint32_t tile_mod, uint32_t tile_rem, uint32_t n_parts, const float *tile_acc, float *rgbw) {
     const int cols = width + 2 * border, rows = height + 2 * border;
     const int gx = blockIdx.x * blockDim.x + threadIdx.x, gy = blockIdx.y;
     if (gx >= cols || gy >= rows) return;
@@ -134,8 +137,10 @@ __global__ void film_resolve_kernel(int width, int height, int border, int tile_
             const uint32_t tile_id = (uint32_t) ty * tiles_x + (uint32_t) tx;
             if (tile_id < tile_rem || (tile_id - tile_rem) % tile_mod != 0u) continue;
             const uint32_t ord = (tile_id - tile_rem) / tile_mod;
-            const float4 v = *reinterpret_cast<const float4 *>(tile_acc + ((size_t) ord * tile_w * tile_w + (size_t) ly * tile_w + lx) * 4);
-            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            for (uint32_t part = 0; part < n_parts; ++part) {      /* fixed order: deterministic */
+                const float4 v = *reinterpret_cast<const float4 *>(tile_acc + ((((size_t) ord * n_parts + part) * tile_w + (size_t) ly) * tile_w + lx) * 4);
+                sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+            }
         }
     float4 *dst = reinterpret_cast<float4 *>(rgbw) + (size_t) gy * cols + gx;
     float4 cur = *dst;
@@ -171,7 +176,9 @@ std::string film_prepare(size_t n_samples, size_t n_sel_tiles, int tile_w, void 
         FILM_TRY(hipMalloc((void **) &g_film.L, std::max<size_t>(n_samples, 1) * sizeof(f4)));
         g_film.capacity = n_samples;
     }
-    const size_t acc = n_sel_tiles * (size_t) tile_w * tile_w * 4;
+    /* enough workgroups to fill the chip even when this GPU owns few tiles */
+    g_film.n_parts = (uint32_t) std::min<size_t>(8, std::max<size_t>(1, 2048 / std::max<size_t>(n_sel_tiles, 1)));
+    const size_t acc = n_sel_tiles * g_film.n_parts * (size_t) tile_w * tile_w * 4;
     if (g_film.acc_floats < acc) {
         if (g_film.tile_acc) (void) hipFree(g_film.tile_acc);
         g_film.tile_acc = nullptr; g_film.acc_floats = 0;
@@ -188,14 +195,14 @@ std::string film_prepare(size_t n_samples, size_t n_sel_tiles, int tile_w, void 
 void film_gather(const DevScene &sc, const float *d_filter_table, const FilmStore &st, const FilmLaunch &fl, void *stream) {
     if (fl.n_tiles == 0 || fl.n_spp == 0) return;
     const size_t lds = (size_t) (2 * (2 * sc.filter.border + 1) + 3) * 256 * sizeof(float);
-    hipLaunchKernelGGL(film_gather_kernel, dim3(fl.n_tiles), dim3(kB), lds, (hipStream_t) stream, sc.camera.width, sc.camera.height,
+    hipLaunchKernelGGL(film_gather_kernel, dim3(fl.n_tiles * st.n_parts), dim3(kB), lds, (hipStream_t) stream, sc.camera.width, sc.camera.height,
                        sc.filter, d_filter_table, st, fl);
 }
 
 void film_resolve(const DevScene &sc, const FilmStore &st, const FilmLaunch &fl, float *d_rgbw, void *stream) {
     const int border = sc.filter.border, cols = sc.camera.width + 2 * border, rows = sc.camera.height + 2 * border;
     hipLaunchKernelGGL(film_resolve_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, (hipStream_t) stream, sc.camera.width,
-                       sc.camera.height, border, fl.tile_w, fl.tiles_x, fl.tiles_y, fl.tile_mod, fl.tile_rem,
+                       sc.camera.height, border, fl.tile_w, fl.tiles_x, fl.tiles_y, fl.tile_mod, fl.tile_rem, st.n_parts,
                        (const float *) st.tile_acc, d_rgbw);
 }
 
