@@ -180,3 +180,90 @@ for (double x : {0.5,5.0,50.0,300.0}) for (int d : {1,10,199}) printf("%.12g\n",
     want = [stats.t.cdf(t, d) for t in (-3.0, -0.5, 0.0, 1.2, 4.0) for d in (3, 30, 99999)]
     want += [stats.chi2.cdf(x, d) for x in (0.5, 5.0, 50.0, 300.0) for d in (1, 10, 199)]
     np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-12)
+
+
+def _obj_reference(text):
+    """The loader's semantics stated plainly (src/obj.cpp:42-93): serial scan, quads as (0,1,2) (3,0,2),
+    corners de-duplicated by their (p, t, n) index triple in first-use order."""
+    pos, uv, nrm, keys, ids, faces = [], [], [], {}, [], []
+    for line in text.split("\n"):
+        tok = line.split()
+        if not tok:
+            continue
+        if tok[0] == "v":
+            pos.append([np.float32(x) for x in tok[1:4]])
+        elif tok[0] == "vt":
+            uv.append([np.float32(x) for x in tok[1:3]])
+        elif tok[0] == "vn":
+            nrm.append([np.float32(x) for x in tok[1:4]])
+        elif tok[0] == "f":
+            c = []
+            for t in tok[1:5]:
+                parts = t.split("/")
+                c.append((int(parts[0]), int(parts[1]) if len(parts) > 1 and parts[1] else -1, int(parts[2]) if len(parts) > 2 and parts[2] else -1))
+            order = c[:3] + ([c[3], c[0], c[2]] if len(c) == 4 else [])
+            for k in order:
+                if k not in keys:
+                    keys[k] = len(ids)
+                    ids.append(k)
+                faces.append(keys[k])
+    P = np.array([pos[k[0] - 1] for k in ids], np.float32)
+    T = np.array([uv[k[1] - 1] for k in ids], np.float32) if uv else None
+    N = np.array([nrm[k[2] - 1] for k in ids], np.float32) if nrm else None
+    return P, T, N, np.array(faces, np.uint32).reshape(-1, 3)
+
+
+_SCENE_WITH_MESH = """<scene><integrator type='normals'/><camera type='perspective'/>
+<mesh type='obj'><string name='filename' value='%s'/></mesh></scene>"""
+
+
+@pytest.mark.parametrize("flavour", ["p", "p/t/n", "p//n"])
+def test_obj_loader_parallel_slices_match_serial_semantics(tmp_path, flavour):
+    """A file large enough (> 4 MB per worker) to be cut into several slices that are scanned in
+    parallel: same vertices, same first-use order, same faces as a serial reader."""
+    rng = np.random.default_rng(7)
+    nv, nf = 60000, 220000
+    lines = ["# generated", "o thing"]
+    P = rng.uniform(-3, 3, (nv, 3)).astype(np.float32)
+    lines += ["v %.9g %.9g %.9g" % tuple(p) for p in P]
+    lines += ["vt %.7g %.7g" % tuple(t) for t in rng.uniform(0, 1, (nv // 2, 2))]
+    N = rng.normal(size=(nv // 3, 3)); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    lines += ["vn %.9g %.9g %.9g" % tuple(n) for n in N.astype(np.float32)]
+    for i in range(nf):
+        k = 4 if i % 5 == 0 else 3
+        a = rng.integers(1, nv + 1, k)
+        if flavour == "p":
+            lines.append("f " + " ".join(str(x) for x in a) + ("  " if i % 7 == 0 else ""))
+        elif flavour == "p/t/n":
+            lines.append("f " + " ".join("%d/%d/%d" % (x, 1 + x % (nv // 2), 1 + x % (nv // 3)) for x in a))
+        else:
+            lines.append("f " + " ".join("%d//%d" % (x, 1 + (x * 7) % (nv // 3)) for x in a) + "\r")
+        if i % 50000 == 0:
+            lines += ["s off", "usemtl none", ""]
+    text = "\n".join(lines)          # no trailing newline on purpose
+    if flavour == "p":
+        text = "\n".join(l for l in text.split("\n") if not l.startswith(("vt", "vn")))
+    if flavour == "p//n":       # a file WITH vt records whose corners carry no t index is an error in the reference too
+        text = "\n".join(l for l in text.split("\n") if not l.startswith("vt"))
+    text = text + ("\n# pad" * 1) + ("\n#" + "x" * 120) * (1 + (9 << 20) // 122 if len(text) < (9 << 20) else 1)
+    (tmp_path / "big.obj").write_text(text)
+    assert len(text) > (8 << 20)
+    sc = host.load_xml(_write_scene(tmp_path, _SCENE_WITH_MESH % "big.obj", obj=False))
+    m = sc.meshes[0]
+    Pr, Tr, Nr, Fr = _obj_reference(text)
+    assert np.array_equal(m.indices, Fr)
+    assert np.array_equal(m.positions, Pr)
+    if flavour == "p":
+        assert m.normals is None and m.texcoords is None
+    else:
+        np.testing.assert_allclose(m.normals, Nr, rtol=0, atol=2e-7)      # renormalised by toWorld (identity)
+        if flavour == "p/t/n":
+            assert np.array_equal(m.texcoords, Tr)
+
+
+@pytest.mark.parametrize("face,msg", [("f 1/1/1/1 2 3", "Invalid vertex data"), ("f 1 x 3", "Could not parse integer value"),
+                                      ("f 1 2", "Could not parse integer value"), ("f 1 2 9", "range")])
+def test_obj_loader_errors(tmp_path, face, msg):
+    (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\n" + face + "\n")
+    with pytest.raises(Exception, match=msg):
+        host.load_xml(_write_scene(tmp_path, _SCENE_WITH_MESH % "bad.obj", obj=False))
