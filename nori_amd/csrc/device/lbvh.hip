@@ -33,6 +33,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
 #include <string>
 
 #include "lbvh.h"
@@ -88,6 +89,13 @@ __global__ void k_morton(const f4 *pos, const uint32_t *idx, uint32_t n, f3 smin
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     f3 mn, mx; tri_box(pos, idx, t, mn, mx);
+    {   /* numerically collinear triangles (rt_types.h, tri_box_pad) sort behind everything else: bit 63 makes
+           the root split them from the spatial hierarchy */
+        const f3 p0 = xyz(pos[idx[3 * (size_t) t]]), p1 = xyz(pos[idx[3 * (size_t) t + 1]]), p2 = xyz(pos[idx[3 * (size_t) t + 2]]);
+        bool unbounded;
+        (void) tri_box_pad(p1 - p0, p2 - p0, 0.0f, unbounded);
+        if (unbounded) { keys[t] = 0x8000000000000000ull; vals[t] = t; return; }
+    }
     const float cx = (0.5f * (mn.x + mx.x) - smin.x) * sinv.x, cy = (0.5f * (mn.y + mx.y) - smin.y) * sinv.y,
                 cz = (0.5f * (mn.z + mx.z) - smin.z) * sinv.z;
     const float S = 2097152.0f, M = 2097151.0f;
@@ -151,7 +159,7 @@ __global__ void k_leaf_boxes(const f4 *pos, const uint32_t *idx, const uint32_t 
         const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
         bool unbounded;
         const float pad = tri_box_pad(p1 - p0, p2 - p0, pad0, unbounded);      /* slivers: rt_types.h */
-        if (unbounded) { mn = smin; mx = smax; }
+        if (unbounded) { mn = mk3(-kBoxInf); mx = mk3(kBoxInf); }
         mn4.x = mn.x - pad; mn4.y = mn.y - pad; mn4.z = mn.z - pad; mx4.x = mx.x + pad; mx4.y = mx.y + pad; mx4.z = mx.z + pad;
     } else {
         mn4.x = mn4.y = mn4.z = kInf; mx4.x = mx4.y = mx4.z = -kInf;
@@ -183,42 +191,86 @@ __device__ __forceinline__ void range_box(const f4 *tmin, const f4 *tmax, uint32
     }
 }
 
-/* A child of a reachable inner node is a leaf when it is a single primitive or a subtree of <= 4
-   triangles (contiguous in sorted order).  Leaves store their triangles in pairs (rt_types.h); the
-   first pair of the leaf starting at sorted position lo is pair_start[lo] (exclusive scan of the
-   per-leaf pair counts). */
-__device__ __forceinline__ bool child_range(const RadixNode *nodes, uint32_t child, uint32_t &lo, uint32_t &hi) {
-    if (child & kLeafBit) { lo = hi = child & ~kLeafBit; return true; }
-    lo = nodes[child].lo; hi = nodes[child].hi;
-    return hi - lo + 1 <= 4u;
+/* A subtree of <= 4 triangles (contiguous in sorted order) can become ONE leaf (its triangles stored as
+   pairs, rt_types.h) or stay split.  k_collapse decides per radix node with the surface-area heuristic:
+       leaf : A(node) * pairs * Cpair          split : A(node) * Cnode + best(left) + best(right)
+   (a leaf step tests a pair of triangles, ~2.5x the work of a node step).  collapse[i] = 1: node i is a
+   leaf wherever it is reached.  Nodes above 4 triangles are always inner nodes. */
+struct CollapseParams { float c_pair, c_node; };
+
+__device__ __forceinline__ float box_area(f3 mn, f3 mx) {
+    const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
 }
 
-__device__ __forceinline__ int32_t child_link(const RadixNode *nodes, const uint32_t *pair_start, const uint32_t *node_index, uint32_t child, uint32_t &lo, uint32_t &hi) {
-    if (!child_range(nodes, child, lo, hi)) return (int32_t) node_index[child];
+__device__ float best_cost(const RadixNode *nodes, const f4 *tmin, const f4 *tmax, uint32_t N, uint32_t child, CollapseParams cp, bool *collapse_out) {
+    f3 mn, mx;
+    if (child & kLeafBit) {
+        const uint32_t k = child & ~kLeafBit;
+        range_box(tmin, tmax, N, k, k, mn, mx);
+        return box_area(mn, mx) * cp.c_pair;
+    }
+    const RadixNode nd = nodes[child];
+    range_box(tmin, tmax, N, nd.lo, nd.hi, mn, mx);
+    const float area = box_area(mn, mx);
+    const float leaf = area * (float) ((nd.hi - nd.lo + 2u) / 2u) * cp.c_pair;
+    const float split = area * cp.c_node + best_cost(nodes, tmin, tmax, N, nd.left, cp, nullptr) + best_cost(nodes, tmin, tmax, N, nd.right, cp, nullptr);
+    if (collapse_out) *collapse_out = leaf <= split;
+    return fminf(leaf, split);
+}
+
+__global__ void k_collapse(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N, CollapseParams cp, uint32_t *collapse) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner) return;
+    const RadixNode nd = nodes[i];
+    bool c = false;
+    if (nd.hi - nd.lo + 1 <= 4u) (void) best_cost(nodes, tmin, tmax, N, i, cp, &c);      /* subtree of <= 3 inner nodes */
+    collapse[i] = c ? 1u : 0u;
+}
+
+/* is `child` a leaf (primitive or collapsed subtree)?  [lo, hi] = its sorted range */
+__device__ __forceinline__ bool child_range(const RadixNode *nodes, const uint32_t *collapse, uint32_t child, uint32_t &lo, uint32_t &hi) {
+    if (child & kLeafBit) { lo = hi = child & ~kLeafBit; return true; }
+    lo = nodes[child].lo; hi = nodes[child].hi;
+    return collapse[child] != 0u;
+}
+
+/* the first pair of the leaf starting at sorted position lo is pair_start[lo] (exclusive scan of the
+   per-leaf pair counts) */
+__device__ __forceinline__ int32_t child_link(const RadixNode *nodes, const uint32_t *collapse, const uint32_t *pair_start, const uint32_t *node_index,
+                                              uint32_t child, uint32_t &lo, uint32_t &hi) {
+    if (!child_range(nodes, collapse, child, lo, hi)) return (int32_t) node_index[child];
     const uint32_t cnt = hi - lo + 1;
     return (int32_t) ~((pair_start[lo] << 3) | ((cnt + 1u) / 2u - 1u));
 }
 
 /* leaf_cnt[lo] = triangles of the leaf that starts at sorted position lo, leaf_pairs[lo] = its pairs;
-   keep[i] = 1 for the radix nodes that survive as BVH nodes (the others sit inside collapsed subtrees) */
-__global__ void k_mark_leaves(const RadixNode *nodes, uint32_t n_inner, uint32_t *leaf_cnt, uint32_t *leaf_pairs, uint32_t *keep) {
+   keep[i] = 1 for the radix nodes that survive as BVH nodes: not collapsed and not below a collapsed node */
+__global__ void k_mark_leaves(const RadixNode *nodes, uint32_t n_inner, const uint32_t *collapse, const uint32_t *parent_inner,
+                              uint32_t *leaf_cnt, uint32_t *leaf_pairs, uint32_t *keep) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_inner) return;
     const RadixNode nd = nodes[i];
-    keep[i] = nd.hi - nd.lo + 1 > 4u ? 1u : 0u;
-    if (nd.hi - nd.lo + 1 <= 4u) return;          /* inside a collapsed subtree: unreachable */
+    bool reachable = collapse[i] == 0u;
+    for (uint32_t p = i; reachable && p != 0u && nodes[p].hi - nodes[p].lo + 1 <= 4u; ) {      /* ancestors that might have collapsed */
+        p = parent_inner[p];
+        if (p == 0xffffffffu) break;
+        if (collapse[p]) reachable = false;
+    }
+    keep[i] = reachable ? 1u : 0u;
+    if (!reachable) return;
     uint32_t lo, hi;
-    if (child_range(nodes, nd.left, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
-    if (child_range(nodes, nd.right, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
+    if (child_range(nodes, collapse, nd.left, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
+    if (child_range(nodes, collapse, nd.right, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
 }
 
 __global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N,
-                             const uint32_t *pair_start, const uint32_t *keep, const uint32_t *node_index, f4 *out) {
+                             const uint32_t *collapse, const uint32_t *pair_start, const uint32_t *keep, const uint32_t *node_index, f4 *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_inner || !keep[i]) return;
     const RadixNode nd = nodes[i];
     uint32_t llo, lhi, rlo, rhi;
-    const int32_t cl = child_link(nodes, pair_start, node_index, nd.left, llo, lhi), cr = child_link(nodes, pair_start, node_index, nd.right, rlo, rhi);
+    const int32_t cl = child_link(nodes, collapse, pair_start, node_index, nd.left, llo, lhi), cr = child_link(nodes, collapse, pair_start, node_index, nd.right, rlo, rhi);
     f3 lmn, lmx, rmn, rmx;
     range_box(tmin, tmax, N, llo, lhi, lmn, lmx);
     range_box(tmin, tmax, N, rlo, rhi, rmn, rmx);
@@ -298,7 +350,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     LB_TRY(hipMemcpy(hb, bounds.p, sizeof(hb), hipMemcpyDeviceToHost));
     f3 smin = mk3(key_float(hb[0]), key_float(hb[1]), key_float(hb[2])), smax = mk3(key_float(hb[3]), key_float(hb[4]), key_float(hb[5]));
     const float ex = smax.x - smin.x, ey = smax.y - smin.y, ez = smax.z - smin.z;
-    const float pad = 2e-5f * sqrtf(ex * ex + ey * ey + ez * ez) + 1e-30f;    /* as scene_prep.cpp */
+    const float pad = box_pad_rel() * sqrtf(ex * ex + ey * ey + ez * ez) + 1e-30f;    /* as scene_prep.cpp */
     const f3 sinv = mk3(ex > 0 ? 1.0f / ex : 0.0f, ey > 0 ? 1.0f / ey : 0.0f, ez > 0 ? 1.0f / ez : 0.0f);
 
     /* 7 first: the triangle records only need the sorted order; tiny scenes are one leaf */
@@ -308,15 +360,16 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     hipLaunchKernelGGL(k_morton, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n, smin, sinv, keys_a.as<unsigned long long>(), vals_a.as<uint32_t>());
     size_t temp_bytes = 0;
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(),
-                                              vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), (int) n, 0, 63));
+                                              vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), (int) n, 0, 64));
     Buf temp; LB_TRY(temp.alloc(temp_bytes));
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(),
-                                              vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), (int) n, 0, 63));
+                                              vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), (int) n, 0, 64));
     const unsigned long long *keys = keys_b.as<unsigned long long>();
     const uint32_t *order = vals_b.as<uint32_t>();      /* sorted position -> global triangle */
 
     /* leaves: start positions, triangle counts, pair counts -> first pair of every leaf */
-    Buf leaf_cnt, leaf_pairs, pair_start, rnodes, pin, plf, keep, node_index;
+    Buf leaf_cnt, leaf_pairs, pair_start, rnodes, pin, plf, keep, node_index, collapse, tmin, tmax;
+    uint32_t N = 1;
     LB_TRY(leaf_cnt.alloc((size_t) n * 4)); LB_TRY(leaf_pairs.alloc((size_t) n * 4)); LB_TRY(pair_start.alloc((size_t) n * 4));
     LB_TRY(hipMemset(leaf_cnt.p, 0, (size_t) n * 4)); LB_TRY(hipMemset(leaf_pairs.p, 0, (size_t) n * 4));
     if (n <= 4) {
@@ -328,9 +381,22 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         LB_TRY(rnodes.alloc((size_t) (n - 1) * sizeof(RadixNode)));
         LB_TRY(pin.alloc((size_t) n * 4)); LB_TRY(plf.alloc((size_t) n * 4));
         hipLaunchKernelGGL(k_hierarchy, dim3(gridN), dim3(B), 0, 0, keys, (int) n, rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());
+        /* 5. segment tree of boxes */
+        N = 1; while (N < n) N <<= 1;
+        LB_TRY(tmin.alloc((size_t) 2 * N * sizeof(f4))); LB_TRY(tmax.alloc((size_t) 2 * N * sizeof(f4)));
+        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, order, n, N, pad, smin, smax, tmin.as<f4>(), tmax.as<f4>());
+        for (uint32_t first = N >> 1; first >= 1; first >>= 1) {
+            hipLaunchKernelGGL(k_tree_level, dim3((first + B - 1) / B), dim3(B), 0, 0, first, first, tmin.as<f4>(), tmax.as<f4>());
+            if (first == 1) break;
+        }
+        /* which small subtrees become one leaf */
+        CollapseParams cp; cp.c_pair = 2.5f; cp.c_node = 1.0f;
+        if (const char *e = getenv("NORI_HIP_LBVH_PAIR_COST")) cp.c_pair = std::max(0.01f, (float) atof(e));
+        LB_TRY(collapse.alloc((size_t) n * 4));
+        hipLaunchKernelGGL(k_collapse, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, tmin.as<f4>(), tmax.as<f4>(), N, cp, collapse.as<uint32_t>());
         LB_TRY(keep.alloc((size_t) n * 4)); LB_TRY(node_index.alloc((size_t) n * 4));
-        hipLaunchKernelGGL(k_mark_leaves, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, leaf_cnt.as<uint32_t>(), leaf_pairs.as<uint32_t>(),
-                           keep.as<uint32_t>());
+        hipLaunchKernelGGL(k_mark_leaves, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, collapse.as<uint32_t>(), pin.as<uint32_t>(),
+                           leaf_cnt.as<uint32_t>(), leaf_pairs.as<uint32_t>(), keep.as<uint32_t>());
     }
     {
         size_t scan_bytes = 0;
@@ -358,15 +424,6 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         out.d_nodes = d_nodes; out.root = (int32_t) ~((0u << 3) | ((n + 1u) / 2u - 1u));
         out.n_nodes = 0; out.n_leaves = 1; out.max_depth = 0;
     } else {
-        /* 5. segment tree of boxes */
-        uint32_t N = 1; while (N < n) N <<= 1;
-        Buf tmin, tmax;
-        LB_TRY(tmin.alloc((size_t) 2 * N * sizeof(f4))); LB_TRY(tmax.alloc((size_t) 2 * N * sizeof(f4)));
-        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, order, n, N, pad, smin, smax, tmin.as<f4>(), tmax.as<f4>());
-        for (uint32_t first = N >> 1; first >= 1; first >>= 1) {
-            hipLaunchKernelGGL(k_tree_level, dim3((first + B - 1) / B), dim3(B), 0, 0, first, first, tmin.as<f4>(), tmax.as<f4>());
-            if (first == 1) break;
-        }
         /* 6. nodes: the radix nodes that are not inside a collapsed subtree, renumbered densely (root stays 0) */
         uint32_t n_nodes = 0;
         {
@@ -383,7 +440,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         LB_TRY(hipMalloc((void **) &d_nodes, (size_t) std::max<uint32_t>(n_nodes, 1) * kNodeQuads * sizeof(f4)));
         out.d_nodes = d_nodes;
         hipLaunchKernelGGL(k_emit_nodes, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, tmin.as<f4>(), tmax.as<f4>(), N,
-                           pair_start.as<uint32_t>(), keep.as<uint32_t>(), node_index.as<uint32_t>(), d_nodes);
+                           collapse.as<uint32_t>(), pair_start.as<uint32_t>(), keep.as<uint32_t>(), node_index.as<uint32_t>(), d_nodes);
         /* 8. depth */
         Buf md; LB_TRY(md.alloc(4)); LB_TRY(hipMemset(md.p, 0, 4));
         hipLaunchKernelGGL(k_depth, dim3(gridN), dim3(B), 0, 0, pin.as<uint32_t>(), plf.as<uint32_t>(), n, md.as<unsigned int>());

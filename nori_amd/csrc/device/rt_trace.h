@@ -121,8 +121,11 @@ NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, Travers
     float nl, fl, nr, fr;
     slab_two(q0, q1, q2, tv.o, tv.rcp, nl, fl, nr, fr);
     fl *= 1.0000004f; fr *= 1.0000004f;
-    const bool hl = (nl <= fl) && (fl >= tv.mint) && (nl <= tv.hit.t);
-    const bool hr = (nr <= fr) && (fr >= tv.mint) && (nr <= tv.hit.t);
+    /* the box interval is clipped against [0, far limit], not [mint, ...]: a ray that leaves a surface at a
+       grazing angle can re-hit its own triangle at a t that is pure rounding noise yet >= mint (the
+       reference's scan reports it), while the ray is outside the triangle's box by then */
+    const bool hl = (nl <= fl) && (fl >= 0.0f) && (nl <= tv.hit.t);
+    const bool hr = (nr <= fr) && (fr >= 0.0f) && (nr <= tv.hit.t);
     const int cl = (int) f2u(q3.x), cr = (int) f2u(q3.y);
     if (hl && hr) {
         const bool leftFirst = nl <= nr;

@@ -97,9 +97,21 @@ NORI_HD f3 to_world(const Frame &f, f3 v) { return (f.s * v.x + f.t * v.y) + f.n
  * (2e-5 x scene diagonal).  The rounding error of det = e1 . (d x e2) is ~2^-23 |e1||e2|, so relative
  * to det it grows like 1 / sin(angle between the edges): a sliver's accepted region is wider by that
  * factor, and for (numerically) collinear vertices u, v, t are noise and the reference's linear scan
- * can report a hit for a ray that passes nowhere near the triangle.  The pad therefore scales with
- * 1 / sin; below 1e-4 the triangle is given the whole scene as its box (`unbounded`): every ray tests
- * it, exactly as the scan does.  Triangles with a zero-length edge have det == 0 and are never hit. */
+ * can report a hit for a ray that passes nowhere near the triangle -- even outside the scene's box.
+ * The pad therefore scales with 1 / sin; below 1e-4 the triangle is `unbounded`: the builders keep such
+ * triangles out of the spatial hierarchy and hang them under the root in a subtree whose boxes are
+ * (-kBoxInf, kBoxInf)^3, so every ray tests them, exactly as the scan does.  Triangles with a
+ * zero-length edge have det == 0 and are never hit. */
+constexpr float kBoxInf = 3.0e38f;
+/* pad of a well-shaped triangle's box, relative to the scene diagonal; NORI_HIP_BOX_PAD overrides (experiments) */
+constexpr float kBoxPadRel = 2e-6f;
+inline float box_pad_rel() {
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (const char *e = std::getenv("NORI_HIP_BOX_PAD")) return (float) std::atof(e);
+#endif
+    return kBoxPadRel;
+}
+
 NORI_HD float tri_box_pad(f3 e1, f3 e2, float pad, bool &unbounded) {
     unbounded = false;
     const float l1 = dot(e1, e1), l2 = dot(e2, e2);

@@ -235,6 +235,8 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
     }
 
     std::vector<Box> boxes(n);
+    std::vector<uint8_t> isUnbounded(n, 0);      /* numerically collinear triangles: rt_types.h, tri_box_pad */
+    uint32_t nUnbounded = 0;
     std::vector<float> cent(3 * (size_t) n);
     Box sceneBox; sceneBox.reset();
     for (uint32_t t = 0; t < n; ++t) {
@@ -246,22 +248,30 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
        Moeller-Trumbore test (rounded differently) accepts the ray. */
     {
         const float dx = sceneBox.mx[0] - sceneBox.mn[0], dy = sceneBox.mx[1] - sceneBox.mn[1], dz = sceneBox.mx[2] - sceneBox.mn[2];
-        const float pad = 2e-5f * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f;
+        const float pad = box_pad_rel() * std::sqrt(dx * dx + dy * dy + dz * dz) + 1e-30f;
         for (uint32_t t = 0; t < n; ++t) {
             const uint32_t *id = &sc.indices[3 * (size_t) t];
             const f3 p0 = xyz(sc.positions[id[0]]), p1 = xyz(sc.positions[id[1]]), p2 = xyz(sc.positions[id[2]]);
             bool unbounded;
             const float padT = tri_box_pad(p1 - p0, p2 - p0, pad, unbounded);      /* slivers: rt_types.h */
+            isUnbounded[t] = unbounded ? 1 : 0;
+            nUnbounded += unbounded ? 1u : 0u;
             for (int k = 0; k < 3; ++k) {
-                if (unbounded) { boxes[t].mn[k] = sceneBox.mn[k]; boxes[t].mx[k] = sceneBox.mx[k]; }
-                boxes[t].mn[k] -= padT; boxes[t].mx[k] += padT;
+                if (unbounded) { boxes[t].mn[k] = -kBoxInf; boxes[t].mx[k] = kBoxInf; }
+                else { boxes[t].mn[k] -= padT; boxes[t].mx[k] += padT; }
                 cent[3 * (size_t) t + k] = 0.5f * (boxes[t].mn[k] + boxes[t].mx[k]);
             }
         }
     }
 
+    /* bounded triangles first: the root splits them from the unbounded ones, whose subtree (all boxes
+       infinite, median splits) every ray walks completely */
     std::vector<uint32_t> prim(n);
-    for (uint32_t t = 0; t < n; ++t) prim[t] = t;
+    {
+        uint32_t a = 0, b = n - nUnbounded;
+        for (uint32_t t = 0; t < n; ++t) { if (isUnbounded[t]) prim[b++] = t; else prim[a++] = t; }
+    }
+    const uint32_t nBounded = n - nUnbounded;
     std::vector<BuildNode> bn;
     bn.reserve(2 * (size_t) n / 2 + 16);
     bn.emplace_back();
@@ -288,8 +298,9 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
           axis = (e0 >= e1 && e0 >= e2) ? 0 : (e1 >= e2 ? 1 : 2); }
         uint32_t mid = first;
         bool split = false;
+        if (id == 0 && nUnbounded > 0 && nBounded > 0) { mid = nBounded; split = true; }
 
-        if (!forceMedian) {
+        if (!split && !forceMedian) {
             float bestCost = std::numeric_limits<float>::infinity(); int bestAxis = -1, bestBin = -1;
             for (int ax = 0; ax < 3; ++ax) {
                 const float cmin = cb.mn[ax], cmax = cb.mx[ax];
@@ -377,7 +388,8 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
     for (size_t b = 0; b < bn.size(); ++b)
         if (isLeaf((int32_t) b) && bn[b].count > (uint32_t) kMaxLeafTris) return "internal: leaf exceeds kMaxLeafTris";
 
-    const float rootArea = std::max(bn[0].box.area(), 1e-30f);
+    const int32_t sahRoot = (nUnbounded > 0 && nBounded > 0) ? bn[0].left : 0;      /* statistic over the spatial hierarchy only */
+    const float rootArea = std::max(bn[sahRoot].box.area(), 1e-30f);
     double sah = 0.0;
     uint32_t maxDepth = 0, nLeaves = 0;
     if (isLeaf(0)) {
@@ -393,7 +405,8 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
           while (!st.empty()) { int32_t b = st.back(); st.pop_back(); if (isLeaf(b)) continue; devId[b] = (int32_t) nInner++; st.push_back(bn[b].right); st.push_back(bn[b].left); } }
         out.nodes.resize((size_t) nInner * kNodeQuads);
         for (size_t b = 0; b < bn.size(); ++b) {
-            const float rel = bn[b].box.area() / rootArea;
+            const float area = bn[b].box.area();
+            const float rel = std::isfinite(area) ? area / rootArea : 0.0f;
             if (isLeaf((int32_t) b)) {
                 nLeaves++; maxDepth = std::max(maxDepth, bn[b].depth);
                 sah += kCostTri * rel * bn[b].count;
