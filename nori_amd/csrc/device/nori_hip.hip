@@ -299,8 +299,8 @@ __global__ void pcg32_kernel(const uint64_t *state, const uint64_t *seq, size_t 
     for (uint32_t j = 0; j < count; ++j) out[i * count + j] = rng_next_float(r);
 }
 
-/* ImageBlock::put(pos, value) straight into the global frame (parity twin;
- * the render kernel splats into LDS instead). */
+/* ImageBlock::put(pos, value) straight into the global frame: the batch twin of the film (film.hip
+ * turns the same weights into a gather over a sample store). */
 __global__ void splat_kernel(FilterRec fl, const float *ftab, int width, int height, const float *pos, const float *val,
                              size_t n, float *rgbw) {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;

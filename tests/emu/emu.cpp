@@ -19,7 +19,7 @@
 #include <vector>
 
 #include "../../include/nori_hip.h"
-#include "../../nori_amd/csrc/device/rt_film.h"
+#include "emu_film.h"
 #include "../../nori_amd/csrc/device/rt_path.h"
 #include "../../nori_amd/csrc/device/scene_prep.h"
 

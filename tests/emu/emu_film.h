@@ -1,16 +1,15 @@
 /*
- * rt_film.h -- ImageBlock::put(pos, value), src/block.cpp:62-91, into a pixel
- * tile of (kTile + 2*border)^2 RGBW accumulators.
+ * emu_film.h -- ImageBlock::put(pos, value), src/block.cpp:62-91, into a pixel tile of
+ * (kTile + 2*border)^2 RGBW accumulators: the CPU emulation harness's film (a plain scatter; the
+ * product's film is film.hip: sample store + gather, checked against the oracle on the GPU).
  *
- * Weights are computed exactly as the reference does for the 32x32 block
- * (NORI_BLOCK_SIZE, include/nori/block.h:17) that contains the tile -- same
- * block-relative float arithmetic, so the filter-table index of every
- * (sample, pixel) pair is the one Nori computes -- and then shifted to tile
- * coordinates with integer offsets only.  `Add` is the accumulate policy:
- * ds_add_f32 on the LDS tile in the render kernel.
+ * Weights are computed exactly as the reference does for the 32x32 block (NORI_BLOCK_SIZE,
+ * include/nori/block.h:17) that contains the tile -- same block-relative float arithmetic, so the
+ * filter-table index of every (sample, pixel) pair is the one Nori computes -- and then shifted to
+ * tile coordinates with integer offsets only.
  */
 #pragma once
-#include "rt_types.h"
+#include "../../nori_amd/csrc/device/rt_types.h"
 
 namespace nrt {
 
