@@ -20,10 +20,13 @@ public:
     };
     virtual ~NoriObject() {}
     virtual EClassType getClassType() const = 0;
-    virtual void addChild(NoriObject *child);
-    virtual void setParent(NoriObject *parent);
-    virtual void activate();
     virtual std::string toString() const = 0;
+    /* defaults of the protocol: leaf objects take no children and need no post-processing */
+    virtual void addChild(NoriObject *) {
+        throw NoriException("NoriObject::addChild() is not implemented for objects of type '%s'!", classTypeName(getClassType()));
+    }
+    virtual void setParent(NoriObject *) {}
+    virtual void activate() {}
 
     static std::string classTypeName(EClassType type) {
         switch (type) {
@@ -40,17 +43,23 @@ public:
     }
 };
 
+/* name -> constructor registry, filled by the static registrars NORI_REGISTER_CLASS plants in every
+   plugin's translation unit; the table is created on first use, so registration order across
+   translation units does not matter */
 class NoriObjectFactory {
 public:
     typedef std::function<NoriObject *(const PropertyList &)> Constructor;
-    static void registerClass(const std::string &name, const Constructor &constr);
+    static void registerClass(const std::string &name, const Constructor &constr) { registry()[name] = constr; }
     static NoriObject *createInstance(const std::string &name, const PropertyList &propList) {
-        if (!m_constructors || m_constructors->find(name) == m_constructors->end())
-            throw NoriException("A constructor for class \"%s\" could not be found!", name);
-        return (*m_constructors)[name](propList);
+        const auto it = registry().find(name);
+        if (it == registry().end()) throw NoriException("A constructor for class \"%s\" could not be found!", name);
+        return it->second(propList);
     }
 private:
-    static std::map<std::string, Constructor> *m_constructors;
+    static std::map<std::string, Constructor> &registry() {
+        static std::map<std::string, Constructor> table;
+        return table;
+    }
 };
 
 #define NORI_REGISTER_CLASS(cls, name)                                          \
