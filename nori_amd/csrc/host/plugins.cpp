@@ -542,7 +542,7 @@ Device &Scene::device() const {
         std::unique_ptr<Device> d(new Device());
         const nori_scene_desc &desc = getDesc();
         d->check(nori_hip_upload_scene(d->ctx(), &desc), "nori_hip_upload_scene");
-        d->check(nori_hip_build_accel(d->ctx(), NORI_ACCEL_HOST_SAH), "nori_hip_build_accel");
+        d->check(nori_hip_build_accel(d->ctx(), NORI_ACCEL_AUTO), "nori_hip_build_accel");
         m_device = std::move(d);
     }
     return *m_device;
