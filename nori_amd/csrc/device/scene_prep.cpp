@@ -10,8 +10,12 @@
 #include "scene_prep.h"
 
 #include <algorithm>
+#include <thread>
+#include <functional>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -272,21 +276,47 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
         for (uint32_t t = 0; t < n; ++t) { if (isUnbounded[t]) prim[b++] = t; else prim[a++] = t; }
     }
     const uint32_t nBounded = n - nUnbounded;
-    std::vector<BuildNode> bn;
-    bn.reserve(2 * (size_t) n / 2 + 16);
-    bn.emplace_back();
-    bn[0].first = 0; bn[0].count = n; bn[0].depth = 0;
-    std::vector<uint32_t> todo; todo.push_back(0);
+    const bool timing = std::getenv("NORI_HIP_BUILD_TIMING") != nullptr;
+    auto lap = [&](const char *what) { if (timing) fprintf(stderr, "[sah] %-10s %.0f ms\n", what, std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count()); };
+    lap("boxes");
+    /* Top-down binned SAH.  Subtrees are independent once their triangle ranges are disjoint, so the
+       build runs on all host cores: the few nodes above kTaskTris triangles are split one after the
+       other with the binning itself spread over the threads, everything below becomes a task for the
+       pool.  Every reduction is exact (min / max / counts), so the tree does not depend on the number of
+       threads. */
+    const uint32_t kTaskTris = 1u << 16;
+    uint32_t nThreads = n < (1u << 18) ? 1u : std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    if (const char *e = std::getenv("NORI_HIP_BUILD_THREADS")) nThreads = (uint32_t) std::max(1, std::min(64, std::atoi(e)));
 
     auto log2ceil = [](uint32_t v) { uint32_t r = 0; while ((1u << r) < v) ++r; return r; };
 
-    while (!todo.empty()) {
-        const uint32_t id = todo.back(); todo.pop_back();
-        const uint32_t first = bn[id].first, count = bn[id].count, depth = bn[id].depth;
-        Box nb, cb; nb.reset(); cb.reset();
-        for (uint32_t i = first; i < first + count; ++i) { nb.grow(boxes[prim[i]]); cb.grow(&cent[3 * (size_t) prim[i]]); }
-        bn[id].box = nb;
-        if (count <= 1) continue;
+    /* run fn(slice_begin, slice_end, slice_index) over [first, first + count) on `threads` threads */
+    auto parallelFor = [](uint32_t first, uint32_t count, uint32_t threads, auto &&fn) {
+        if (threads <= 1 || count < (1u << 16)) { fn(first, first + count, 0u); return; }
+        std::vector<std::thread> pool;
+        for (uint32_t k = 1; k < threads; ++k)
+            pool.emplace_back([&fn, first, count, threads, k] { fn(first + (uint32_t) ((uint64_t) count * k / threads), first + (uint32_t) ((uint64_t) count * (k + 1) / threads), k); });
+        fn(first, first + (uint32_t) ((uint64_t) count / threads), 0u);
+        for (std::thread &t : pool) t.join();
+    };
+
+    struct Bins { Box bb[3][kBins]; uint32_t bc[3][kBins]; };
+
+    /* box of a node and its split position: returns false when the node stays a leaf */
+    auto splitNode = [&](BuildNode &node, bool isRoot, uint32_t threads, uint32_t &mid) -> bool {
+        const uint32_t first = node.first, count = node.count, depth = node.depth;
+        const uint32_t slices = (threads <= 1 || count < (1u << 16)) ? 1u : threads;
+        Box nbs[64], cbs[64];
+        parallelFor(first, count, threads, [&](uint32_t lo, uint32_t hi, uint32_t k) {
+            Box nb, cb; nb.reset(); cb.reset();
+            for (uint32_t i = lo; i < hi; ++i) { nb.grow(boxes[prim[i]]); cb.grow(&cent[3 * (size_t) prim[i]]); }
+            nbs[k] = nb; cbs[k] = cb;
+        });
+        Box nb = nbs[0], cb = cbs[0];
+        for (uint32_t k = 1; k < slices; ++k) { nb.grow(nbs[k]); cb.grow(cbs[k]); }
+        node.box = nb;
+        if (count <= 1) return false;
+        if (isRoot && nUnbounded > 0 && nBounded > 0) { mid = nBounded; return true; }
 
         /* depth budget: once the remaining levels only just suffice for a
            balanced split, stop using SAH */
@@ -296,23 +326,33 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
         int axis = 0;
         { float e0 = cb.mx[0] - cb.mn[0], e1 = cb.mx[1] - cb.mn[1], e2 = cb.mx[2] - cb.mn[2];
           axis = (e0 >= e1 && e0 >= e2) ? 0 : (e1 >= e2 ? 1 : 2); }
-        uint32_t mid = first;
+        mid = first;
         bool split = false;
-        if (id == 0 && nUnbounded > 0 && nBounded > 0) { mid = nBounded; split = true; }
 
-        if (!split && !forceMedian) {
+        if (!forceMedian) {
+            float scale[3]; bool usable[3];
+            for (int ax = 0; ax < 3; ++ax) { usable[ax] = cb.mx[ax] > cb.mn[ax]; scale[ax] = usable[ax] ? kBins / (cb.mx[ax] - cb.mn[ax]) : 0.0f; }
+            Bins one; std::vector<Bins> many; if (slices > 1) many.resize(slices);
+            Bins *part = slices > 1 ? many.data() : &one;
+            parallelFor(first, count, threads, [&](uint32_t lo, uint32_t hi, uint32_t k) {
+                Bins &B = part[k];
+                for (int ax = 0; ax < 3; ++ax) for (int b = 0; b < kBins; ++b) { B.bb[ax][b].reset(); B.bc[ax][b] = 0; }
+                for (uint32_t i = lo; i < hi; ++i) {
+                    const uint32_t g = prim[i];
+                    for (int ax = 0; ax < 3; ++ax) {
+                        if (!usable[ax]) continue;
+                        int b = (int) ((cent[3 * (size_t) g + ax] - cb.mn[ax]) * scale[ax]);
+                        b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+                        B.bb[ax][b].grow(boxes[g]); B.bc[ax][b]++;
+                    }
+                }
+            });
+            for (uint32_t k = 1; k < slices; ++k)
+                for (int ax = 0; ax < 3; ++ax) for (int b = 0; b < kBins; ++b) { part[0].bb[ax][b].grow(part[k].bb[ax][b]); part[0].bc[ax][b] += part[k].bc[ax][b]; }
             float bestCost = std::numeric_limits<float>::infinity(); int bestAxis = -1, bestBin = -1;
             for (int ax = 0; ax < 3; ++ax) {
-                const float cmin = cb.mn[ax], cmax = cb.mx[ax];
-                if (!(cmax > cmin)) continue;
-                Box bb[kBins]; uint32_t bc[kBins];
-                for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
-                const float scale = kBins / (cmax - cmin);
-                for (uint32_t i = first; i < first + count; ++i) {
-                    int b = (int) ((cent[3 * (size_t) prim[i] + ax] - cmin) * scale);
-                    b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
-                    bb[b].grow(boxes[prim[i]]); bc[b]++;
-                }
+                if (!usable[ax]) continue;
+                const Box *bb = part[0].bb[ax]; const uint32_t *bc = part[0].bc[ax];
                 float ra[kBins]; uint32_t rc[kBins]; Box acc; acc.reset(); uint32_t c = 0;
                 for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); c += bc[b]; ra[b] = acc.area(); rc[b] = c; }
                 Box la; la.reset(); uint32_t lc = 0;
@@ -328,9 +368,9 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
                 const float splitCost = kCostNode * area + kCostTri * bestCost;
                 const float leafCost = kCostTri * area * (float) count;
                 if (count > kLeafTarget || splitCost < leafCost) {
-                    const float cmin = cb.mn[bestAxis], scale = kBins / (cb.mx[bestAxis] - cmin);
+                    const float cmin = cb.mn[bestAxis], sc2 = scale[bestAxis];
                     auto it = std::partition(prim.begin() + first, prim.begin() + first + count, [&](uint32_t g) {
-                        int b = (int) ((cent[3 * (size_t) g + bestAxis] - cmin) * scale);
+                        int b = (int) ((cent[3 * (size_t) g + bestAxis] - cmin) * sc2);
                         b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
                         return b <= bestBin;
                     });
@@ -340,19 +380,85 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
             }
         }
         if (!split) {
-            if (count <= kLeafTarget) continue;            /* stays a leaf */
+            if (count <= kLeafTarget) return false;            /* stays a leaf */
             mid = first + count / 2;
             std::nth_element(prim.begin() + first, prim.begin() + mid, prim.begin() + first + count,
                              [&](uint32_t a, uint32_t b) { return cent[3 * (size_t) a + axis] < cent[3 * (size_t) b + axis]; });
         }
-        const int32_t l = (int32_t) bn.size(); bn.emplace_back();
-        const int32_t r = (int32_t) bn.size(); bn.emplace_back();
-        bn[id].left = l; bn[id].right = r;
-        bn[l].first = first; bn[l].count = mid - first; bn[l].depth = depth + 1;
-        bn[r].first = mid; bn[r].count = first + count - mid; bn[r].depth = depth + 1;
-        todo.push_back((uint32_t) r); todo.push_back((uint32_t) l);
+        return true;
+    };
+
+    /* the subtree below nodes[root], depth first, appended to `nodes` */
+    auto buildSubtree = [&](std::vector<BuildNode> &nodes, uint32_t root, bool rootIsTreeRoot) {
+        std::vector<uint32_t> todo; todo.push_back(root);
+        while (!todo.empty()) {
+            const uint32_t id = todo.back(); todo.pop_back();
+            uint32_t mid = 0;
+            BuildNode cur = nodes[id];
+            const bool split = splitNode(cur, rootIsTreeRoot && id == root, 1, mid);
+            nodes[id] = cur;
+            if (!split) continue;
+            const int32_t l = (int32_t) nodes.size(); nodes.emplace_back();
+            const int32_t r = (int32_t) nodes.size(); nodes.emplace_back();
+            nodes[id].left = l; nodes[id].right = r;
+            nodes[l].first = cur.first; nodes[l].count = mid - cur.first; nodes[l].depth = cur.depth + 1;
+            nodes[r].first = mid; nodes[r].count = cur.first + cur.count - mid; nodes[r].depth = cur.depth + 1;
+            todo.push_back((uint32_t) r); todo.push_back((uint32_t) l);
+        }
+    };
+
+    std::vector<BuildNode> bn;
+    bn.reserve((size_t) n / 2 + 16);
+    bn.emplace_back();
+    bn[0].first = 0; bn[0].count = n; bn[0].depth = 0;
+    if (nThreads <= 1) {
+        buildSubtree(bn, 0, true);
+    } else {
+        /* top of the tree: big nodes one at a time, binning on all threads */
+        std::vector<uint32_t> big, tasks;
+        big.push_back(0);
+        for (size_t q = 0; q < big.size(); ++q) {
+            const uint32_t id = big[q];
+            uint32_t mid = 0;
+            BuildNode cur = bn[id];
+            const bool split = splitNode(cur, id == 0, nThreads, mid);
+            bn[id] = cur;
+            if (!split) continue;
+            const int32_t l = (int32_t) bn.size(); bn.emplace_back();
+            const int32_t r = (int32_t) bn.size(); bn.emplace_back();
+            bn[id].left = l; bn[id].right = r;
+            bn[l].first = cur.first; bn[l].count = mid - cur.first; bn[l].depth = cur.depth + 1;
+            bn[r].first = mid; bn[r].count = cur.first + cur.count - mid; bn[r].depth = cur.depth + 1;
+            for (int32_t c : {l, r}) (bn[c].count > kTaskTris ? big : tasks).push_back((uint32_t) c);
+        }
+        lap("top");
+        /* the subtrees, one task each; results are stitched in task order */
+        std::vector<std::vector<BuildNode>> sub(tasks.size());
+        std::atomic<size_t> next(0);
+        auto worker = [&] {
+            for (size_t k; (k = next.fetch_add(1)) < tasks.size(); ) {
+                sub[k].reserve((size_t) bn[tasks[k]].count / 2 + 4);
+                sub[k].push_back(bn[tasks[k]]);
+                buildSubtree(sub[k], 0, false);
+            }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (uint32_t k = 1; k < nThreads; ++k) pool.emplace_back(worker);
+            worker();
+            for (std::thread &t : pool) t.join();
+        }
+        lap("subtrees");
+        for (size_t k = 0; k < tasks.size(); ++k) {
+            const int32_t base = (int32_t) bn.size() - 1;            /* local node i >= 1 -> base + i */
+            auto remap = [&](BuildNode nd) { if (nd.left >= 0) { nd.left += base; nd.right += base; } return nd; };
+            bn[tasks[k]] = remap(sub[k][0]);
+            for (size_t i = 1; i < sub[k].size(); ++i) bn.push_back(remap(sub[k][i]));
+            std::vector<BuildNode>().swap(sub[k]);
+        }
     }
 
+    lap("tree");
     /* leaf triangle records: pairs, leaf by leaf in prim order (rt_types.h) */
     auto isLeaf = [&](int32_t b) { return bn[b].left < 0; };
     std::vector<uint32_t> firstPair(bn.size(), 0);
@@ -381,6 +487,7 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
         out.n_pairs = nPairs;
     }
 
+    lap("pairs");
     /* flatten: one device node per inner build node, DFS pre-order */
     auto leafCode = [&](int32_t b) -> int32_t {
         return (int32_t) ~((firstPair[b] << 3) | ((bn[b].count + 1) / 2 - 1));
@@ -421,6 +528,7 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
         out.root = 0;
         out.n_nodes = nInner;
     }
+    lap("flatten");
     out.n_leaves = nLeaves;
     out.max_depth = maxDepth;
     out.sah_cost = (float) sah;
