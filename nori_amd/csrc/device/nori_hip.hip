@@ -457,7 +457,7 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
 int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     if (!ctx) return NORI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) { ctx->error = "build_accel: no scene uploaded"; return NORI_ERR_NOT_READY; }
-    if (builder == NORI_ACCEL_AUTO) builder = ctx->dev.n_triangles > (1u << 20) ? NORI_ACCEL_GPU_LBVH : NORI_ACCEL_HOST_SAH;
+    if (builder == NORI_ACCEL_AUTO) builder = ctx->dev.n_triangles > (1u << 22) ? NORI_ACCEL_GPU_LBVH : NORI_ACCEL_HOST_SAH;
     if (builder != NORI_ACCEL_HOST_SAH && builder != NORI_ACCEL_GPU_LBVH) { ctx->error = "build_accel: unknown builder"; return NORI_ERR_INVALID_ARGUMENT; }
     DeviceGuard g(ctx->device);
     free_pool(ctx->allocs_accel);

@@ -463,27 +463,33 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
     auto isLeaf = [&](int32_t b) { return bn[b].left < 0; };
     std::vector<uint32_t> firstPair(bn.size(), 0);
     {
-        std::vector<int32_t> leaves;
-        for (size_t b = 0; b < bn.size(); ++b) if (isLeaf((int32_t) b)) leaves.push_back((int32_t) b);
-        std::sort(leaves.begin(), leaves.end(), [&](int32_t a, int32_t b) { return bn[a].first < bn[b].first; });
+        /* leaves in prim order: the leaf that starts at prim position p, if any */
+        std::vector<int32_t> leafAt(n, -1), leaves;
+        for (size_t b = 0; b < bn.size(); ++b) if (isLeaf((int32_t) b)) leafAt[bn[b].first] = (int32_t) b;
+        leaves.reserve(bn.size() / 2 + 1);
         uint32_t nPairs = 0;
-        for (int32_t b : leaves) { firstPair[b] = nPairs; nPairs += (bn[b].count + 1) / 2; }
+        for (uint32_t p = 0; p < n; ++p)
+            if (leafAt[p] >= 0) { const int32_t b = leafAt[p]; leaves.push_back(b); firstPair[b] = nPairs; nPairs += (bn[b].count + 1) / 2; }
         out.tris.assign((size_t) std::max<uint32_t>(nPairs, 1) * kPairQuads, f4{0.0f, 0.0f, 0.0f, 0.0f});
-        for (int32_t b : leaves)
-            for (uint32_t k = 0; k < ((bn[b].count + 1) / 2) * 2; ++k) {
-                f4 *q = &out.tris[(size_t) (firstPair[b] + k / 2) * kPairQuads];
-                if (k >= bn[b].count) {      /* padding: all-zero triangle, never hit */
-                    const float z[3] = {0.0f, 0.0f, 0.0f};
-                    pair_pack(q, (int) (k & 1u), z, z, z, kNoTriangle, kNoTriangle);
-                    continue;
+        parallelFor(0, (uint32_t) leaves.size(), nThreads, [&](uint32_t lo, uint32_t hi, uint32_t) {
+            for (uint32_t li = lo; li < hi; ++li) {
+                const int32_t b = leaves[li];
+                for (uint32_t k = 0; k < ((bn[b].count + 1) / 2) * 2; ++k) {
+                    f4 *q = &out.tris[(size_t) (firstPair[b] + k / 2) * kPairQuads];
+                    if (k >= bn[b].count) {      /* padding: all-zero triangle, never hit */
+                        const float z[3] = {0.0f, 0.0f, 0.0f};
+                        pair_pack(q, (int) (k & 1u), z, z, z, kNoTriangle, kNoTriangle);
+                        continue;
+                    }
+                    const uint32_t g = prim[bn[b].first + k];
+                    const uint32_t *id = &sc.indices[3 * (size_t) g];
+                    const f3 p0 = xyz(sc.positions[id[0]]), p1 = xyz(sc.positions[id[1]]), p2 = xyz(sc.positions[id[2]]);
+                    const f3 e1 = p1 - p0, e2 = p2 - p0;
+                    const float a0[3] = {p0.x, p0.y, p0.z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
+                    pair_pack(q, (int) (k & 1u), a0, a1, a2, g, sc.tri_mesh[g]);
                 }
-                const uint32_t g = prim[bn[b].first + k];
-                const uint32_t *id = &sc.indices[3 * (size_t) g];
-                const f3 p0 = xyz(sc.positions[id[0]]), p1 = xyz(sc.positions[id[1]]), p2 = xyz(sc.positions[id[2]]);
-                const f3 e1 = p1 - p0, e2 = p2 - p0;
-                const float a0[3] = {p0.x, p0.y, p0.z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
-                pair_pack(q, (int) (k & 1u), a0, a1, a2, g, sc.tri_mesh[g]);
             }
+        });
         out.n_pairs = nPairs;
     }
 
