@@ -36,6 +36,7 @@
 #include "../../../include/nori_hip.h"
 #include "film.h"
 #include "ktimer.h"
+#include "shade_tables.h"
 #include "rt_path.h"
 #include "scene_prep.h"
 #include "lbvh.h"
@@ -89,6 +90,8 @@ __global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(D
     const int tid = threadIdx.x;
     if (tid < 16) cnt[tid] = 0u;
     __syncthreads();
+    __shared__ uint4 s_tab[kShadeTabWords / 4];
+    shade_tables_to_lds(sc, s_tab);      /* mesh / emitter tables: LDS instead of L2 round trips (shade_tables.h) */
 
     /* which tile / which samples */
     const uint32_t sel = blockIdx.x / args.n_chunks, chunk = blockIdx.x % args.n_chunks;
@@ -365,7 +368,7 @@ static std::string g_create_error;
 template <class T>
 static int upload(nori_hip_ctx *ctx, std::vector<void *> &pool, const std::vector<T> &v, const T **out) {
     void *d = nullptr;
-    const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    const size_t bytes = (std::max<size_t>(v.size() * sizeof(T), 16) + 15) & ~(size_t) 15;      /* whole 16-B words: tables are copied as uint4 */
     HIP_TRY(ctx, hipMalloc(&d, bytes));
     pool.push_back(d);
     if (!v.empty()) HIP_TRY(ctx, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -449,6 +452,7 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
     d.n_emitters = (uint32_t) h.emitters.size();
     d.n_meshes = (uint32_t) h.meshes.size();
     d.n_triangles = (uint32_t) h.tri_mesh.size();
+    d.n_cdf = (uint32_t) h.emitter_cdf.size();
     d.camera = h.camera; d.filter = h.filter; d.integrator = h.integrator;
     ctx->have_scene = true;
     return NORI_OK;

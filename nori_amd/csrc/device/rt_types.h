@@ -221,6 +221,7 @@ struct DevScene {
     uint32_t n_emitters;
     uint32_t n_meshes;
     uint32_t n_triangles;
+    uint32_t n_cdf;             /* entries of emitter_cdf */
     int32_t root;               /* child-link code of the root */
     CameraRec camera;
     FilterRec filter;

@@ -38,6 +38,7 @@
 
 #include "film.h"
 #include "ktimer.h"
+#include "shade_tables.h"
 #include "rt_path.h"
 #include "wavefront.h"
 
@@ -339,6 +340,8 @@ template <int INTEG, bool FIRST>
 __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
     const WfState S = b.st[cur], D = b.st[cur ^ 1];
     const uint32_t s_first = bt.s_first, n_spp = bt.n_spp;
+    __shared__ uint4 s_tab[kShadeTabWords / 4];
+    shade_tables_to_lds(sc, s_tab);      /* mesh / emitter tables: LDS instead of L2 round trips (shade_tables.h) */
     const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
     const uint32_t rounds_total = (n + kB - 1) / kB;
     const uint32_t rounds_per_block = (rounds_total + gridDim.x - 1) / gridDim.x;
@@ -443,6 +446,8 @@ __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, W
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStackW<16, true> stack;
     stack.init(smem, b.stack_spill, gridDim.x * kB);
+    __shared__ uint4 s_tab[kShadeTabWords / 4];
+    shade_tables_to_lds(sc, s_tab);
     const WfState S = b.st[cur];
     const uint32_t n = b.ctr[C_N + cur];
     const uint32_t per_tile = 256u * bt.n_spp;

@@ -54,6 +54,7 @@ static void bind(emu_ctx *c) {
     d.shade_tris = h.shade_tris.data();
     d.n_emitters = (uint32_t) h.emitters.size(); d.n_meshes = (uint32_t) h.meshes.size();
     d.n_triangles = (uint32_t) h.tri_mesh.size();
+    d.n_cdf = (uint32_t) h.emitter_cdf.size();
     d.root = c->bvh.root;
     d.camera = h.camera; d.filter = h.filter; d.integrator = h.integrator;
 }
