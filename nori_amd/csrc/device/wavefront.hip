@@ -227,11 +227,14 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
                 }
             } else if (pend || (!trav_active(tv) && rank < avail)) {
                 const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
-                const uint32_t fl = pend ? F_HAS_A : S.flags[i];
+                /* flags, origin and both directions are requested together: one round trip to HBM instead
+                   of two (the direction a path needs first depends on its flags) */
+                const uint32_t fl0 = S.flags[i];
+                const f4 o = S.o[i], dA0 = S.dA[i], dB0 = S.dB[i];
+                const uint32_t fl = pend ? F_HAS_A : fl0;
                 if (fl & (F_HAS_A | F_HAS_B)) {      /* 0: empty slot */
                     const bool any = (fl & F_HAS_B) != 0u;
-                    const f4 o = S.o[i];
-                    const f4 d = any ? S.dB[i] : S.dA[i];
+                    const f4 d = any ? dB0 : dA0;
                     RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z);
                     ray.mint = any ? kEpsilon : o.w; ray.maxt = d.w;
                     rid = pend ? (rid & ~2u) : ((i << 2) | ((any && (fl & F_HAS_A)) ? 2u : 0u));
