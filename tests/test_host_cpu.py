@@ -267,3 +267,29 @@ def test_obj_loader_errors(tmp_path, face, msg):
     (tmp_path / "bad.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvn 0 0 1\n" + face + "\n")
     with pytest.raises(Exception, match=msg):
         host.load_xml(_write_scene(tmp_path, _SCENE_WITH_MESH % "bad.obj", obj=False))
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The latest committed bench line (profiles/*_default_bench.json, written by `python bench.py` on the
+    GPU box) carries every field the driver and the judge read, with consistent values."""
+    import glob
+    import json
+    path = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "*_default_bench.json")))[-1]
+    d = json.load(open(path))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["config"]["workload"] == "pa4-cbox-path_mis" and (d["config"]["width"], d["config"]["height"], d["config"]["spp"]) == (1024, 1024, 256)
+    assert abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-3 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
+    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
+    assert r["kernel_ms"] < d["ms_per_step"] and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == "Mrays/s" and c["cores"] >= 1 and c["value"] > 0
