@@ -195,3 +195,12 @@ def test_reference_scenes_both_engines_and_oracle(renderer_factory, name):
     rel = np.abs(x - y) / np.maximum(np.abs(x), 1e-2)
     assert (rel < 1e-3).mean() > 0.97, (rel < 1e-3).mean()
     assert abs(x.mean() - y.mean()) < 5e-3 * max(x.mean(), 1e-3)
+
+
+def test_fuzz_engines_short():
+    """A few rounds of tests/fuzz_engines.py: random scenes / materials / integrators / filters / path budgets,
+    megakernel against wavefront."""
+    from nori_amd.render import Renderer
+    from tests import fuzz_engines
+    for seed in range(2000, 2012):
+        fuzz_engines.one_round(seed, Renderer)
