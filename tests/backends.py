@@ -74,6 +74,7 @@ def emu_lib():
             "emu_accel_info": (C.c_int, [_P, C.POINTER(capi.AccelInfo)]),
             "emu_border_size": (C.c_int, [_P]),
             "emu_intersect": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
+            "emu_packed_vs_scalar": (C.c_size_t, [C.c_size_t, C.c_uint64]),
             "emu_sample_rays": (C.c_int, [_P, _P, C.c_size_t, _P]),
             "emu_li": (C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
             "emu_bsdf_sample": (C.c_int, [C.POINTER(capi.BsdfDesc), _P, _P, C.c_size_t, _P, _P, _P, _P]),

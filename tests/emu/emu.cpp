@@ -215,6 +215,61 @@ int emu_pcg32_floats(const uint64_t *ss, const uint64_t *sq, size_t n, uint32_t 
 
 /* Mirrors render_kernel: tiles, spp chunks, thread<->pixel, splat to a tile,
  * merge tile into the frame. */
+/* Unit check of the packed kernels of rt_trace.h against their scalar statements: n random (triangle pair,
+   ray) and (node, ray) cases from `seed`; returns the number of mismatching results (bit level). */
+size_t emu_packed_vs_scalar(size_t n, uint64_t seed) {
+    Rng r; rng_seed(r, seed, 7);
+    auto rnd = [&](float lo, float hi) { return lo + (hi - lo) * rng_next_float(r); };
+    size_t bad = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float scale = i % 3 == 0 ? 100.0f : (i % 3 == 1 ? 1.0f : 1e-2f);
+        float p0[2][3], e1[2][3], e2[2][3];
+        f4 q[6];
+        for (int k = 0; k < 2; ++k) {
+            for (int a = 0; a < 3; ++a) { p0[k][a] = rnd(-scale, scale); e1[k][a] = rnd(-scale, scale) * 0.3f; e2[k][a] = rnd(-scale, scale) * 0.3f; }
+            if (i % 11 == 5 && k == 1) for (int a = 0; a < 3; ++a) e2[k][a] = 0.5f * e1[k][a];      /* collinear */
+            if (i % 13 == 7 && k == 0) for (int a = 0; a < 3; ++a) e1[k][a] = e2[k][a] = p0[k][a] = 0.0f;      /* padding triangle */
+            pair_pack(q, k, p0[k], e1[k], e2[k], (uint32_t) (2 * i + k), 0u);
+        }
+        const f3 o = mk3(rnd(-scale, scale), rnd(-scale, scale), rnd(-scale, scale));
+        f3 d = mk3(rnd(-1, 1), rnd(-1, 1), rnd(-1, 1));
+        if (i % 7 == 3) d.y = 0.0f;
+        d = normalized(d);
+        const float mint = 1e-4f * scale, maxt = i % 5 == 0 ? scale : kInf;
+        TriPairHit h;
+        tri_pair_test(q[0], q[1], q[2], q[3], q[4], o, d, mint, maxt, h);
+        for (int k = 0; k < 2; ++k) {
+            float u, v, t;
+            const bool ok = tri_test(mk3(p0[k][0], p0[k][1], p0[k][2]), mk3(e1[k][0], e1[k][1], e1[k][2]), mk3(e2[k][0], e2[k][1], e2[k][2]), o, d, u, v, t) &&
+                            t >= mint && t <= maxt;
+            if (ok != h.ok[k]) ++bad;
+            else if (ok && (f2u(u) != f2u(h.u[k]) || f2u(v) != f2u(h.v[k]) || f2u(t) != f2u(h.t[k]))) ++bad;
+        }
+        /* node test: packed slab_two against the scalar slab of bbox.h:323-350 */
+        f4 n[4]; float lmn[3], lmx[3], rmn[3], rmx[3];
+        for (int a = 0; a < 3; ++a) {
+            float x0 = rnd(-scale, scale), x1 = rnd(-scale, scale), y0 = rnd(-scale, scale), y1 = rnd(-scale, scale);
+            lmn[a] = fminf(x0, x1); lmx[a] = i % 9 == 4 ? lmn[a] : fmaxf(x0, x1); rmn[a] = fminf(y0, y1); rmx[a] = fmaxf(y0, y1);
+        }
+        node_pack(lmn, lmx, rmn, rmx, 1, 2, n);
+        const f3 rcp = mk3(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
+        float nl, fl, nr, fr;
+        slab_two(n[0], n[1], n[2], o, rcp, nl, fl, nr, fr);
+        const float oo[3] = {o.x, o.y, o.z}, rr[3] = {rcp.x, rcp.y, rcp.z};
+        for (int side = 0; side < 2; ++side) {
+            const float *mn = side ? rmn : lmn, *mx = side ? rmx : lmx;
+            float tn = -kInf, tf = kInf;
+            for (int a = 0; a < 3; ++a) {
+                const float t1 = (mn[a] - oo[a]) * rr[a], t2 = (mx[a] - oo[a]) * rr[a];
+                tn = fmaxf(tn, fminf(t1, t2)); tf = fminf(tf, fmaxf(t1, t2));
+            }
+            const float gn = side ? nr : nl, gf = side ? fr : fl;
+            if (f2u(tn) != f2u(gn) || f2u(tf) != f2u(gf)) ++bad;
+        }
+    }
+    return bad;
+}
+
 int emu_render(emu_ctx *c, const nori_render_params *p, float *rgbw, nori_render_stats *stats) {
     const DevScene &sc = c->dev;
     const int W = sc.camera.width, H = sc.camera.height, border = sc.filter.border;

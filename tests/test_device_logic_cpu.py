@@ -159,3 +159,13 @@ def test_fuzz_intersect_on_emulated_device_code():
 
     hits = sum(fuzz_intersect.one_round(seed, EmuRenderer, n_rays=5000) for seed in list(range(60)) + [542])
     assert hits > 10000
+
+
+def test_packed_triangle_pair_and_node_tests_equal_the_scalar_statements():
+    """rt_trace.h: tri_pair_test (two Moeller-Trumbore tests on packed f32) and slab_two (both child boxes)
+    give, bit for bit, what the scalar tri_test / the slab test of bbox.h give -- random triangles incl.
+    collinear and padding ones, zero direction components, flat boxes, three coordinate scales."""
+    from tests.backends import emu_lib
+    lib = emu_lib()
+    assert lib.emu_packed_vs_scalar(400000, 12345) == 0
+    assert lib.emu_packed_vs_scalar(100000, 999) == 0
