@@ -41,6 +41,7 @@
 #include "shade_tables.h"
 #include "rt_path.h"
 #include "wavefront.h"
+#include "wf_records.h"
 
 using namespace nrt;
 
@@ -54,10 +55,6 @@ enum { S_CAM = 0, S_CLOSEST = 1, S_SHADOW = 2, S_NODES = 3, S_TRIS = 4, S_INVALI
 /* census (COUNT builds, NORI_HIP_CENSUS): wave-level trips of wf_extend's loop and the lanes they used */
 enum { Z_TRIPS = 0, Z_INNER_TRIPS = 1, Z_INNER_LANES = 2, Z_LEAF_TRIPS = 3, Z_LEAF_LANES = 4, Z_REFILLS = 5, Z_REFILL_LANES = 6, Z_COUNT = 8 };
 
-/* path flags */
-constexpr uint32_t F_HAS_A = 1u, F_HAS_B = 2u, F_END_AFTER_B = 4u;
-/* hit word: low 31 bits = global triangle of the closest hit or kMissA, bit 31 = shadow ray occluded */
-constexpr uint32_t kMissA = 0x7fffffffu, kOccludedB = 0x80000000u;
 constexpr uint32_t kShadeChunk = 4096u;     /* output space a wf_shade workgroup reserves per atomic */
 
 /* The state of the paths in flight, one record per path, structure of arrays.  Two copies: wf_shade
@@ -220,8 +217,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
                         trav_begin(sc, ray, false, stack, tv);
                         ++nClosest; ++nCam;
                         if (!trav_active(tv)) {
-                            f4 h; h.x = kInf; h.y = h.z = 0.0f; h.w = __uint_as_float(kMissA);
-                            b.hit[i] = h;
+                            b.hit[i] = hit_pack(nullptr, false);
                         }
                     }
                 }
@@ -242,8 +238,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
                     if (any) ++nShadow; else ++nClosest;
                     if (!trav_active(tv)) {            /* empty scene: nothing occludes, nothing is hit */
                         if (rid & 2u) { ++nClosest; rid &= ~2u; }
-                        f4 h; h.x = kInf; h.y = h.z = 0.0f; h.w = __uint_as_float(kMissA);
-                        b.hit[i] = h;
+                        b.hit[i] = hit_pack(nullptr, false);
                     }
                 }
             }
@@ -267,12 +262,8 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
             if (rid & 2u) {      /* the shadow ray is answered; the continuation ray of the same vertex is next */
                 rid |= tv.hit.tri != kNoHit ? 1u : 0u;
             } else {
-                f4 h; h.x = tv.hit.t; h.y = tv.hit.u; h.z = tv.hit.v;
-                uint32_t w;
-                if (tv.any) w = kMissA | (tv.hit.tri != kNoHit ? kOccludedB : 0u);      /* a path with a shadow ray only */
-                else w = (tv.hit.tri == kNoHit ? kMissA : tv.hit.tri) | ((rid & 1u) ? kOccludedB : 0u);
-                h.w = __uint_as_float(w);
-                b.hit[rid >> 2] = h;
+                /* a path with a shadow ray only ends on it (tv.any); otherwise the closest hit + the shadow answer */
+                b.hit[rid >> 2] = tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u);
             }
         }
     }
@@ -290,48 +281,6 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
         if (COUNT) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
         if (COUNT && b.census) for (int k = 0; k < Z_COUNT; ++k) if (zc[k]) atomicAdd(&b.census[k], (unsigned long long) zc[k]);
     }
-}
-
-/* state record <-> PathState (rt_path.h) */
-__device__ __forceinline__ void vertex_unpack(PathState &st, uint32_t fl, const f4 &L4, const f4 &t4, uint64_t rng_state, uint64_t rng_inc) {
-    st.L = mk3(L4.x, L4.y, L4.z);
-    st.T = mk3(t4.x, t4.y, t4.z); st.eta = t4.w; st.pdf_mat = L4.w;
-    st.Ld = mk3(0.0f); st.cont_d = mk3(0.0f);
-    st.prev_measure = (int32_t) ((fl >> 4) & 3u); st.depth = (int32_t) (fl >> 8);
-    st.phase = PH_CLOSEST; st.end_after_shadow = 0;
-    st.ray.o = st.ray.d = mk3(0.0f); st.ray.mint = st.ray.maxt = 0.0f;
-    st.rng.inc = rng_inc; st.rng.state = rng_state;
-}
-
-/* the surviving path's next record: origin, continuation ray (slot A), shadow ray (slot B) */
-__device__ __forceinline__ void vertex_pack(const PathState &st, f4 &o, f4 &dA, f4 &dB, f4 &T, f4 &L, f4 &Ld, uint32_t &fl) {
-    o.x = st.ray.o.x; o.y = st.ray.o.y; o.z = st.ray.o.z;
-    fl = ((uint32_t) st.prev_measure << 4) | ((uint32_t) st.depth << 8);
-    if (st.phase == PH_SHADOW) {
-        dB.x = st.ray.d.x; dB.y = st.ray.d.y; dB.z = st.ray.d.z; dB.w = st.ray.maxt;
-        Ld.x = st.Ld.x; Ld.y = st.Ld.y; Ld.z = st.Ld.z; Ld.w = 0.0f;
-        fl |= F_HAS_B;
-        o.w = kEpsilon;
-        if (st.end_after_shadow) fl |= F_END_AFTER_B;
-        else {
-            dA.x = st.cont_d.x; dA.y = st.cont_d.y; dA.z = st.cont_d.z; dA.w = kInf;
-            fl |= F_HAS_A;
-        }
-    } else {
-        dA.x = st.ray.d.x; dA.y = st.ray.d.y; dA.z = st.ray.d.z; dA.w = st.ray.maxt;
-        fl |= F_HAS_A;
-        o.w = st.ray.mint;
-    }
-    T.x = st.T.x; T.y = st.T.y; T.z = st.T.z; T.w = st.eta;
-    L.x = st.L.x; L.y = st.L.y; L.z = st.L.z; L.w = st.pdf_mat;
-}
-
-__device__ __forceinline__ void hit_unpack(const DevScene &sc, const f4 &h, Hit &hit, bool &found) {
-    const uint32_t hw = __float_as_uint(h.w);
-    hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = hw & kMissA;
-    found = hit.tri != kMissA;
-    if (!found) hit.tri = kNoHit;
-    hit.mesh = found ? f2u(sc.shade_tris[(size_t) hit.tri * kShadeQuads].w) : kNoHit;      /* same fetch as p0 */
 }
 
 /* Integrator::Li, one vertex: consume the shadow result, shade the closest hit, write the surviving

@@ -77,6 +77,7 @@ def emu_lib():
             "emu_packed_vs_scalar": (C.c_size_t, [C.c_size_t, C.c_uint64]),
             "emu_sample_rays": (C.c_int, [_P, _P, C.c_size_t, _P]),
             "emu_li": (C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
+            "emu_li_records": (C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
             "emu_bsdf_sample": (C.c_int, [C.POINTER(capi.BsdfDesc), _P, _P, C.c_size_t, _P, _P, _P, _P]),
             "emu_bsdf_eval": (C.c_int, [C.POINTER(capi.BsdfDesc), _P, _P, C.c_size_t, _P]),
             "emu_bsdf_pdf": (C.c_int, [C.POINTER(capi.BsdfDesc), _P, _P, C.c_size_t, _P]),

@@ -20,6 +20,7 @@
 
 #include "../../include/nori_hip.h"
 #include "emu_film.h"
+#include "../../nori_amd/csrc/device/wf_records.h"
 #include "../../nori_amd/csrc/device/rt_path.h"
 #include "../../nori_amd/csrc/device/scene_prep.h"
 
@@ -87,6 +88,48 @@ static f3 run_path_dyn(const DevScene &sc, PathState &st, ArrayStack &stack, uin
 }
 
 struct PlainAdd { void operator()(float *p, float v) const { *p += v; } };
+
+/* Integrator::Li the way the wavefront engine walks a path (wavefront.hip: wf_extend / wf_shade / wf_finish):
+   per vertex the shadow ray, then the continuation ray, the answers squeezed through the 16-B hit record, the
+   path through the state records of wf_records.h.  Must equal emu_li bit for bit. */
+template <int INTEG>
+static f3 run_path_records(const DevScene &sc, const RayIn &cam, uint64_t rng_state, uint64_t rng_inc, ArrayStack &stack, TraversalCounters &tc) {
+    f4 o, dA, dB, T, L, Ld;
+    o.x = cam.o.x; o.y = cam.o.y; o.z = cam.o.z; o.w = cam.mint;
+    dA.x = cam.d.x; dA.y = cam.d.y; dA.z = cam.d.z; dA.w = cam.maxt;
+    dB = dA; Ld.x = Ld.y = Ld.z = Ld.w = 0.0f;
+    T.x = T.y = T.z = T.w = 1.0f; L.x = L.y = L.z = L.w = 0.0f;
+    uint32_t fl = F_HAS_A | (2u << 4);
+    while (true) {
+        bool occluded = false;
+        if (fl & F_HAS_B) {
+            RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(dB.x, dB.y, dB.z); ray.mint = kEpsilon; ray.maxt = dB.w;
+            Hit sh; occluded = traverse<false>(sc, ray, true, stack, sh, tc);
+        }
+        f4 h;
+        if (fl & F_HAS_A) {
+            RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(dA.x, dA.y, dA.z); ray.mint = o.w; ray.maxt = dA.w;
+            Hit hit; (void) traverse<false>(sc, ray, false, stack, hit, tc);
+            h = hit_pack(&hit, occluded);
+        } else {
+            h = hit_pack(nullptr, occluded);
+        }
+        /* wf_shade */
+        if ((fl & F_HAS_B) && !(f2u(h.w) & kOccludedB)) { L.x = L.x + Ld.x; L.y = L.y + Ld.y; L.z = L.z + Ld.z; }
+        if (fl & F_END_AFTER_B) break;
+        Hit hit; bool found;
+        hit_unpack(sc, h, hit, found);
+        PathState st;
+        vertex_unpack(st, fl, L, T, rng_state, rng_inc);
+        const bool done = path_on_closest<INTEG>(sc, st, hit, found, mk3(dA.x, dA.y, dA.z));
+        L.x = st.L.x; L.y = st.L.y; L.z = st.L.z;
+        if (done) break;
+        vertex_pack(st, o, dA, dB, T, L, Ld, fl);
+        rng_state = st.rng.state;
+    }
+    return mk3(L.x, L.y, L.z);
+}
+
 
 extern "C" {
 
@@ -169,6 +212,28 @@ int emu_li(emu_ctx *c, const nori_ray *rays, size_t n, const uint64_t *ss, const
         }
     });
     for (auto &t : th) t.join();
+    return NORI_OK;
+}
+
+int emu_li_records(emu_ctx *c, const nori_ray *rays, size_t n, const uint64_t *ss, const uint64_t *sq, float *rgb) {
+    const DevScene &sc = c->dev;
+    ArrayStack stack; TraversalCounters tc; tc.nodes = tc.tris = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const nori_ray &r = rays[i];
+        RayIn ray; ray.o = mk3(r.o[0], r.o[1], r.o[2]); ray.d = mk3(r.d[0], r.d[1], r.d[2]); ray.mint = r.mint; ray.maxt = r.maxt;
+        Rng g; rng_seed(g, ss[i], sq[i]);
+        f3 L;
+        switch (sc.integrator.type) {
+        case 0: L = run_path_records<0>(sc, ray, g.state, g.inc, stack, tc); break;
+        case 1: L = run_path_records<1>(sc, ray, g.state, g.inc, stack, tc); break;
+        case 2: L = run_path_records<2>(sc, ray, g.state, g.inc, stack, tc); break;
+        case 3: L = run_path_records<3>(sc, ray, g.state, g.inc, stack, tc); break;
+        case 4: L = run_path_records<4>(sc, ray, g.state, g.inc, stack, tc); break;
+        case 5: L = run_path_records<5>(sc, ray, g.state, g.inc, stack, tc); break;
+        default: L = run_path_records<6>(sc, ray, g.state, g.inc, stack, tc); break;
+        }
+        rgb[3 * i] = L.x; rgb[3 * i + 1] = L.y; rgb[3 * i + 2] = L.z;
+    }
     return NORI_OK;
 }
 

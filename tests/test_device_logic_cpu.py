@@ -169,3 +169,26 @@ def test_packed_triangle_pair_and_node_tests_equal_the_scalar_statements():
     lib = emu_lib()
     assert lib.emu_packed_vs_scalar(400000, 12345) == 0
     assert lib.emu_packed_vs_scalar(100000, 999) == 0
+
+
+@pytest.mark.parametrize("integ", ["normals", "ao", "simple", "whitted", "path_mats", "path_ems", "path_mis"])
+def test_wavefront_records_walk_equals_the_direct_path_loop(integ):
+    """wf_records.h: a path walked the way the wavefront engine does -- shadow ray, continuation ray, the answers
+    through the 16-B hit record, the path through the flag / state records every vertex -- gives bit for bit
+    the radiance of the direct per-lane loop (the megakernel's), for every integrator and BSDF."""
+    sb = [Bsdf("mirror"), Bsdf("dielectric")] if integ in ("whitted", "path_mis") else [Bsdf("microfacet", (0.2, 0.3, 0.1), 0.2), Bsdf("diffuse")]
+    sc = scenes.cornell_box(32, 32, 1, integ, sphere_bsdfs=sb)
+    sc.integrator.position, sc.integrator.energy = (0, 1.5, 0.5), (30, 30, 30)
+    e = Emu(sc)
+    n = 6000
+    ps = np.random.default_rng(5).uniform(0, 32, (n, 2)).astype(np.float32)
+    rays = e.sample_rays(ps)
+    ss = np.arange(n, dtype=np.uint64) * 7 + 1
+    sq = np.arange(n, dtype=np.uint64) + 11
+    a = e.li(rays, ss, sq)
+    b = np.zeros((n, 3), np.float32)
+    from tests.backends import ptr
+    assert e.lib.emu_li_records(e._h, ptr(rays), n, ptr(ss), ptr(sq), ptr(b)) == 0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert (a.sum(1) > 0).mean() > 0.01          # the comparison is not vacuous (path_mats: only light hits count)
+    e.close()
