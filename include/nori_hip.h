@@ -330,6 +330,13 @@ int nori_hip_warp_pdf(nori_hip_ctx *ctx, int warp, float param,
 int nori_hip_pcg32_floats(nori_hip_ctx *ctx, const uint64_t *seed_state,
                           const uint64_t *seed_seq, size_t n, uint32_t count,
                           float *out);
+/* The same streams `skip` draws further (pcg32::advance): out[k*count + j] = float number
+ * skip + j of pcg32.seed(seed_state[k], seed_seq[k]).  This is how the host's Independent sampler
+ * continues ONE stream seeded by prepare(block) = seed(offset.x, offset.y)
+ * (src/independent.cpp:36-41) across refills of its buffer. */
+int nori_hip_pcg32_floats_at(nori_hip_ctx *ctx, const uint64_t *seed_state,
+                             const uint64_t *seed_seq, uint64_t skip, size_t n,
+                             uint32_t count, float *out);
 
 /* ImageBlock::put(pos, value) (src/block.cpp:62-91) of n samples into the
  * full-frame RGBW buffer `rgbw` (HOST memory, layout as in

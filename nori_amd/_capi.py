@@ -129,6 +129,7 @@ HIP_PROTOTYPES = {
     "nori_hip_warp": (C.c_int, [_P, C.c_int, C.c_float, _P, C.c_size_t, _P]),
     "nori_hip_warp_pdf": (C.c_int, [_P, C.c_int, C.c_float, _P, C.c_size_t, _P]),
     "nori_hip_pcg32_floats": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_uint32, _P]),
+    "nori_hip_pcg32_floats_at": (C.c_int, [_P, _P, _P, C.c_uint64, C.c_size_t, C.c_uint32, _P]),
     "nori_hip_splat": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
     "nori_hip_render": (C.c_int, [_P, C.POINTER(RenderParams), _P, C.POINTER(RenderStats)]),
     "nori_hip_render_host": (C.c_int, [_P, C.POINTER(RenderParams), _P, C.POINTER(RenderStats)]),

@@ -49,14 +49,15 @@ NORI_HD void film_tile_pixel(int pix, int x0, int y0, int &px, int &py) {
     py = y0 + ((wave >> 1) << 3) + (lane >> 3);
 }
 
-/* (Re)allocate the process-wide store; zeroes the tile accumulators.  "" or an error. */
-std::string film_prepare(size_t n_samples, size_t n_sel_tiles, int tile_w, void *stream, FilmStore &out);
+/* (Re)allocate the context's store `store` (owned by nori_hip_ctx, grown on demand, freed by film_release);
+   zeroes the tile accumulators; `out` = the view to launch with.  "" or an error. */
+std::string film_prepare(FilmStore &store, size_t n_samples, size_t n_sel_tiles, int tile_w, void *stream, FilmStore &out);
 /* splat the store's samples of tiles [tile_first, tile_first + n_tiles) into their accumulators */
 void film_gather(const DevScene &sc, const float *d_filter_table, const FilmStore &st, const FilmLaunch &fl, void *stream);
 /* add all accumulators into the caller's RGBW frame */
 void film_resolve(const DevScene &sc, const FilmStore &st, const FilmLaunch &fl, float *d_rgbw, void *stream);
 /* samples dropped by the isValid() guard (src/block.cpp:63-67) since film_prepare; synchronises `stream` */
 unsigned long long film_invalid_count(const FilmStore &st, void *stream);
-void film_release();
+void film_release(FilmStore &store);
 
 } // namespace nrt

@@ -21,7 +21,7 @@ constexpr int kMaxBorder = 8;                  /* (16 + 2 * 8)^2 / 256 = 4 outpu
  *     pos   = p - 0.5 - (block_offset - border)
  *     pixel x is touched iff ceil(pos.x - r) <= x <= floor(pos.x + r)   <=>  pos.x - r <= x <= pos.x + r
  *     wx[x] = filter[(int)(|x - pos.x| * lookupFactor)],  wy[y] likewise       (block.cpp:79-84)
- *     px   += (r, g, b, 1) * (wx[x] * wy[y])                                    (block.cpp:86-88)
+ *     px   += ((r, g, b, 1) * wx[x]) * wy[y]                                    (block.cpp:88-90)
  * A sample of tile pixel (sx, sy) reaches the output pixels (sx + k, sy + m), k, m in [0, 2 border]
  * of the bordered tile frame: 2 border + 1 taps per axis, zero where out of the filter's reach or
  * for samples the isValid() guard (block.cpp:63-67) rejects. */
@@ -100,8 +100,9 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
                     const int sx = ox - k;
                     if (sx < 0 || sx >= kTile) continue;
                     const int r = sy * kTile + sx;
-                    const float w = s_wx[k][r] * s_wy[m][r];
-                    acc[o].x += s_Lr[r] * w; acc[o].y += s_Lg[r] * w; acc[o].z += s_Lb[r] * w; acc[o].w += w;
+                    /* Color4f(value) * wx * wy, left to right (block.cpp:88-90): (L * wx) * wy per channel, W = (1 * wx) * wy */
+                    const float wx = s_wx[k][r], wy = s_wy[m][r];
+                    acc[o].x += (s_Lr[r] * wx) * wy; acc[o].y += (s_Lg[r] * wx) * wy; acc[o].z += (s_Lb[r] * wx) * wy; acc[o].w += wx * wy;
                 }
             }
         }
@@ -148,16 +149,13 @@ __global__ void film_resolve_kernel(int width, int height, int border, int tile_
     *dst = cur;
 }
 
-FilmStore g_film;
-int g_film_device = -1;
-
 } // namespace
 
 namespace nrt {
 
 #define FILM_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e__); } while (0)
 
-void film_release() {
+void film_release(FilmStore &g_film) {
     if (g_film.pos) (void) hipFree(g_film.pos);
     if (g_film.L) (void) hipFree(g_film.L);
     if (g_film.tile_acc) (void) hipFree(g_film.tile_acc);
@@ -165,9 +163,7 @@ void film_release() {
     g_film = FilmStore();
 }
 
-std::string film_prepare(size_t n_samples, size_t n_sel_tiles, int tile_w, void *stream, FilmStore &out) {
-    int dev = 0; (void) hipGetDevice(&dev);
-    if (dev != g_film_device) { film_release(); g_film_device = dev; }
+std::string film_prepare(FilmStore &g_film, size_t n_samples, size_t n_sel_tiles, int tile_w, void *stream, FilmStore &out) {
     if (g_film.capacity < n_samples) {
         if (g_film.pos) (void) hipFree(g_film.pos);
         if (g_film.L) (void) hipFree(g_film.L);

@@ -295,10 +295,11 @@ __global__ void warp_kernel(int warp, float param, int pdf, const float *in, siz
     }
 }
 
-__global__ void pcg32_kernel(const uint64_t *state, const uint64_t *seq, size_t n, uint32_t count, float *out) {
+__global__ void pcg32_kernel(const uint64_t *state, const uint64_t *seq, uint64_t skip, size_t n, uint32_t count, float *out) {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Rng r; rng_seed(r, state[i], seq[i]);
+    if (skip) rng_advance(r, skip);
     for (uint32_t j = 0; j < count; ++j) out[i * count + j] = rng_next_float(r);
 }
 
@@ -352,6 +353,10 @@ struct nori_hip_ctx {
     uint64_t lbvh_bytes = 0;
     int engine = -1;                /* -1 auto, 0 megakernel, 1 wavefront */
     size_t wavefront_paths = (size_t) 1 << 28;     /* 240 B of state each (two copies) + film: ~80 GB of the 288 GB */
+    /* render-time resources of THIS context (never shared, freed in nori_hip_destroy): the wavefront
+       engine's state pool / streams / events and the film's sample store + tile accumulators */
+    WfEngine *wf = nullptr;
+    FilmStore film;
 };
 
 static std::string g_create_error;
@@ -361,7 +366,8 @@ static std::string g_create_error;
         hipError_t e__ = (expr);                                                                   \
         if (e__ != hipSuccess) {                                                                   \
             (ctx)->error = std::string(#expr) + ": " + hipGetErrorString(e__);                     \
-            return e__ == hipErrorOutOfMemory ? NORI_ERR_OUT_OF_MEMORY : NORI_ERR_NO_DEVICE;       \
+            return e__ == hipErrorOutOfMemory ? NORI_ERR_OUT_OF_MEMORY :                          \
+                   (e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice) ? NORI_ERR_NO_DEVICE : NORI_ERR_INTERNAL; \
         }                                                                                          \
     } while (0)
 
@@ -406,6 +412,7 @@ int nori_hip_create(int device, nori_hip_ctx **out) {
     DeviceGuard g(device);
     e = hipMalloc((void **) &ctx->d_stats, 16 * sizeof(unsigned long long));
     if (e != hipSuccess) { g_create_error = std::string("hipMalloc: ") + hipGetErrorString(e); delete ctx; return NORI_ERR_NO_DEVICE; }
+    ctx->wf = wavefront_create();
     *out = ctx;
     return NORI_OK;
 }
@@ -414,8 +421,8 @@ void nori_hip_destroy(nori_hip_ctx *ctx) {
     if (!ctx) return;
     DeviceGuard g(ctx->device);
     free_pool(ctx->allocs_scene); free_pool(ctx->allocs_accel);
-    wavefront_release();
-    film_release();
+    wavefront_destroy(ctx->wf);
+    film_release(ctx->film);
     if (ctx->d_stats) (void) hipFree(ctx->d_stats);
     delete ctx;
 }
@@ -696,13 +703,17 @@ int nori_hip_warp_pdf(nori_hip_ctx *ctx, int warp, float param, const float *poi
 }
 
 int nori_hip_pcg32_floats(nori_hip_ctx *ctx, const uint64_t *seed_state, const uint64_t *seed_seq, size_t n, uint32_t count, float *out) {
+    return nori_hip_pcg32_floats_at(ctx, seed_state, seed_seq, 0, n, count, out);
+}
+
+int nori_hip_pcg32_floats_at(nori_hip_ctx *ctx, const uint64_t *seed_state, const uint64_t *seed_seq, uint64_t skip, size_t n, uint32_t count, float *out) {
     if (!ctx || !seed_state || !seed_seq || !out) return NORI_ERR_INVALID_ARGUMENT;
     if (n == 0 || count == 0) return NORI_OK;
     DeviceGuard g(ctx->device);
     SCRATCH_IN(ctx, ds, seed_state, n * sizeof(uint64_t));
     SCRATCH_IN(ctx, dq, seed_seq, n * sizeof(uint64_t));
     SCRATCH_OUT(ctx, dout, n * count * sizeof(float));
-    hipLaunchKernelGGL(pcg32_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, (const uint64_t *) ds.p, (const uint64_t *) dq.p, n, count, (float *) dout.p);
+    hipLaunchKernelGGL(pcg32_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, 0, (const uint64_t *) ds.p, (const uint64_t *) dq.p, skip, n, count, (float *) dout.p);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpy(out, dout.p, n * count * sizeof(float), hipMemcpyDeviceToHost));
     return NORI_OK;
@@ -802,7 +813,11 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
     plan_chunks(a);
     unsigned long long n_invalid = 0; uint32_t n_workgroups = 0;
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    struct EventPair {      /* destroyed on every return path */
+        hipEvent_t a = nullptr, b = nullptr;
+        ~EventPair() { if (a) (void) hipEventDestroy(a); if (b) (void) hipEventDestroy(b); }
+    } evp;
+    hipEvent_t &ev0 = evp.a, &ev1 = evp.b;
     if (stats) {
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_stats, 0, 16 * sizeof(unsigned long long), s));
         HIP_TRY(ctx, hipEventCreate(&ev0)); HIP_TRY(ctx, hipEventCreate(&ev1));
@@ -823,9 +838,19 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         wl.stack_depth = (int) need;
         wl.count_traversal = params->count_traversal != 0;
         wl.time_kernels = stats && params->time_kernels != 0;
+        /* paths in flight: the option, bounded by what this GPU has free right now (state already held by
+           this context counts as free) -- a second context or another process may own part of the HBM */
         wl.max_paths = ctx->wavefront_paths;
-        std::string err = wavefront_render(ctx->dev, ctx->d_filter, wl, (float *) d_rgbw, s, wst);
-        if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const size_t usable = (size_t) ((double) (free_b + wavefront_held_bytes(ctx->wf, ctx->film)) * 0.85);
+            wl.max_paths = std::max<size_t>(256, std::min(wl.max_paths, usable / wavefront_bytes_per_path()));
+        }
+        std::string err = wavefront_render(*ctx->wf, ctx->film, ctx->dev, ctx->d_filter, wl, (float *) d_rgbw, s, wst);
+        if (!err.empty()) {
+            ctx->error = err;
+            return err.find("out of memory") != std::string::npos ? NORI_ERR_OUT_OF_MEMORY : NORI_ERR_INTERNAL;
+        }
     } else
     if (a.n_sel_tiles > 0 && a.spp_count > 0) {
         /* Samples go to the film store (24 B each); if a call produces more than the store
@@ -834,7 +859,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         if (const char *e = getenv("NORI_HIP_FILM_SAMPLES")) cap = (size_t) std::max(256ll, atoll(e));
         const uint32_t spp_per_launch = (uint32_t) std::max<size_t>(1, std::min<size_t>(a.spp_count, cap / ((size_t) a.n_sel_tiles * 256)));
         FilmStore film;
-        std::string ferr = film_prepare((size_t) a.n_sel_tiles * 256 * spp_per_launch, a.n_sel_tiles, a.tile_w, s, film);
+        std::string ferr = film_prepare(ctx->film, (size_t) a.n_sel_tiles * 256 * spp_per_launch, a.n_sel_tiles, a.tile_w, s, film);
         if (!ferr.empty()) { ctx->error = ferr; return NORI_ERR_OUT_OF_MEMORY; }
         FilmLaunch fl;
         fl.tile_first = 0; fl.store_tile_first = 0; fl.n_tiles = a.n_sel_tiles; fl.tile_mod = a.tile_mod; fl.tile_rem = a.tile_rem;
@@ -871,7 +896,6 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         HIP_TRY(ctx, hipEventSynchronize(ev1));
         float ms = 0.0f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ev0, ev1));
-        (void) hipEventDestroy(ev0); (void) hipEventDestroy(ev1);
         unsigned long long h[16];
         HIP_TRY(ctx, hipMemcpy(h, ctx->d_stats, sizeof(h), hipMemcpyDeviceToHost));
         memset(stats, 0, sizeof(*stats));

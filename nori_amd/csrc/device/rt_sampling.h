@@ -30,6 +30,18 @@ NORI_HD void rng_seed(Rng &r, uint64_t initstate, uint64_t initseq) {
     r.state += initstate;
     rng_next_uint(r);
 }
+/* pcg32::advance(delta): the LCG state `delta` draws further, in O(log delta) (Brown, "Random number
+   generation with arbitrary strides"): state' = a^delta * state + c (a^delta - 1) / (a - 1) */
+NORI_HD void rng_advance(Rng &r, uint64_t delta) {
+    uint64_t cur_mult = 0x5851f42d4c957f2dULL, cur_plus = r.inc, acc_mult = 1u, acc_plus = 0u;
+    while (delta > 0) {
+        if (delta & 1u) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+        cur_plus = (cur_mult + 1u) * cur_plus;
+        cur_mult *= cur_mult;
+        delta >>= 1u;
+    }
+    r.state = acc_mult * r.state + acc_plus;
+}
 /* Independent::next1D -> pcg32::nextFloat: [0,1) from the top 23 bits */
 NORI_HD float rng_next_float(Rng &r) {
     return u2f((rng_next_uint(r) >> 9) | 0x3f800000u) - 1.0f;

@@ -94,7 +94,7 @@ NORI_HD f3 to_world(const Frame &f, f3 v) { return (f.s * v.x + f.t * v.y) + f.n
 /* Padding of a triangle's box in the BVH builders.  The node test must never cull a triangle whose
  * Moeller-Trumbore test (src/mesh.cpp:39-76, float arithmetic) would accept the ray.  For a well-shaped
  * triangle the accepted region exceeds the exact triangle by rounding only, covered by `pad`
- * (2e-5 x scene diagonal).  The rounding error of det = e1 . (d x e2) is ~2^-23 |e1||e2|, so relative
+ * (kBoxPadRel = 2e-6 x scene diagonal).  The rounding error of det = e1 . (d x e2) is ~2^-23 |e1||e2|, so relative
  * to det it grows like 1 / sin(angle between the edges): a sliver's accepted region is wider by that
  * factor, and for (numerically) collinear vertices u, v, t are noise and the reference's linear scan
  * can report a hit for a ray that passes nowhere near the triangle -- even outside the scene's box.

@@ -135,8 +135,11 @@ std::string prepare_scene(const nori_scene_desc &desc, HostScene &out) {
                 out.emitter_cdf.push_back(out.emitter_cdf.back() + area);
             }
             const float sum = out.emitter_cdf.back();
+            /* a light without area cannot be sampled (pdf 1 / area): fail at load time instead of feeding inf / NaN
+               emitter samples to the film's isValid() guard */
+            if (!(sum > 0.0f) || !(sum < kInf)) return "area emitter attached to a mesh of zero (or non-finite) surface area";
             float normalization = 0.0f;
-            if (sum > 0) {
+            {
                 normalization = 1.0f / sum;
                 for (uint32_t t = 1; t <= m.n_triangles; ++t) out.emitter_cdf[rec.cdf_offset + t] *= normalization;
                 out.emitter_cdf[rec.cdf_offset + m.n_triangles] = 1.0f;

@@ -3,6 +3,7 @@
 #include <string>
 
 #include "../../../include/nori_hip.h"
+#include "film.h"
 #include "rt_types.h"
 
 namespace nrt {
@@ -26,12 +27,19 @@ struct WfStats {
     uint32_t class_launches[3] = {0, 0, 0};
 };
 
-/* Renders the selected tiles / samples into d_rgbw (accumulating), on `stream`.
- * Synchronises the stream.  Returns "" or an error message. */
-std::string wavefront_render(const DevScene &sc, const float *d_filter_table, const WfLaunch &launch, float *d_rgbw,
-                             void *stream, WfStats &stats);
+/* The engine's per-context resources (path-state pool, pipe streams / events, device properties);
+ * created on the context's device, owned by nori_hip_ctx, never shared between contexts. */
+struct WfEngine;
+WfEngine *wavefront_create();
+void wavefront_destroy(WfEngine *);
+/* HBM bytes one path in flight costs (two state copies + hit record + its film sample): sizes max_paths */
+size_t wavefront_bytes_per_path();
+/* device bytes this context already holds for rendering (they are reusable, so they count as free) */
+size_t wavefront_held_bytes(const WfEngine *engine, const FilmStore &film);
 
-/* frees the cached device buffers of this process (called from nori_hip_destroy) */
-void wavefront_release();
+/* Renders the selected tiles / samples into d_rgbw (accumulating), on `stream`, with the context's
+ * engine resources and film store.  Synchronises the stream.  Returns "" or an error message. */
+std::string wavefront_render(WfEngine &engine, FilmStore &film_store, const DevScene &sc, const float *d_filter_table,
+                             const WfLaunch &launch, float *d_rgbw, void *stream, WfStats &stats);
 
 } // namespace nrt

@@ -466,7 +466,6 @@ struct Pool {
     uint32_t *h_ctr = nullptr; /* pinned */
     int *spill = nullptr;      /* traversal-stack overflow of wf_extend, one column per lane and pipe */
     size_t spill_ints = 0;
-    int device = -1;
     void release() {
         for (void *p : allocs) (void) hipFree(p);
         allocs.clear(); capacity = 0; bytes = 0;
@@ -474,26 +473,26 @@ struct Pool {
         if (h_ctr) { (void) hipHostFree(h_ctr); h_ctr = nullptr; }
     }
 };
-Pool g_pool;
 
 #define WF_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e__); } while (0)
 
-template <class T> std::string pool_alloc(T **out, size_t count) {
+template <class T> std::string pool_alloc(Pool &pool, T **out, size_t count) {
     void *p = nullptr;
     WF_TRY(hipMalloc(&p, std::max<size_t>(count * sizeof(T), 16)));
-    g_pool.allocs.push_back(p); g_pool.bytes += count * sizeof(T);
+    pool.allocs.push_back(p); pool.bytes += count * sizeof(T);
     *out = reinterpret_cast<T *>(p);
     return std::string();
 }
 
-std::string ensure_pool(size_t records) {
-    int dev = 0; (void) hipGetDevice(&dev);
-    if (g_pool.capacity >= records && g_pool.device == dev) return std::string();
-    g_pool.release();
-    g_pool.device = dev;
-    WfBuf &b = g_pool.buf;
+/* bytes of path state per record: two copies of the SoA state + the hit record */
+constexpr size_t kStateBytesPerRecord = 2 * (6 * sizeof(f4) + 2 * sizeof(uint32_t) + sizeof(unsigned long long)) + sizeof(f4);
+
+std::string ensure_pool(Pool &pool, size_t records) {
+    if (pool.capacity >= records) return std::string();
+    pool.release();
+    WfBuf &b = pool.buf;
     std::string e;
-#define A(field, count) if (!(e = pool_alloc(&b.field, (count))).empty()) return e
+#define A(field, count) if (!(e = pool_alloc(pool, &b.field, (count))).empty()) { pool.release(); return e; }
     for (int k = 0; k < 2; ++k) {
         A(st[k].o, records); A(st[k].dA, records); A(st[k].dB, records);
         A(st[k].T_eta, records); A(st[k].L_pdf, records); A(st[k].Ld, records);
@@ -502,8 +501,8 @@ std::string ensure_pool(size_t records) {
     A(hit, records);
     A(ctr, (size_t) 2 * C_COUNT); A(stats, (size_t) 2 * S_COUNT);
 #undef A
-    WF_TRY(hipHostMalloc((void **) &g_pool.h_ctr, 2 * C_COUNT * sizeof(uint32_t)));
-    g_pool.capacity = records;
+    WF_TRY(hipHostMalloc((void **) &pool.h_ctr, 2 * C_COUNT * sizeof(uint32_t)));
+    pool.capacity = records;
     return std::string();
 }
 
@@ -550,7 +549,38 @@ void launch_finish(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &b
 
 namespace nrt {
 
-void wavefront_release() { g_pool.release(); }
+/* Everything a context keeps between render calls: the path-state pool, the pipes' streams and
+   events, what the device offers.  One per nori_hip_ctx (= per GPU); nothing here is process-global,
+   so contexts on different devices, or two contexts on one device, never share or free each
+   other's buffers. */
+struct WfEngine {
+    Pool pool;
+    hipStream_t streams[2] = {nullptr, nullptr};
+    hipEvent_t events[3] = {nullptr, nullptr, nullptr};
+    int n_cus = 0;                  /* hipDeviceProp_t::multiProcessorCount of the context's device */
+};
+
+WfEngine *wavefront_create() {
+    WfEngine *e = new WfEngine();
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) e->n_cus = prop.multiProcessorCount;
+    if (e->n_cus <= 0) e->n_cus = 256;
+    return e;
+}
+
+void wavefront_destroy(WfEngine *e) {
+    if (!e) return;
+    e->pool.release();
+    for (hipStream_t &st : e->streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
+    for (hipEvent_t &ev : e->events) if (ev) { (void) hipEventDestroy(ev); ev = nullptr; }
+    delete e;
+}
+
+size_t wavefront_bytes_per_path() { return kStateBytesPerRecord + sizeof(f2) + sizeof(f4); }
+
+size_t wavefront_held_bytes(const WfEngine *e, const FilmStore &film) {
+    return (e ? e->pool.bytes : 0) + film.capacity * (sizeof(f2) + sizeof(f4));
+}
 
 /* A pipe works through its own list of batches with its own slice of the state pool, on its own
    HIP stream.  Two pipes interleave so that one pipe's wf_shade (HBM-bound) overlaps the other
@@ -564,12 +594,10 @@ struct Pipe {
     uint32_t tiles_b = 0, spp_b = 0;        /* batch geometry */
     uint32_t t0 = 0, s0 = 0;                /* next batch */
     bool active = false, finished = false, first = false;
+    uint32_t batch_rounds = 0;               /* host-loop rounds spent on the current batch */
     WfBatch bt;
     int cur = 0;
 };
-
-static hipStream_t g_streams[2] = {nullptr, nullptr};
-static hipEvent_t g_events[3] = {nullptr, nullptr, nullptr};
 
 static WfBuf slice(const WfBuf &b, size_t off, size_t records, int k) {
     WfBuf v = b;
@@ -584,8 +612,12 @@ static WfBuf slice(const WfBuf &b, size_t off, size_t records, int k) {
     return v;
 }
 
-std::string wavefront_render(const DevScene &sc, const float *d_filter_table, const WfLaunch &L, float *d_rgbw, void *stream_, WfStats &stats) {
+std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScene &sc, const float *d_filter_table, const WfLaunch &L,
+                             float *d_rgbw, void *stream_, WfStats &stats) {
     hipStream_t s = (hipStream_t) stream_;
+    Pool &g_pool = eng.pool;
+    hipStream_t (&g_streams)[2] = eng.streams;
+    hipEvent_t (&g_events)[3] = eng.events;
     stats = WfStats();
     if (L.n_sel_tiles == 0 || L.spp_count == 0) return std::string();
 
@@ -611,10 +643,10 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     const size_t records = state_capacity(per_pipe);            /* per pipe, per state copy */
     const int sh_grid = shade_grid(per_pipe);
     if (records >= ((size_t) 1 << 30)) return "wavefront: wavefront_paths too large (state index is 30 bits)";
-    std::string err = ensure_pool(records * n_pipes);
+    std::string err = ensure_pool(g_pool, records * n_pipes);
     if (!err.empty()) return err;
     FilmStore film;
-    err = film_prepare(per_pipe * n_pipes, L.n_sel_tiles, L.tile_w, s, film);
+    err = film_prepare(film_store, per_pipe * n_pipes, L.n_sel_tiles, L.tile_w, s, film);
     if (!err.empty()) return err;
     stats.state_bytes = g_pool.bytes + per_pipe * n_pipes * 24;
     WF_TRY(hipMemsetAsync(g_pool.buf.stats, 0, 2 * S_COUNT * sizeof(unsigned long long), s));
@@ -657,7 +689,7 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
     int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + 64))));
     if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(8, std::max(1, atoi(e)));
-    const int extend_grid = 256 * per_cu;
+    const int extend_grid = eng.n_cus * per_cu;
     if (L.stack_depth > 16) {      /* wf_finish keeps 16 entries in LDS */
         const size_t per_pipe_ints = (size_t) (L.stack_depth - 16) * std::max(extend_grid, finish_grid) * kB, ints = per_pipe_ints * n_pipes;
         if (g_pool.spill_ints < ints) {
@@ -696,7 +728,7 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             P.bt.tile_mod = L.tile_mod; P.bt.tile_rem = L.tile_rem; P.bt.tiles_x = L.tiles_x; P.bt.tile_w = L.tile_w;
             WF_TRY(hipMemsetAsync(P.b.ctr, 0, C_COUNT * sizeof(uint32_t), P.stream));
             stats.n_batches++;
-            P.cur = 0; P.first = true; P.active = true; any = true;
+            P.cur = 0; P.first = true; P.active = true; any = true; P.batch_rounds = 0;
         }
         if (!any) break;
         /* the path count is read back every sync_every iterations, more often once it is small
@@ -745,7 +777,10 @@ std::string wavefront_render(const DevScene &sc, const float *d_filter_table, co
             P.s0 += P.bt.n_spp;
             if (P.s0 >= L.spp_count) { P.s0 = 0; P.t0 += P.bt.n_tiles; }
         }
-        if (stats.n_iterations > 100000) return "wavefront: path loop did not terminate";
+        /* a batch's paths die geometrically (Russian roulette from depth 3): thousands of iterations on ONE
+           batch mean the loop is stuck; the bound is per batch, however many batches the call needs */
+        for (int k = 0; k < n_pipes; ++k)
+            if (pipes[k].active && ++pipes[k].batch_rounds > 20000) return "wavefront: path loop did not terminate";
     }
     if (n_pipes > 1)        /* back to the caller's stream */
         for (int k = 0; k < n_pipes; ++k) {

@@ -162,18 +162,23 @@ NORI_REGISTER_CLASS(AreaLight, "area");
 
 /* ================================================================ Sampler */
 /* src/independent.cpp:21-67.  The pcg32 arithmetic runs on the device
-   (nori_hip_pcg32_floats); the host keeps the stream key and a buffer. */
+   (nori_hip_pcg32_floats_at); the host keeps the stream key, how many numbers of the stream it has
+   handed out, and a buffer.  prepare(block) = m_random.seed(offset.x, offset.y)
+   (independent.cpp:36-41): next1D / next2D then walk exactly the reference's pcg32 sequence, however the
+   buffer is refilled and whatever blocks were rendered before. */
 class Independent : public Sampler {
 public:
     Independent(const PropertyList &propList) { m_sampleCount = (size_t) propList.getInteger("sampleCount", 1); }
     std::unique_ptr<Sampler> clone() const {
         std::unique_ptr<Independent> c(new Independent());
+        /* the reference copies m_random, i.e. the position in the stream too (independent.cpp:30-34) */
         c->m_sampleCount = m_sampleCount; c->m_state = m_state; c->m_seq = m_seq; c->m_forks = m_forks;
+        c->m_drawn = m_drawn - (m_buffer.size() - m_pos);
         return std::move(c);
     }
     void prepare(const ImageBlock &block) {
         m_state = (uint64_t) block.getOffset().x(); m_seq = (uint64_t) block.getOffset().y();
-        m_buffer.clear(); m_pos = 0; m_forks = 0;
+        m_buffer.clear(); m_pos = 0; m_forks = 0; m_drawn = 0;
     }
     void generate() {}
     void advance() {}
@@ -185,7 +190,7 @@ public:
     void forkStream(uint64_t &state, uint64_t &seq) {
         /* distinct pcg32 streams per path: same initstate, initseq advanced in a
            range disjoint from the refill streams */
-        state = m_state; seq = (m_seq << 32) + 0x80000000ull + m_forks++;
+        state = m_state; seq = (m_seq << 32) + 0x80000000ull + m_forks++;      /* never equal to the block's own initseq (< 2^31) */
     }
     std::string toString() const { return format("Independent[sampleCount=%i]", (int) m_sampleCount); }
 protected:
@@ -194,12 +199,13 @@ private:
     void refill() {
         const uint32_t kChunk = 4096;
         m_buffer.resize(kChunk);
-        uint64_t st = m_state, sq = (m_seq << 32) + m_refills++;
+        uint64_t st = m_state, sq = m_seq;
         Device &d = Device::shared();
-        d.check(nori_hip_pcg32_floats(d.ctx(), &st, &sq, 1, kChunk, m_buffer.data()), "nori_hip_pcg32_floats");
+        d.check(nori_hip_pcg32_floats_at(d.ctx(), &st, &sq, m_drawn, 1, kChunk, m_buffer.data()), "nori_hip_pcg32_floats_at");
+        m_drawn += kChunk;        /* numbers of the stream fetched so far */
         m_pos = 0;
     }
-    uint64_t m_state = 0x853c49e6748fea9bULL, m_seq = 0xda3e39cb94b95bdbULL >> 1, m_forks = 0, m_refills = 0;
+    uint64_t m_state = 0x853c49e6748fea9bULL, m_seq = 0xda3e39cb94b95bdbULL >> 1, m_forks = 0, m_drawn = 0;
     std::vector<float> m_buffer;
     size_t m_pos = 0;
 };
