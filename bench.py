@@ -1,81 +1,145 @@
 #!/usr/bin/env python
-"""bench.py -- Mrays/s of the hot path (BVH traversal + Li path loop + tile splat).
+"""bench.py -- Mrays/s of the hot path (Accel traversal + Integrator::Li path loop + ImageBlock splat).
 
-One "step" = one complete render pass of the workload (every pixel, every
-sample) through libnori_hip.  N GPUs (one process per GPU under
-torch.distributed.run) split the 16x16 tiles of the frame round-robin and rank 0
-receives the RCCL sum-reduce of the RGBW frame (ImageBlock::put(ImageBlock&)
-across GPUs).  Total work is fixed as N grows -> "scaling": "strong".
+One "step" = one complete render pass of the workload (every pixel, every sample) through libnori_hip
+(C ABI, include/nori_hip.h).  `--workload` names a BASELINE.json configuration (nori_amd/workloads.py;
+default: configs[2], the pa4 Cornell box, path_mis, 1024 x 1024, 256 spp).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) extended with
-`roofline` (dominant kernel: render_kernel) and `cpu_baseline` (the oracle,
-timed on the host cores on a bounded sample of the same workload).
+N GPUs = one process per GPU.  `python bench.py --gpus N` spawns the N ranks itself
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`) unless it is
+already running under such a launcher (WORLD_SIZE set).  The path shards with no data-path collective:
+  --split tile     16x16 tiles round-robin over the ranks (ImageBlock tiles; default for C1-C4)
+  --split sample   every rank renders the whole frame with its share of the samples per pixel (C5)
+and ends with ONE exchange of the RGBW frame to rank 0 -- ImageBlock::put(ImageBlock&) (src/block.cpp:93-102)
+across GPUs: `--merge reduce` (RCCL sum-reduce, either split) or `--merge gather` (RCCL gather of each rank's
+tile columns + halo, tile split only).  Total work is fixed as N grows -> "scaling": "strong".
+
+Rank 0 prints ONE JSON line: the contract fields plus
+  roofline      dominant kernel (the ray-query kernel, all its launches of one pass), timed live with HIP events on
+                the launch stream.  bound "valu": scenes whose BVH is cache-resident are VALU-issue bound
+                (profiles/*_counters.json: SQ_ACTIVE_INST_VALU vs SQ_BUSY_CYCLES); achieved = algorithmic f32 vector
+                operations (52 per two-box node test, 54 per triangle test, 9 per ray) / time
+                against 78.6 Tops/s (256 CUs x 4 SIMD x 32 lanes x 2.4 GHz, non-FMA).  bound "hbm": trees beyond
+                L2 + Infinity Cache; achieved = algorithmic bytes / time against 8 TB/s.
+                `traffic` = PMC-measured HBM bytes of that kernel per pass, from the committed counter summary
+                whose device-source hash matches this build (else null), stamped with its source.
+  parity        the GPU render of exactly the sample range the CPU baseline rendered, compared with it
+                (fraction of pixels within 1e-3, mean relative error, ray counts)
+  cpu_baseline  the oracle (CPU restatement, `-O3 -march=native -ffp-contract=off`, SAH BVH, std::thread over
+                32x32 blocks) on the host cores, on a bounded sample of the same workload
 """
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK_TOPS = 78.6          # 256 CUs x 4 SIMD-32 x 2.4 GHz: one non-FMA f32 lane-operation per lane per clock
+OPS_NODE, OPS_TRI, OPS_RAY = 52, 54, 9      # algorithmic f32 vector ops per two-box node test / triangle test / ray setup
+CACHE_RESIDENT_BYTES = 256 << 20             # a BVH below this lives in L2 + Infinity Cache: HBM is not its bound
 
 
-def load_workload(name: str, width: int, height: int, spp: int):
-    from nori_amd.scene import Scene
-    from tests import scenes
-    golden = os.path.join(ROOT, "tests", "golden", f"{name}.npz")
-    if os.path.exists(golden):
-        sc = Scene.load_npz(golden)
-    elif name == "procedural-cornell":
-        sc = scenes.cornell_box(width, height, spp, "path_mis", sphere_subdiv=4)
-    else:
-        raise SystemExit(f"unknown workload {name}")
-    sc.camera.width, sc.camera.height, sc.sample_count = width, height, spp
-    return sc
-
-
-def algorithmic_bytes(stats: dict, info: dict, tile_w: int, n_tiles: int, engine: str) -> dict:
-    """Algorithmic bytes of one render pass:
-      traversal  N_node * 64 + N_tri * 48                     (both engines; from the COUNT pass)
-      surface    96 B per closest-hit ray: the triangle's pre-gathered shading record (3 positions +
-                 3 normals as 16-B records)
-      film       24 B written + 24 B read per camera sample (sample store), plus one
-                 read-modify-write of every tile accumulator and one frame read-modify-write
-      state      wavefront only (dense ping-pong path state, wavefront.hip): per path vertex
-                 (= closest-hit ray) wf_extend reads 36 B + writes the 16-B hit, wf_shade reads 80 B
-                 and the surviving path is written back as 80 B; per shadow ray another 64 B
-                 (direction + emitter sample, written and read once each); the first vertex of
-                 every path is recomputed, not stored (-180 B per camera sample):
-                 212 B * closest + 64 B * shadow - 180 B * camera samples.
-                 0 for the megakernel, whose paths live in registers."""
-    trav = stats["n_node_tests"] * info["node_bytes"] + stats["n_tri_tests"] * info["tri_bytes"]
-    surface = stats["n_closest_rays"] * 96
-    film = stats["n_camera_samples"] * 48 + n_tiles * 2 * 16 * tile_w * tile_w
-    state = 0
-    if engine == "wavefront":
-        state = stats["n_closest_rays"] * 212 + stats["n_shadow_rays"] * 64 - stats["n_camera_samples"] * 180
-    return {"traversal": int(trav), "surface": int(surface), "film": int(film), "state": int(state),
-            "total": int(trav + surface + film + state)}
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("NORI_BENCH_WORKLOAD", "pa4-cbox-path_mis"))
-    ap.add_argument("--width", type=int, default=1024)
-    ap.add_argument("--height", type=int, default=1024)
-    ap.add_argument("--spp", type=int, default=256)
+    ap.add_argument("--width", type=int, default=None)
+    ap.add_argument("--height", type=int, default=None)
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--triangles", type=int, default=None, help="c5 only: triangle count of the generated terrain")
+    ap.add_argument("--split", default="auto", choices=["auto", "tile", "sample"])
+    ap.add_argument("--merge", default="reduce", choices=["reduce", "gather"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--engine", default="auto", choices=["auto", "megakernel", "wavefront"])
-    args = ap.parse_args()
+    ap.add_argument("--emulate", action="store_true",
+                    help="TEST ONLY (tests/test_distributed_cpu.py): run the same sharding / merge / reporting code on CPU "
+                         "ranks (gloo) with the emulated device headers standing in for the GPU; never a fallback")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 saves the merged RGBW frame of the last step (.npy)")
+    return ap.parse_args(argv)
+
+
+def self_spawn(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N ranks the way the driver does."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# --------------------------------------------------------------------------------------- renderers
+class _EmuRenderer:
+    """--emulate: tests/backends.Emu behind the Renderer surface bench.py uses (CPU tensors)."""
+
+    def __init__(self, scene):
+        from tests.backends import Emu
+        self._e = Emu(scene)
+        self.scene = scene
+        self.border = self._e.border
+
+    def frame_shape(self):
+        return self._e.frame_shape()
+
+    def accel_info(self):
+        return self._e.accel_info()
+
+    def set_option(self, k, v):
+        pass
+
+    def render_into(self, frame, spp_count=None, spp_begin=0, tile_mod=1, tile_rem=0, count_traversal=False, stream=None,
+                    want_stats=True, time_kernels=False):
+        import torch
+        rgbw, st = self._e.render_host(spp_count=spp_count, spp_begin=spp_begin, tile_mod=tile_mod, tile_rem=tile_rem,
+                                       count_traversal=count_traversal)
+        frame += torch.from_numpy(rgbw)
+        return st
+
+
+def device_source_sha() -> str:
+    """Hash of the device sources: ties a committed counter summary to the build it was measured on."""
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "nori_amd", "csrc", "device", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def measured_counters(workload: str, engine: str):
+    """The newest profiles/*_counters.json (tools/summarize_profile.py) for this workload / engine that was
+    collected on THIS build of the device code; None otherwise (a stale figure is worse than none)."""
+    sha = device_source_sha()
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_counters.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("device_source_sha") == sha and d.get("workload") == workload and d.get("engine") == engine:
+            best = (f, d)
+    return best
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
 
     import numpy as np
     import torch
@@ -84,41 +148,60 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if not args.emulate and not torch.cuda.is_available():
+        raise SystemExit("bench.py: no GPU (torch.cuda.is_available() is False); the hot path has no CPU fallback")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if args.emulate:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if args.emulate:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
 
-    if not os.path.exists(os.path.join(ROOT, "tests", "golden", f"{args.workload}.npz")):
-        args.workload = "procedural-cornell"
-    sc = load_workload(args.workload, args.width, args.height, args.spp)
+    from nori_amd import dist as ndist
+    from nori_amd import workloads
+    wl = workloads.load(args.workload, args.width, args.height, args.spp, args.triangles)
+    sc = wl.scene
+    width, height, spp = sc.camera.width, sc.camera.height, sc.sample_count
+    split = wl.split if args.split == "auto" else args.split
+    if args.merge == "gather" and split != "tile":
+        raise SystemExit("bench.py: --merge gather needs --split tile (a sample split merges by sum-reduce)")
 
-    from nori_amd.render import Renderer
-    r = Renderer(local_rank).upload(sc)
-    tiles = ((args.width + 15) // 16) * ((args.height + 15) // 16)
-    my_tiles = (tiles - rank + world - 1) // world
+    if args.emulate:
+        r = _EmuRenderer(sc)
+    else:
+        from nori_amd.render import Renderer
+        r = Renderer(local_rank).upload(sc)
+    tiles_x, tiles_y = (width + 15) // 16, (height + 15) // 16
+    tiles = tiles_x * tiles_y
+    shard = ndist.shard(split, rank, world, spp)
+    my_tiles = (tiles - shard["tile_rem"] + shard["tile_mod"] - 1) // shard["tile_mod"]
     engine = args.engine
     if engine == "auto":      # the library's rule (nori_hip.h, nori_hip_set_option)
-        engine = "wavefront" if my_tiles * 256 * args.spp >= (1 << 24) else "megakernel"
+        engine = "wavefront" if my_tiles * 256 * shard["spp_count"] >= (1 << 24) else "megakernel"
     r.set_option("engine", engine)
     info = r.accel_info()
     frame = torch.zeros(r.frame_shape(), dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev)
+    stream = None if args.emulate else torch.cuda.current_stream(dev)
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    from nori_amd import dist as ndist
+        if not args.emulate:
+            torch.cuda.synchronize(dev)
 
     def step(want_stats=False, count=False, time_kernels=False):
-        # tile split over ranks + one RCCL SUM-reduce of the RGBW frame to rank 0
-        return ndist.render_distributed(r.render_into, frame, "tile", args.spp, rank, world, stream=stream,
-                                        want_stats=want_stats, count_traversal=count, time_kernels=time_kernels)
+        # this rank's share of the frame, then ONE exchange: ImageBlock::put(ImageBlock&) across GPUs
+        return ndist.render_distributed(r.render_into, frame, split, spp, rank, world, merge=args.merge, tiles_x=tiles_x,
+                                        border=r.border, stream=stream, want_stats=want_stats, count_traversal=count,
+                                        time_kernels=time_kernels)
 
     # one instrumented pass: traversal counters for the roofline (untimed)
     counted = step(want_stats=True, count=True)
@@ -131,8 +214,8 @@ def main():
     for _ in range(args.steps):
         # stats: HIP-event times on the launch stream -- whole pass and per kernel class
         last = step(want_stats=True, time_kernels=True)
-        kernel_ms.append(last["kernel_ms"]); trace_ms.append(last["trace_ms"]); shade_ms.append(last["shade_ms"])
-        film_ms.append(last["film_ms"]); trace_launches = last["n_trace_launches"]
+        kernel_ms.append(last["kernel_ms"]); trace_ms.append(last.get("trace_ms", 0.0)); shade_ms.append(last.get("shade_ms", 0.0))
+        film_ms.append(last.get("film_ms", 0.0)); trace_launches = last.get("n_trace_launches", 0)
     barrier()
     dt = time.perf_counter() - t0
 
@@ -146,67 +229,77 @@ def main():
         rays_total = rays_local
 
     if rank == 0:
+        if args.dump_frame:
+            np.save(args.dump_frame, frame.cpu().numpy())
         ms_per_step = dt / args.steps * 1e3
         mrays = rays_total / (ms_per_step * 1e-3) / 1e6
-        # roofline of the dominant kernel on this rank: the ray-query kernel (wf_extend, all its launches
-        # of one pass; render_kernel for the megakernel, which also contains the shading)
-        tile_w = 16 + 2 * r.border
-        parts = algorithmic_bytes(counted, info, tile_w, my_tiles, engine)
         k_ms, t_ms = float(np.mean(kernel_ms)), float(np.mean(trace_ms))
+        if t_ms <= 0.0:
+            t_ms = k_ms
+        rays_c = counted["n_closest_rays"] + counted["n_shadow_rays"]
+        ops = counted["n_node_tests"] * OPS_NODE + counted["n_tri_tests"] * OPS_TRI + rays_c * OPS_RAY
+        trav_bytes = counted["n_node_tests"] * info["node_bytes"] + counted["n_tri_tests"] * info["tri_bytes"]
         if engine == "wavefront":
             dom_name = "wf_extend (all launches of one render pass)"
-            dom_bytes = parts["traversal"] + counted["n_closest_rays"] * 52 + counted["n_shadow_rays"] * 16 - counted["n_camera_samples"] * 36
+            # per closest-hit ray 36 B read (flags, origin, direction) + 16 B hit written, +16 B per shadow ray,
+            # first vertex recomputed (-36 B per camera sample)
+            rec_bytes = counted["n_closest_rays"] * 52 + counted["n_shadow_rays"] * 16 - counted["n_camera_samples"] * 36
         else:
             dom_name = "render_kernel (all launches of one render pass)"
-            dom_bytes = parts["traversal"] + parts["surface"] + counted["n_camera_samples"] * 24
-        achieved = dom_bytes / (t_ms * 1e-3) / 1e9
-        traffic = measured_traffic(args, sc, engine)
-        compulsory = info["total_bytes"] + parts["state"] + parts["film"]       # each byte that has to cross HBM at least once
+            rec_bytes = counted["n_closest_rays"] * 96 + counted["n_camera_samples"] * 24
+        ctr = measured_counters(wl.name, engine)
+        cache_resident = info["total_bytes"] <= CACHE_RESIDENT_BYTES
+        roof = {"kernel": dom_name, "kernel_ms": round(t_ms, 3), "launches": int(trace_launches),
+                "node_tests": int(counted["n_node_tests"]), "tri_tests": int(counted["n_tri_tests"]), "rays": int(rays_c),
+                "bvh_bytes": int(info["total_bytes"])}
+        hbm_alg = (trav_bytes + rec_bytes) / (t_ms * 1e-3) / 1e9
+        valu_ach = ops / (t_ms * 1e-3) / 1e12
+        if cache_resident:
+            roof.update({"bound": "valu", "achieved": round(valu_ach, 3), "peak": VALU_PEAK_TOPS, "unit": "Tops/s",
+                         "frac": round(valu_ach / VALU_PEAK_TOPS, 5), "algorithmic_ops": int(ops),
+                         "note": "BVH (%.1f MB) is L2 / Infinity-Cache resident: the ray-query kernel is VALU-issue bound, not HBM bound; "
+                                 "ops = %d/node test + %d/triangle test + %d/ray (f32 vector operations as written in rt_trace.h), "
+                                 "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz" % (info["total_bytes"] / 1e6, OPS_NODE, OPS_TRI, OPS_RAY)})
+        else:
+            roof.update({"bound": "hbm", "achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(hbm_alg / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(trav_bytes + rec_bytes),
+                         "valu_frac": round(valu_ach / VALU_PEAK_TOPS, 5),
+                         "note": "algorithmic bytes per SURVEY 8(d): N_node x %d + N_tri x %d + ray / hit records; the BVH (%.0f MB) "
+                                 "exceeds L2 + Infinity Cache" % (info["node_bytes"], info["tri_bytes"], info["total_bytes"] / 1e6)})
+        roof["traffic"] = None
+        if ctr:
+            f, d = ctr
+            roof["traffic"] = d.get("dominant_kernel_hbm_bytes")
+            roof["traffic_source"] = os.path.relpath(f, ROOT)
+            if roof["traffic"]:
+                roof["hbm_measured_frac"] = round(roof["traffic"] / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
+            for k in ("valu_busy_frac", "valu_lanes_per_instr", "valu_useful_frac"):
+                if k in d.get("dominant_kernel", {}):
+                    roof[k] = d["dominant_kernel"][k]
         out = {
-            "metric": "Mrays/sec (primary+secondary) at 1024x1024 256spp",
+            "metric": "Mrays/sec (primary+secondary) at 1024x1024 256spp" if wl.name == "pa4-cbox-path_mis" else "Mrays/sec (primary+secondary)",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.workload, "integrator": sc.integrator.type, "width": args.width,
-                       "height": args.height, "spp": args.spp, "triangles": info["n_triangles"],
-                       "parallelism": f"tile-split x{world} + RCCL reduce" if world > 1 else "single GPU",
+            "config": {"workload": wl.name, "baseline_config": wl.config, "generator": wl.generator,
+                       "integrator": sc.integrator.type, "width": width, "height": height, "spp": spp,
+                       "triangles": info["n_triangles"],
+                       "parallelism": f"{split}-split x{world} + RCCL {args.merge}" if world > 1 else "single GPU",
                        "rays_per_step": int(rays_total), "seed_mode": "per_sample", "engine": engine},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic.get("dominant_kernel_bytes") if traffic else None,
-                         "kernel_ms": round(t_ms, 3), "launches": int(trace_launches), "algorithmic_bytes": int(dom_bytes),
-                         "node_tests": int(counted["n_node_tests"]), "tri_tests": int(counted["n_tri_tests"]),
-                         "note": "algorithmic bytes per SURVEY.md 8(d): N_node*64 + N_tri*48 + ray/hit records; "
-                                 "this scene's BVH (%.1f MB) is L2-resident, so the node/triangle bytes are served by L2 and "
-                                 "'achieved' can exceed the HBM peak -- see 'pass' for what HBM has to carry" % (info["total_bytes"] / 1e6)},
-            "pass": {"kernel_ms": round(k_ms, 3), "trace_ms": round(t_ms, 3), "shade_ms": round(float(np.mean(shade_ms)), 3),
-                     "film_ms": round(float(np.mean(film_ms)), 3), "launches": int(last["n_workgroups"]) if engine == "wavefront" else None,
-                     "algorithmic_bytes_parts": parts,
-                     "hbm_compulsory_bytes": int(compulsory),
-                     "hbm_compulsory_gbs": round(compulsory / (k_ms * 1e-3) / 1e9, 2),
-                     "hbm_compulsory_frac": round(compulsory / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                     "hbm_measured_bytes": traffic.get("hbm_bytes_per_launch") if traffic else None},
+            "roofline": roof,
+            "pass": {"kernel_ms": round(k_ms, 3), "trace_ms": round(float(np.mean(trace_ms)), 3), "shade_ms": round(float(np.mean(shade_ms)), 3),
+                     "film_ms": round(float(np.mean(film_ms)), 3),
+                     "hbm_measured_bytes": (ctr[1].get("pass_hbm_bytes") if ctr else None)},
             "accel": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in info.items()},
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(sc, args)
+            cpu, parity = cpu_baseline_and_parity(wl, r, frame, args)
+            out["cpu_baseline"] = cpu
+            out["parity"] = parity
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def measured_traffic(args, sc, engine):
-    """HBM bytes per launch of render_kernel from the PMC passes (FETCH_SIZE, WRITE_SIZE; separate
-    rocprofv3 --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM).  PMC counters cannot be read
-    from inside this process, so the figure comes from the committed summary of a profiled run of this
-    same command (profiles/*_traffic.json); null if there is none for this workload."""
-    path = os.path.join(ROOT, "profiles", "r1_traffic.json")
-    if not os.path.exists(path):
-        return None
-    t = json.load(open(path))
-    key = f"{args.workload}:{args.width}x{args.height}:{args.spp}:{engine}"
-    return t.get(key)
 
 
 def usable_cores() -> int:
@@ -227,21 +320,58 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline(sc, args):
-    """The oracle (kind 'port': CPU restatement with a SAH BVH) on all host cores,
-    on a bounded sample: the same frame at reduced spp, sized for ~cpu_seconds."""
-    from tests.backends import Oracle
-    o = Oracle(sc, use_bvh=True)
+def cpu_baseline_and_parity(wl, r, frame, args):
+    """The oracle (kind 'port': the CPU restatement of the path, compiled for THIS host with -O3 -march=native
+    -ffp-contract=off, SAH BVH, std::thread workers pulling 32x32 blocks as src/main.cpp:85-113 does) on all
+    host cores, on a bounded sample: every k-th tile of the frame at s samples per pixel, sized for
+    ~cpu_seconds.  The GPU then renders exactly that sample (same tiles, same sample indices, same per-sample
+    seeds) and the two images are compared: the parity verdict of this timed run."""
+    import numpy as np
+    import torch
+    from nori_amd.render import develop_host
+    from tests.backends import Oracle, use_native_oracle
+    native = use_native_oracle()          # builds oracle/_native/liboracle_native_<cpu>.so on this host if it can
+    sc = wl.scene
+    spp = sc.sample_count
     cores = usable_cores()
-    _, st = o.render_host(spp_count=1, threads=cores)
-    per_spp = max(st["kernel_ms"] * 1e-3, 1e-3)
-    spp = int(max(1, min(args.spp, args.cpu_seconds / per_spp)))
-    _, st = o.render_host(spp_count=spp, threads=cores)
+    t0 = time.perf_counter()
+    o = Oracle(sc, use_bvh=wl.name != "c1-bunny-normals")
+    build_s = time.perf_counter() - t0
+    # probe: every 16th tile at 1 spp -> seconds per (tile x spp)
+    tiles = ((sc.camera.width + 15) // 16) * ((sc.camera.height + 15) // 16)
+    probe_mod = 16 if tiles >= 256 else 1
+    _, st = o.render_host(spp_count=1, tile_mod=probe_mod, tile_rem=0, threads=cores)
+    per_tile_spp = max(st["kernel_ms"] * 1e-3, 1e-4) / max(1, tiles // probe_mod)
+    budget = args.cpu_seconds / per_tile_spp                  # (tile x spp) units we can afford
+    if budget >= tiles * spp:
+        mod, s = 1, spp
+    elif budget >= tiles:
+        mod, s = 1, int(budget // tiles)
+    else:
+        mod, s = int(min(tiles, -(-tiles // max(1.0, budget)))), 1
+    A, st = o.render_host(spp_count=s, tile_mod=mod, tile_rem=0, threads=cores)
     rays = st["n_closest_rays"] + st["n_shadow_rays"]
     sec = st["kernel_ms"] * 1e-3
-    return {"value": round(rays / sec / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": f"{args.width}x{args.height} at {spp} spp of {args.spp} ({rays} rays in {sec:.1f} s, "
-                      f"std::thread x{cores}, SAH BVH, per-sample seeding)"}
+    cpu = {"value": round(rays / sec / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
+           "flags": "-O3 -march=native -ffp-contract=off" if native else "-O2 -ffp-contract=off (native build unavailable)",
+           "accel": "binned-SAH BVH" if wl.name != "c1-bunny-normals" else "brute force over all triangles (the reference's Accel, src/accel.cpp:30-40)",
+           "accel_build_s": round(build_s, 2),
+           "sample": f"{sc.camera.width}x{sc.camera.height}, every {mod}. tile, {s} spp of {spp} ({rays} rays in {sec:.1f} s, "
+                     f"std::thread x{cores}, per-sample seeding)"}
+    frame.zero_()
+    gst = r.render_into(frame, spp_count=s, spp_begin=0, tile_mod=mod, tile_rem=0)
+    if frame.is_cuda:
+        torch.cuda.synchronize()
+    B = frame.cpu().numpy()
+    a, b = develop_host(A, r.border), develop_host(B, r.border)
+    covered = A[r.border:A.shape[0] - r.border, r.border:A.shape[1] - r.border, 3] > 0
+    rel = (np.abs(a - b) / np.maximum(np.abs(a), 1e-2)).max(axis=-1)[covered]
+    parity = {"frac_within_1e-3": round(float((rel <= 1e-3).mean()), 6), "mean_rel": float(f"{rel.mean():.3e}"),
+              "tolerance": ">= 0.999 of pixels within 1e-3 relative, mean relative error <= 1e-4 (SURVEY 8(d), per-sample seeding)",
+              "pixels": int(covered.sum()), "rays_cpu": int(rays), "rays_gpu": int(gst["n_closest_rays"] + gst["n_shadow_rays"]),
+              "w_channel_max_abs_diff": float(np.abs(A[..., 3] - B[..., 3]).max())}
+    parity["ok"] = bool(parity["frac_within_1e-3"] >= 0.999 and parity["mean_rel"] <= 1e-4)
+    return cpu, parity
 
 
 if __name__ == "__main__":

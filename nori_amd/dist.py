@@ -1,18 +1,28 @@
 """One-process-per-GPU sharding of a render (torch.distributed; backend "nccl"
-is RCCL on ROCm, "gloo" for the CPU tests).
+is RCCL on ROCm, "gloo" for the CPU tests).  Started by `bench.py --gpus N`
+(which spawns the ranks itself) or by any torch.distributed launcher.
 
 The path shards with no data-path collective: every rank renders its share of
-the frame into its own zero-initialised RGBW buffer; the only exchange is one
-SUM-reduce of that buffer to rank 0 -- ImageBlock::put(ImageBlock&)
+the frame into its own zero-initialised RGBW buffer; the only exchange is ONE
+merge of those buffers on rank 0 -- ImageBlock::put(ImageBlock&)
 (src/block.cpp:93-102) across GPUs instead of across TBB workers.
 
-  mode "tile"   : 16x16 tiles round-robin over ranks (tile_mod / tile_rem);
-                  fixed total work -> strong scaling.
-  mode "sample" : every rank renders the whole frame with a disjoint range of
-                  the per-pixel sample indices (disjoint pcg32 streams).
+  split "tile"   : 16x16 tiles round-robin over ranks (tile_mod / tile_rem);
+                   fixed total work -> strong scaling.
+  split "sample" : every rank renders the whole frame with a disjoint range of
+                   the per-pixel sample indices (disjoint pcg32 streams).
+  merge "reduce" : SUM-reduce of the whole RGBW frame to rank 0 (either split).
+  merge "gather" : tile split only.  With tiles_x divisible by the world size a rank's
+                   tiles are whole tile COLUMNS (c = rank mod world), so what it
+                   touched is a set of (16 + 2 border)-pixel-wide column strips: each rank
+                   packs its strips, one gather brings them to rank 0, which adds them
+                   (overlapping halos included) into the frame -- 1/N of the frame per
+                   rank over the wire instead of a ring reduce of all of it.
 Both give, up to float summation order, the single-GPU image.
 """
 from __future__ import annotations
+
+TILE = 16      # NORI_TILE_SIZE of the device code (rt_types.h kTile)
 
 
 def shard(mode: str, rank: int, world: int, spp: int):
@@ -26,18 +36,59 @@ def shard(mode: str, rank: int, world: int, spp: int):
     raise ValueError(f"unknown shard mode {mode!r}")
 
 
+def _world():
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def reduce_frame(frame, dst: int = 0):
     """SUM-reduce the RGBW frame tensor to rank `dst` (in place there)."""
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _world() > 1:
         dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
     return frame
 
 
-def render_distributed(render_fn, frame, mode: str, spp: int, rank: int, world: int, **kw):
+def column_strips(rank: int, world: int, tiles_x: int, border: int, frame_cols: int, device=None):
+    """Bordered-frame x coordinates rank `rank`'s tile columns touch (tile column c covers
+    [16 c, 16 c + 16 + 2 border)), and which of them lie inside the frame (the last column of an image
+    whose width is not a multiple of 16 is clipped)."""
+    import torch
+    cols = torch.arange(rank, tiles_x, world, device=device)
+    x = (cols[:, None] * TILE + torch.arange(TILE + 2 * border, device=device)[None, :]).reshape(-1)
+    return x.clamp(max=frame_cols - 1), x < frame_cols
+
+
+def gather_frame(frame, rank: int, world: int, tiles_x: int, border: int, dst: int = 0):
+    """Tile-split merge by ONE gather of every rank's column strips (see module docstring)."""
+    import torch
+    import torch.distributed as dist
+    if world <= 1:
+        return frame
+    if tiles_x % world != 0:
+        raise ValueError(f"gather merge needs tiles_x ({tiles_x}) divisible by the world size ({world}); use merge='reduce'")
+    x, valid = column_strips(rank, world, tiles_x, border, frame.shape[1], frame.device)
+    pack = (frame[:, x, :] * valid[None, :, None].to(frame.dtype)).contiguous()
+    parts = [torch.empty_like(pack) for _ in range(world)] if rank == dst else None
+    dist.gather(pack, parts, dst=dst)
+    if rank == dst:
+        frame.zero_()
+        for r in range(world):
+            xr, _ = column_strips(r, world, tiles_x, border, frame.shape[1], frame.device)
+            frame.index_add_(1, xr, parts[r])      # masked entries are zero: clamped duplicates add nothing
+    return frame
+
+
+def render_distributed(render_fn, frame, mode: str, spp: int, rank: int, world: int, merge: str = "reduce",
+                       tiles_x: int | None = None, border: int = 0, **kw):
     """render_fn(frame, **shard_kwargs, **kw) accumulates this rank's share into
-    `frame` (a torch tensor, CUDA for the product / CPU in tests); then reduce."""
+    `frame` (a torch tensor, CUDA for the product / CPU in tests); then merge on rank 0."""
     frame.zero_()
     stats = render_fn(frame, **shard(mode, rank, world, spp), **kw)
-    reduce_frame(frame, 0)
+    if merge == "gather":
+        if mode != "tile":
+            raise ValueError("gather merge applies to the tile split only")
+        gather_frame(frame, rank, world, tiles_x, border, 0)
+    else:
+        reduce_frame(frame, 0)
     return stats

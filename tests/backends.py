@@ -33,12 +33,38 @@ def _make(dirpath, target):
 
 _oracle = None
 _emu = None
+_oracle_path = None      # set by use_native_oracle() before the first oracle call
+
+
+def use_native_oracle() -> bool:
+    """bench.py's cpu_baseline leg: load the oracle compiled FOR THIS HOST (-O3 -march=native
+    -ffp-contract=off, oracle/Makefile target `native`) instead of the portable -O2 checker.  The file is keyed
+    by the CPU model, so a copy built on another machine (the snapshot travels) is never loaded.  Returns
+    False -- and leaves the portable build in place -- if it cannot be built or the oracle is already loaded."""
+    global _oracle_path
+    if _oracle is not None:
+        return _oracle_path is not None
+    try:
+        import hashlib
+        model = [ln for ln in open("/proc/cpuinfo") if ln.startswith(("model name", "flags"))][:2]
+        key = hashlib.sha1("".join(model).encode()).hexdigest()[:10]
+        rel = f"_native/liboracle_native_{key}.so"
+        odir = os.path.join(ROOT, "oracle")
+        so = os.path.join(odir, rel)
+        srcs = [os.path.join(odir, f) for f in ("oracle.cpp", "oracle_scene.h", "oracle_math.h", "oracle.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.run(["make", "-C", odir, "native", f"NATIVE_SO={rel}"], check=True, capture_output=True, timeout=300)
+        _oracle_path = so
+        return True
+    except Exception:
+        _oracle_path = None
+        return False
 
 
 def oracle_lib():
     global _oracle
     if _oracle is None:
-        lib = C.CDLL(_make(os.path.join(ROOT, "oracle"), "liboracle.so"))
+        lib = C.CDLL(_oracle_path or _make(os.path.join(ROOT, "oracle"), "liboracle.so"))
         protos = {
             "oracle_create": (C.c_int, [C.POINTER(capi.SceneDesc), C.POINTER(_P)]),
             "oracle_destroy": (None, [_P]),

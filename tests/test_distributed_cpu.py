@@ -1,7 +1,8 @@
-"""N > 1 path on the CPU: two processes, gloo backend, the tile split and the
-sample split + SUM-reduce of nori_amd.dist, with the emulated device code as
-the per-rank renderer.  The result on rank 0 must equal the single-process
-render up to float summation order."""
+"""N > 1 path on the CPU, through bench.py itself: `bench.py --emulate` runs the product's sharding / merge /
+reporting code (nori_amd.dist, the JSON line) on gloo ranks with the emulated device headers as the per-rank
+renderer -- the same code path `bench.py --gpus N` takes on a GPU node, minus the GPU.  The merged frame on
+rank 0 must equal the single-process render up to float summation order."""
+import json
 import os
 import subprocess
 import sys
@@ -10,52 +11,64 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-WORKER = r'''
-import os, sys
-sys.path.insert(0, {root!r})
-import numpy as np, torch, torch.distributed as dist
-from nori_amd import dist as ndist
-from tests import scenes
-from tests.backends import Emu
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo", rank=rank, world_size=world)
-sc = scenes.cornell_box(40, 24, 6, "path_mis")
-emu = Emu(sc)
-def render_fn(frame, **kw):
-    rgbw, st = emu.render_host(**kw)
-    frame += torch.from_numpy(rgbw)
-    return st
-for mode in ("tile", "sample"):
-    frame = torch.zeros(emu.frame_shape(), dtype=torch.float32)
-    st = ndist.render_distributed(render_fn, frame, mode, sc.sample_count, rank, world)
-    rays = torch.tensor([float(st["n_camera_samples"])], dtype=torch.float64)
-    dist.all_reduce(rays)
-    if rank == 0:
-        np.save(os.path.join({out!r}, mode + ".npy"), frame.numpy())
-        np.save(os.path.join({out!r}, mode + "_cam.npy"), rays.numpy())
-dist.barrier()
-dist.destroy_process_group()
-'''
+BENCH = os.path.join(ROOT, "bench.py")
+SIZE = dict(width=64, height=48, spp=3)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_two_process_split_and_reduce(tmp_path, world):
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29500 + world + os.getpid() % 1000))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", env["MASTER_PORT"], str(script)]
-    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
-    from tests import scenes
+def _whole():
+    from nori_amd import workloads
     from tests.backends import Emu
-    sc = scenes.cornell_box(40, 24, 6, "path_mis")
-    whole, st = Emu(sc).render_host()
-    for mode in ("tile", "sample"):
-        got = np.load(tmp_path / f"{mode}.npy")
-        np.testing.assert_allclose(got, whole, rtol=2e-5, atol=1e-6, err_msg=mode)
-        assert np.load(tmp_path / f"{mode}_cam.npy")[0] == st["n_camera_samples"]
+    sc = workloads.load("pa4-cbox-path_mis", SIZE["width"], SIZE["height"], SIZE["spp"]).scene
+    return Emu(sc).render_host()
+
+
+@pytest.fixture(scope="module")
+def whole():
+    return _whole()
+
+
+@pytest.mark.parametrize("world,split,merge", [(2, "tile", "reduce"), (2, "tile", "gather"), (2, "sample", "reduce"),
+                                               (3, "tile", "reduce"), (4, "tile", "gather")])
+def test_bench_spawns_ranks_and_merges(tmp_path, whole, world, split, merge):
+    """`python bench.py --gpus N` starts its own N ranks (no external launcher) and rank 0 holds the merged frame."""
+    frame = tmp_path / "frame.npy"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, BENCH, "--gpus", str(world), "--emulate", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+           "--workload", "pa4-cbox-path_mis", "--width", str(SIZE["width"]), "--height", str(SIZE["height"]), "--spp", str(SIZE["spp"]),
+           "--split", split, "--merge", merge, "--dump-frame", str(frame)]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    ref, st = whole
+    assert out["n_gpus"] == world and out["config"]["workload"] == "pa4-cbox-path_mis"
+    assert out["config"]["rays_per_step"] == st["n_closest_rays"] + st["n_shadow_rays"]
+    assert out["config"]["parallelism"] == f"{split}-split x{world} + RCCL {merge}"
+    assert 0.0 < out["roofline"]["frac"] <= 1.0 and out["roofline"]["bound"] in ("valu", "hbm")
+    np.testing.assert_allclose(np.load(frame), ref, rtol=2e-5, atol=1e-6)
+
+
+def test_bench_without_gpu_fails_at_no_gpu():
+    """On a box without a GPU the multi-GPU entry gets as far as 'no GPU' -- not an assert, not a launcher error."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this box has a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, env=env, timeout=600)
+    assert p.returncode != 0
+    assert "no GPU" in p.stdout + p.stderr
+    assert "AssertionError" not in p.stderr
+
+
+def test_gather_needs_divisible_columns():
+    from nori_amd.dist import column_strips, gather_frame
+    import torch
+    x, valid = column_strips(1, 2, 4, 2, 64 + 4)
+    assert x.tolist()[:3] == [16, 17, 18] and len(x) == 2 * 20 and bool(valid.all())
+    x, valid = column_strips(0, 1, 3, 2, 40 + 4)       # 40-px-wide image: the third tile column is clipped
+    assert int(valid.sum()) == 20 + 20 + 12
+    with pytest.raises(ValueError):
+        gather_frame(torch.zeros(8, 52, 4), 0, 2, 3, 2)
 
 
 def test_shard_partitions():

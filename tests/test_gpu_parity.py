@@ -5,7 +5,9 @@ CPU oracle, on a real MI355X.  Tolerances:
   * anything through sin/cos/log/exp (warps, microfacet, sampled directions):
     the device libm (ocml) and glibc differ by <= ~2 ulp, so values are compared
     with rtol 2e-5 and whole paths with an outlier budget (a perturbed direction
-    can flip a hit/miss decision near a silhouette).
+    can flip a hit/miss decision near a silhouette);
+  * images (per-sample seeding): >= 99.9 % of the pixels within 1e-3 relative and
+    mean relative error <= 1e-4 -- `assert_image_parity` below, used by every image test.
 """
 import numpy as np
 import pytest
@@ -18,6 +20,27 @@ from tests.backends import Oracle
 pytestmark = pytest.mark.gpu
 
 ITS_FIELDS = ["p", "t", "uv", "sh_s", "sh_t", "sh_n", "geo_s", "geo_t", "geo_n", "mesh", "tri"]
+
+# SURVEY.md 8(d), per-sample seeding: the image contract every oracle comparison is held to
+PIXEL_REL_TOL, PIXEL_FRACTION, MEAN_REL_TOL = 1e-3, 0.999, 1e-4
+
+
+def image_parity(ref_rgb, got_rgb, floor=1e-2):
+    """(fraction of pixels within PIXEL_REL_TOL, mean relative error) of two developed RGB images; a pixel's
+    error is its worst channel, relative to the reference (values below `floor` compared absolutely against it)."""
+    rel = (np.abs(ref_rgb - got_rgb) / np.maximum(np.abs(ref_rgb), floor)).max(axis=-1)
+    return float((rel <= PIXEL_REL_TOL).mean()), float(rel.mean())
+
+
+def assert_image_parity(ref_rgbw, got_rgbw, border, what=""):
+    from nori_amd.render import develop_host
+    # filter weights do not depend on libm: the W channel must agree to summation order
+    np.testing.assert_allclose(got_rgbw[..., 3], ref_rgbw[..., 3], rtol=1e-5, atol=1e-6, err_msg=what)
+    frac, mean_rel = image_parity(develop_host(ref_rgbw, border), develop_host(got_rgbw, border))
+    print(f"[parity] {what}: {frac:.5%} of pixels within {PIXEL_REL_TOL:g}, mean relative error {mean_rel:.2e}")
+    assert frac >= PIXEL_FRACTION, (what, frac)
+    assert mean_rel <= MEAN_REL_TOL, (what, mean_rel)
+    return frac, mean_rel
 
 
 def test_native_library_is_loaded(renderer_factory):
@@ -114,10 +137,11 @@ def test_li_matches_oracle(renderer_factory, integ):
     a, b = o.li(rays, ss, sq), r.li(rays, ss, sq)
     assert np.isfinite(b).all()
     err = np.abs(a - b).max(axis=1) / np.maximum(np.abs(a).max(axis=1), 1e-2)
-    # per-path: >= 99.5% of paths within 1e-3 relative (libm ulps only); the rest flipped a decision
-    assert (err < 1e-3).mean() > 0.995, (err < 1e-3).mean()
+    # per-path: >= 99.9 % of paths within 1e-3 relative (libm ulps only); the rest flipped a decision
+    print(f"[parity] li {integ}: {(err < 1e-3).mean():.5%} of paths within 1e-3")
+    assert (err < 1e-3).mean() >= 0.999, (err < 1e-3).mean()
     # and the estimator itself is unchanged
-    assert abs(a.mean() - b.mean()) < 0.01 * max(a.mean(), 1e-3)
+    assert abs(a.mean() - b.mean()) < 1e-3 * max(a.mean(), 1e-3)
 
 
 def test_splat_matches_imageblock_put(renderer_factory):
@@ -144,13 +168,7 @@ def test_render_matches_oracle(renderer_factory, integ, rf, size):
     assert sb["n_invalid"] == 0
     for k in ("n_closest_rays", "n_shadow_rays"):
         assert abs(int(sa[k]) - int(sb[k])) <= 1e-3 * sa[k] + 2, k
-    # filter weights do not depend on libm: the W channel must agree to summation order
-    np.testing.assert_allclose(B[..., 3], A[..., 3], rtol=1e-5, atol=1e-6)
-    from nori_amd.render import develop_host
-    a, b = develop_host(A, o.border), develop_host(B, r.border)
-    rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-2)
-    assert (rel < 1e-3).mean() > 0.98, (rel < 1e-3).mean()
-    assert abs(a.mean() - b.mean()) < 2e-3 * a.mean()
+    assert_image_parity(A, B, r.border, f"{integ}/{rf} {size}")
 
 
 def test_tile_and_sample_split_sum_to_whole(renderer_factory):
@@ -276,8 +294,57 @@ def test_film_radius_beyond_limit_fails_loudly(renderer_factory):
 
 
 def test_fuzz_intersect_short():
-    """A few rounds of tests/fuzz_intersect.py (randomised scene shapes, both BVH builders, bit-exact hits)."""
+    """A few rounds of tests/fuzz_intersect.py (randomised scene shapes, both BVH builders, bit-exact hits).
+    The fuzzer exempts a mismatching ray only when the reference's own answer is ill-posed (ray within
+    2e-3 rad of the triangle's plane); the exemptions are counted, logged, and on these seeds there are none."""
     from nori_amd.render import Renderer
     from tests import fuzz_intersect
+    fuzz_intersect.TOLERATED[0] = 0
+    hits = 0
     for seed in range(1000, 1015):
-        fuzz_intersect.one_round(seed, Renderer, n_rays=8000)
+        hits += fuzz_intersect.one_round(seed, Renderer, n_rays=8000)
+    print(f"[fuzz] {hits} hits bit-identical on both builders, {fuzz_intersect.TOLERATED[0]} ill-posed rays exempted")
+    assert hits > 10000
+    assert fuzz_intersect.TOLERATED[0] == 0, f"{fuzz_intersect.TOLERATED[0]} rays needed the ill-posed exemption"
+
+
+def test_headline_workload_matches_oracle(renderer_factory):
+    """BASELINE config 3 -- the bench workload: pa4 Cornell box geometry, path_mis, full 1024 x 1024 frame, at
+    a sample count the CPU oracle finishes in seconds -- wavefront engine against the oracle, per-sample
+    seeding, held to the SURVEY 8(d) image contract; ray counts agree to the flipped decisions."""
+    import os
+    from nori_amd.scene import Scene
+    sc = Scene.load_npz(os.path.join(os.path.dirname(__file__), "golden", "pa4-cbox-path_mis.npz"))
+    assert (sc.camera.width, sc.camera.height, sc.integrator.type) == (1024, 1024, "path_mis")
+    sc.sample_count = 8
+    r, o = renderer_factory(sc), Oracle(sc, use_bvh=True)
+    r.set_option("engine", "wavefront")
+    B, sb = r.render_host()
+    A, sa = o.render_host()
+    assert sb["n_camera_samples"] == sa["n_camera_samples"] == 1024 * 1024 * 8 and sb["n_invalid"] == 0
+    for k in ("n_closest_rays", "n_shadow_rays"):
+        assert abs(int(sa[k]) - int(sb[k])) <= 1e-4 * sa[k], (k, sa[k], sb[k])
+    assert_image_parity(A, B, r.border, "pa4-cbox-path_mis 1024x1024x8")
+
+
+def test_nori_block_seeding_zscore(renderer_factory):
+    """The reference seeds ONE serial pcg32 stream per 32x32 block (src/independent.cpp:36-41); the device's
+    default seeds one stream per camera sample.  Different streams, same estimator: SURVEY 8(d)'s check for
+    that case -- per-pixel z-score of the oracle's NORI_SEED_NORI_BLOCK render against the GPU per-sample
+    render, <= 1 % of the pixels beyond 4 sigma and the whole-image mean within 0.5 %.  The per-pixel variance of
+    the mean comes from 16 independent GPU renders of spp / 16 samples each (disjoint sample indices)."""
+    from nori_amd import _capi as capi
+    from nori_amd.render import develop_host
+    sc = scenes.cornell_box(160, 160, 64, "path_mis", rfilter=RFilter("box"))
+    r, o = renderer_factory(sc), Oracle(sc, use_bvh=True)
+    groups, per = 16, 4
+    parts = np.stack([develop_host(r.render_host(spp_count=per, spp_begin=g * per)[0], r.border) for g in range(groups)])
+    gpu = develop_host(r.render_host()[0], r.border)
+    cpu = develop_host(o.render_host(seed_mode=capi.SEED_NORI_BLOCK)[0], o.border)
+    lum = lambda x: x @ np.float32([0.212671, 0.715160, 0.072169])
+    var_mean = lum(parts).var(axis=0, ddof=1) / groups           # variance of a 64-spp pixel mean
+    z = np.abs(lum(cpu) - lum(gpu)) / np.sqrt(2.0 * var_mean + 1e-12)
+    beyond = float((z > 4.0).mean())
+    print(f"[parity] nori-block seeding: {beyond:.3%} of pixels beyond 4 sigma, image means {cpu.mean():.5f} / {gpu.mean():.5f}")
+    assert beyond <= 0.01, beyond
+    assert abs(cpu.mean() - gpu.mean()) <= 5e-3 * cpu.mean()

@@ -70,11 +70,8 @@ def test_wavefront_matches_oracle_on_reference_scene(renderer_factory):
     B, sb = r.render_host()
     A, sa = Oracle(sc, use_bvh=True).render_host()
     assert sb["n_camera_samples"] == sa["n_camera_samples"] == 96 * 72 * 8
-    np.testing.assert_allclose(B[..., 3], A[..., 3], rtol=1e-5, atol=1e-6)
-    from nori_amd.render import develop_host
-    a, b = develop_host(A, r.border), develop_host(B, r.border)
-    rel = np.abs(a - b) / np.maximum(np.abs(a), 1e-2)
-    assert (rel < 1e-3).mean() > 0.98 and abs(a.mean() - b.mean()) < 2e-3 * a.mean()
+    from tests.test_gpu_parity import assert_image_parity
+    assert_image_parity(A, B, r.border, "pa5-cbox_mis 96x72x8 wavefront")
 
 
 def test_wavefront_empty_scene_and_options(renderer_factory):
@@ -170,12 +167,13 @@ def test_kernel_class_timing(renderer_factory):
         assert st0["trace_ms"] == 0 and st0["n_trace_launches"] == 0
 
 
-@pytest.mark.parametrize("name", ["pa1-bunny", "pa4-cbox-distributed", "pa4-cbox-whitted", "pa4-motto-dielectric",
-                                  "pa5-cbox_mis", "pa5-table_mis", "pa5-veach_mis"])
+@pytest.mark.parametrize("name", ["pa1-bunny", "pa4-cbox-distributed", "pa4-cbox-path_mis", "pa4-cbox-whitted",
+                                  "pa4-motto-dielectric", "pa5-cbox_mis", "pa5-table_mis", "pa5-veach_mis"])
 def test_reference_scenes_both_engines_and_oracle(renderer_factory, name):
     """Every shipped scene (geometry, materials, camera, integrator as in the XML; reduced resolution
     and sample count): both engines trace the same rays and produce the same frame, and the frame
-    agrees with the CPU oracle within the tolerance of DESIGN.md section 5."""
+    agrees with the CPU oracle within the SURVEY 8(d) image contract (>= 99.9 % of pixels within 1e-3,
+    mean relative error <= 1e-4)."""
     sc = Scene.load_npz(os.path.join(GOLDEN, name + ".npz"))
     sc.camera.width, sc.camera.height = sc.camera.width // 4, sc.camera.height // 4
     sc.sample_count = 4
@@ -188,13 +186,9 @@ def test_reference_scenes_both_engines_and_oracle(renderer_factory, name):
     o = Oracle(sc, use_bvh=True)
     ref, so = o.render_host()
     for k in ("n_closest_rays", "n_shadow_rays"):
-        assert abs(int(so[k]) - int(sb[k])) <= 2e-3 * so[k] + 2, k
-    np.testing.assert_allclose(b[..., 3], ref[..., 3], rtol=1e-5, atol=1e-6)
-    from nori_amd.render import develop_host
-    x, y = develop_host(ref, o.border), develop_host(b, wf.border)
-    rel = np.abs(x - y) / np.maximum(np.abs(x), 1e-2)
-    assert (rel < 1e-3).mean() > 0.97, (rel < 1e-3).mean()
-    assert abs(x.mean() - y.mean()) < 5e-3 * max(x.mean(), 1e-3)
+        assert abs(int(so[k]) - int(sb[k])) <= 1e-3 * so[k] + 2, k
+    from tests.test_gpu_parity import assert_image_parity
+    assert_image_parity(ref, b, wf.border, name)
 
 
 def test_fuzz_engines_short():

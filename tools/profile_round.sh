@@ -1,0 +1,32 @@
+# One round's profile set for bench.py's roofline (run on the GPU box):
+#   bash tools/profile_round.sh <tag> [workload]      -> gpurun_out/prof_<tag>/, then copy the summaries into profiles/
+#   1. the bench line itself                                   <tag>_bench.json
+#   2. rocprofv3 --kernel-trace --stats of the same command    <tag>_kernel_stats.csv
+#   3. counter passes (each its own rocprofv3 run, --kernel-trace only), ONE render pass each (tools/wf_probe.py, REPS=1):
+#      SQ issue / SQ mix / TCC hit-miss / FETCH_SIZE / WRITE_SIZE   <tag>_<pass>_counter_collection.csv
+#   4. tools/summarize_profile.py -> <tag>_counters.json  (what bench.py's `traffic` / `valu_busy_frac` read)
+set -u
+TAG=${1:-r2}
+WL=${2:-pa4-cbox-path_mis}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
+B="python bench.py --steps 3 --warmup 1 --workload $WL"
+timeout 600 $B 2>$OUT/bench.err | tail -1 > $OUT/${TAG}_bench.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o s -- $B --no-cpu-baseline > $OUT/stats.log 2>&1
+find /tmp/prof_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
+rm -rf /tmp/prof_stats
+export REPS=1 WORKLOAD=$WL
+run_pass() {
+  local NAME=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/prof_$NAME -o c -- python tools/wf_probe.py > $OUT/${NAME}.log 2>&1
+  find /tmp/prof_$NAME -name '*counter_collection.csv' -exec cp {} $OUT/${TAG}_${NAME}_counter_collection.csv \;
+  rm -rf /tmp/prof_$NAME
+}
+run_pass sq_issue SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
+run_pass sq_mix SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTIVE_INST_SCA SQ_WAVES
+run_pass tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
+run_pass fetch FETCH_SIZE
+run_pass write WRITE_SIZE
+python tools/summarize_profile.py $OUT $TAG $WL > $OUT/${TAG}_summary.txt 2>&1
+cat $OUT/${TAG}_summary.txt; cat $OUT/${TAG}_bench.json

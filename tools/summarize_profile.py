@@ -1,0 +1,85 @@
+"""rocprofv3 counter CSVs of ONE render pass (tools/profile_round.sh) -> <dir>/<tag>_counters.json, the file bench.py
+reads for `roofline.traffic` and the VALU-issue evidence.   usage: python tools/summarize_profile.py <dir> <tag> <workload> [engine]
+
+Derived per kernel (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles; FETCH_SIZE reads half of a wide
+coalesced stream on gfx950 -> doubled; counters are summed over the chip):
+  elapsed_cycles       GRBM_GUI_ACTIVE / 8 XCDs                         (cross-check: SQ_BUSY_CYCLES / 32 shader engines)
+  valu_busy_frac       4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x elapsed_cycles)      share of SIMD time issuing VALU
+  valu_lanes_per_instr SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU                  active lanes per VALU instruction (of 64)
+  valu_useful_frac     valu_busy_frac x lanes / 64                                  share of VALU lane-cycles doing work
+  hbm_bytes            (2 x FETCH_SIZE + WRITE_SIZE) x 1024
+  l2_hit_rate          TCC_HIT / (TCC_HIT + TCC_MISS)
+"""
+import collections, csv, glob, hashlib, json, os, re, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+d, tag, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+engine = sys.argv[4] if len(sys.argv) > 4 else "wavefront"
+
+
+def short(n):
+    return re.sub(r"\(anonymous namespace\)::|nrt::|void ", "", n).split("(")[0]
+
+
+def source_sha():
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "nori_amd", "csrc", "device", "*"))):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+acc = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(lambda: collections.defaultdict(int))
+for f in sorted(glob.glob(os.path.join(d, f"{tag}_*_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k.startswith(("__amd", "at::", "Cijk", "hip")):
+            continue
+        acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        launches[k][r["Counter_Name"]] += 1
+
+
+def derive(c):
+    out = {}
+    el = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+    if el > 0:
+        out["elapsed_cycles"] = el
+    if el > 0 and "SQ_ACTIVE_INST_VALU" in c:
+        out["valu_busy_frac"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * el), 4)
+    if c.get("SQ_ACTIVE_INST_VALU"):
+        out["valu_lanes_per_instr"] = round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / c["SQ_ACTIVE_INST_VALU"], 2)
+    if "valu_busy_frac" in out and "valu_lanes_per_instr" in out:
+        out["valu_useful_frac"] = round(out["valu_busy_frac"] * out["valu_lanes_per_instr"] / 64.0, 4)
+    if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+        out["hbm_bytes"] = int((2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024)
+    if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
+        out["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
+    if c.get("SQ_WAVE_CYCLES"):
+        for k2, n in (("SQ_WAIT_ANY", "wait_any_frac"), ("SQ_WAIT_INST_ANY", "wait_inst_frac"), ("SQ_ACTIVE_INST_ANY", "active_inst_frac")):
+            if k2 in c:
+                out[n] = round(c[k2] / c["SQ_WAVE_CYCLES"], 4)
+    return out
+
+
+kernels = {}
+for k, c in sorted(acc.items()):
+    kernels[k] = {"launches": max(launches[k].values()), "counters": {n: v for n, v in sorted(c.items())}, "derived": derive(c)}
+dom_prefix = "wf_extend" if engine == "wavefront" else "render_kernel"
+dom = collections.defaultdict(float)
+for k, c in acc.items():
+    if k.startswith(dom_prefix):
+        for n, v in c.items():
+            dom[n] += v
+dd = derive(dom)
+out = {"tag": tag, "workload": workload, "engine": engine, "device_source_sha": source_sha(),
+       "collected_with": "tools/profile_round.sh: one rocprofv3 --kernel-trace --pmc run per counter group, one render pass each (tools/wf_probe.py, REPS=1)",
+       "kernels": kernels, "dominant_kernel": dict(dd, name=dom_prefix + " (all launches of the pass)"),
+       "dominant_kernel_hbm_bytes": dd.get("hbm_bytes"),
+       "pass_hbm_bytes": int(sum(v["derived"].get("hbm_bytes", 0) for v in kernels.values())) or None}
+path = os.path.join(d, f"{tag}_counters.json")
+json.dump(out, open(path, "w"), indent=1)
+print(path)
+for k, v in kernels.items():
+    print(f"{k}: launches {v['launches']} {json.dumps(v['derived'])}")
+print("dominant:", json.dumps(out["dominant_kernel"]))

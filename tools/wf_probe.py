@@ -2,8 +2,8 @@ import os, sys
 sys.path.insert(0, ".")
 import torch
 from nori_amd.render import Renderer
-from nori_amd.scene import Scene
-sc = Scene.load_npz("tests/golden/pa4-cbox-path_mis.npz")
+from nori_amd import workloads
+sc = workloads.load(os.environ.get("WORKLOAD", "pa4-cbox-path_mis"), spp=int(os.environ["SPP"]) if "SPP" in os.environ else None).scene
 r = Renderer(0).upload(sc)
 r.set_option("engine", os.environ.get("ENGINE", "wavefront"))
 r.set_option("wavefront_paths", int(os.environ.get("PATHS", 1 << 28)))
