@@ -8,6 +8,7 @@
  * Microfacet parameter sets (src/dielectric.cpp:17-23, src/microfacet.cpp:17-36).
  */
 #pragma once
+#include "rt_math.h"
 #include "rt_types.h"
 
 namespace nrt {
@@ -65,7 +66,7 @@ NORI_HD float square_to_tent_pdf(f2 p) {
 NORI_HD f2 square_to_uniform_disk(f2 s) {
     float r = sqrtf(s.x);
     float sp, cp;
-    sincosf(2.0f * kPi * s.y, &sp, &cp);
+    det_sincosf(2.0f * kPi * s.y, &sp, &cp);
     return mk2(r * cp, r * sp);
 }
 NORI_HD float square_to_uniform_disk_pdf(f2 p) {
@@ -75,14 +76,14 @@ NORI_HD f3 square_to_uniform_sphere(f2 s) {
     float z = 1.0f - 2.0f * s.x;
     float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
     float sp, cp;
-    sincosf(2.0f * kPi * s.y, &sp, &cp);
+    det_sincosf(2.0f * kPi * s.y, &sp, &cp);
     return mk3(r * cp, r * sp, z);
 }
 NORI_HD f3 square_to_uniform_hemisphere(f2 s) {
     float z = s.x;
     float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
     float sp, cp;
-    sincosf(2.0f * kPi * s.y, &sp, &cp);
+    det_sincosf(2.0f * kPi * s.y, &sp, &cp);
     return mk3(r * cp, r * sp, z);
 }
 NORI_HD f3 square_to_cosine_hemisphere(f2 s) {
@@ -93,8 +94,8 @@ NORI_HD f3 square_to_cosine_hemisphere(f2 s) {
 NORI_HD float square_to_cosine_hemisphere_pdf(f3 v) { return v.z > 0.0f ? v.z * kInvPi : 0.0f; }
 NORI_HD f3 square_to_beckmann(f2 s, float alpha) {
     float sp, cp;
-    sincosf(2.0f * kPi * s.x, &sp, &cp);
-    float tan2 = -alpha * alpha * logf(1.0f - s.y);
+    det_sincosf(2.0f * kPi * s.x, &sp, &cp);
+    float tan2 = -alpha * alpha * det_logf(1.0f - s.y);
     float cosTheta = 1.0f / sqrtf(1.0f + tan2);
     float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
     return mk3(sinTheta * cp, sinTheta * sp, cosTheta);
@@ -104,7 +105,7 @@ NORI_HD float square_to_beckmann_pdf(f3 m, float alpha) {
     float cos2 = m.z * m.z;
     float tan2 = (1.0f - cos2) / cos2;
     float a2 = alpha * alpha;
-    return expf(-tan2 / a2) / (kPi * a2 * cos2 * m.z);
+    return det_expf(-tan2 / a2) / (kPi * a2 * cos2 * m.z);
 }
 
 NORI_HD f3 warp_dispatch(int warp, float param, f2 s) {

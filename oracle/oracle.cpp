@@ -201,6 +201,21 @@ int oracle_pcg32_uints(uint64_t seed_state, uint64_t seed_seq, int use_default, 
 
 float oracle_fresnel(float c, float e, float i) { return fresnel(c, e, i); }
 
+/* op 0: sin, 1: cos, 2: log, 3: exp -- the oracle's specified transcendental functions (oracle_libm.h) */
+int oracle_libm_eval(int op, const float *x, size_t n, float *out) {
+    for (size_t i = 0; i < n; ++i) {
+        float s, c;
+        switch (op) {
+        case 0: oracle_libm::sincos(x[i], &s, &c); out[i] = s; break;
+        case 1: oracle_libm::sincos(x[i], &s, &c); out[i] = c; break;
+        case 2: out[i] = oracle_libm::log(x[i]); break;
+        case 3: out[i] = oracle_libm::exp(x[i]); break;
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
 int oracle_splat(oracle_ctx *ctx, const float *positions, const float *values, size_t n, float *rgbw) {
     if (!ctx) return NORI_ERR_INVALID_ARGUMENT;
     const Scene &sc = *ctx->scene;

@@ -54,6 +54,8 @@ int oracle_pcg32_floats(const uint64_t *seed_state, const uint64_t *seed_seq, si
 int oracle_pcg32_uints(uint64_t seed_state, uint64_t seed_seq, int use_default, uint32_t count, uint32_t *out);
 int oracle_splat(oracle_ctx *ctx, const float *positions, const float *values, size_t n, float *rgbw);
 float oracle_fresnel(float cos_theta_i, float ext_ior, float int_ior);
+/* sin (0) / cos (1) / log (2) / exp (3) as the oracle evaluates them (oracle_libm.h) */
+int oracle_libm_eval(int op, const float *x, size_t n, float *out);
 
 /* renderBlock + render (src/main.cpp:27-119) with `threads` std::thread
  * workers pulling 32x32 blocks in the reference's spiral order.  Same

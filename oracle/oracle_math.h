@@ -28,6 +28,8 @@
 #include <limits>
 #include <vector>
 
+#include "oracle_libm.h"
+
 namespace oracle {
 
 /* include/nori/common.h:38-48 */
@@ -219,8 +221,8 @@ struct Frame {
 /* src/common.cpp:225-235 */
 inline Vec3 sphericalDirection(float theta, float phi) {
     float sinTheta, cosTheta, sinPhi, cosPhi;
-    sincosf(theta, &sinTheta, &cosTheta);
-    sincosf(phi, &sinPhi, &cosPhi);
+    oracle_libm::sincos(theta, &sinTheta, &cosTheta);
+    oracle_libm::sincos(phi, &sinPhi, &cosPhi);
     return Vec3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
 }
 

@@ -50,7 +50,7 @@ struct Warp {
     static Vec2 squareToUniformDisk(const Vec2 &s) {
         float r = std::sqrt(s.x);
         float sinPhi, cosPhi;
-        sincosf(2.0f * kPi * s.y, &sinPhi, &cosPhi);
+        oracle_libm::sincos(2.0f * kPi * s.y, &sinPhi, &cosPhi);
         return Vec2(r * cosPhi, r * sinPhi);
     }
     static float squareToUniformDiskPdf(const Vec2 &p) {
@@ -60,7 +60,7 @@ struct Warp {
         float z = 1.0f - 2.0f * s.x;
         float r = std::sqrt(std::max(0.0f, 1.0f - z * z));
         float sinPhi, cosPhi;
-        sincosf(2.0f * kPi * s.y, &sinPhi, &cosPhi);
+        oracle_libm::sincos(2.0f * kPi * s.y, &sinPhi, &cosPhi);
         return Vec3(r * cosPhi, r * sinPhi, z);
     }
     static float squareToUniformSpherePdf(const Vec3 &) { return kInvFourPi; }
@@ -68,7 +68,7 @@ struct Warp {
         float z = s.x;
         float r = std::sqrt(std::max(0.0f, 1.0f - z * z));
         float sinPhi, cosPhi;
-        sincosf(2.0f * kPi * s.y, &sinPhi, &cosPhi);
+        oracle_libm::sincos(2.0f * kPi * s.y, &sinPhi, &cosPhi);
         return Vec3(r * cosPhi, r * sinPhi, z);
     }
     static float squareToUniformHemispherePdf(const Vec3 &v) { return v.z >= 0 ? kInvTwoPi : 0.0f; }
@@ -80,8 +80,8 @@ struct Warp {
     static float squareToCosineHemispherePdf(const Vec3 &v) { return v.z > 0 ? v.z * kInvPi : 0.0f; }
     static Vec3 squareToBeckmann(const Vec2 &s, float alpha) {
         float sinPhi, cosPhi;
-        sincosf(2.0f * kPi * s.x, &sinPhi, &cosPhi);
-        float tan2 = -alpha * alpha * std::log(1.0f - s.y);
+        oracle_libm::sincos(2.0f * kPi * s.x, &sinPhi, &cosPhi);
+        float tan2 = -alpha * alpha * oracle_libm::log(1.0f - s.y);
         float cosTheta = 1.0f / std::sqrt(1.0f + tan2);
         float sinTheta = std::sqrt(std::max(0.0f, 1.0f - cosTheta * cosTheta));
         return Vec3(sinTheta * cosPhi, sinTheta * sinPhi, cosTheta);
@@ -91,7 +91,7 @@ struct Warp {
         float cos2 = m.z * m.z;
         float tan2 = (1.0f - cos2) / cos2;
         float a2 = alpha * alpha;
-        return std::exp(-tan2 / a2) / (kPi * a2 * cos2 * m.z);
+        return oracle_libm::exp(-tan2 / a2) / (kPi * a2 * cos2 * m.z);
     }
 };
 

@@ -83,6 +83,7 @@ def oracle_lib():
             "oracle_pcg32_uints": (C.c_int, [C.c_uint64, C.c_uint64, C.c_int, C.c_uint32, _P]),
             "oracle_splat": (C.c_int, [_P, _P, _P, C.c_size_t, _P]),
             "oracle_fresnel": (C.c_float, [C.c_float, C.c_float, C.c_float]),
+            "oracle_libm_eval": (C.c_int, [C.c_int, _P, C.c_size_t, _P]),
             "oracle_render": (C.c_int, [_P, C.POINTER(capi.RenderParams), _P, C.POINTER(capi.RenderStats), C.c_int]),
             "oracle_develop": (C.c_int, [_P, _P, _P]),
         }
@@ -101,6 +102,7 @@ def emu_lib():
             "emu_border_size": (C.c_int, [_P]),
             "emu_intersect": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
             "emu_packed_vs_scalar": (C.c_size_t, [C.c_size_t, C.c_uint64]),
+            "emu_libm_eval": (C.c_int, [C.c_int, _P, C.c_size_t, _P]),
             "emu_sample_rays": (C.c_int, [_P, _P, C.c_size_t, _P]),
             "emu_li": (C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
             "emu_li_records": (C.c_int, [_P, _P, C.c_size_t, _P, _P, _P]),
@@ -216,6 +218,15 @@ class _CpuBackend:
         p = _f32(points, 3)
         out = np.zeros(p.shape[0], np.float32)
         assert getattr(cls.lib_fn(), cls.prefix + "warp_pdf")(capi.WARP_NAMES[name], float(param), ptr(p), p.shape[0], ptr(out)) == 0
+        return out
+
+    @classmethod
+    def libm(cls, op: str, x):
+        """sin / cos / log / exp as this backend evaluates them on the render path (one specification:
+        rt_math.h on the device side, oracle_libm.h in the oracle)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.zeros_like(x)
+        assert getattr(cls.lib_fn(), cls.prefix + "libm_eval")({"sin": 0, "cos": 1, "log": 2, "exp": 3}[op], ptr(x), x.size, ptr(out)) == 0
         return out
 
     @classmethod

@@ -282,6 +282,21 @@ int emu_pcg32_floats(const uint64_t *ss, const uint64_t *sq, size_t n, uint32_t 
  * merge tile into the frame. */
 /* Unit check of the packed kernels of rt_trace.h against their scalar statements: n random (triangle pair,
    ray) and (node, ray) cases from `seed`; returns the number of mismatching results (bit level). */
+/* sin (0) / cos (1) / log (2) / exp (3) of the device headers (rt_math.h), evaluated on the CPU */
+int emu_libm_eval(int op, const float *x, size_t n, float *out) {
+    for (size_t i = 0; i < n; ++i) {
+        float s, c;
+        switch (op) {
+        case 0: det_sincosf(x[i], &s, &c); out[i] = s; break;
+        case 1: det_sincosf(x[i], &s, &c); out[i] = c; break;
+        case 2: out[i] = det_logf(x[i]); break;
+        case 3: out[i] = det_expf(x[i]); break;
+        default: return -1;
+        }
+    }
+    return 0;
+}
+
 size_t emu_packed_vs_scalar(size_t n, uint64_t seed) {
     Rng r; rng_seed(r, seed, 7);
     auto rnd = [&](float lo, float hi) { return lo + (hi - lo) * rng_next_float(r); };

@@ -192,3 +192,48 @@ def test_wavefront_records_walk_equals_the_direct_path_loop(integ):
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert (a.sum(1) > 0).mean() > 0.01          # the comparison is not vacuous (path_mats: only light hits count)
     e.close()
+
+
+def test_specified_transcendentals():
+    """sin / cos / log / exp of the render path follow ONE specification (binary64 arithmetic without FMA, one
+    rounding to binary32), implemented twice -- rt_math.h for the device, oracle_libm.h for the
+    oracle.  The two agree bit for bit, and both equal the correctly rounded value (numpy float64 -> float32) on
+    every one of 4 M arguments per function over the ranges the path uses."""
+    from tests.backends import Emu, Oracle
+    rng = np.random.default_rng(3)
+    n = 4_000_000
+    args = {
+        "sin": rng.uniform(0, 2 * np.pi, n).astype(np.float32), "cos": rng.uniform(0, 2 * np.pi, n).astype(np.float32),
+        "log": np.concatenate([1.0 - rng.uniform(0, 1, n // 2), rng.uniform(1e-30, 1e30, n // 2)]).astype(np.float32),
+        "exp": np.concatenate([-rng.exponential(8.0, n // 2), rng.uniform(-104, 88, n // 2)]).astype(np.float32),
+    }
+    exact = {"sin": np.sin, "cos": np.cos, "log": np.log, "exp": np.exp}
+    for op, x in args.items():
+        x = x[np.isfinite(x) & ((x > 0) | (op != "log"))]
+        a, b = Oracle.libm(op, x), Emu.libm(op, x)
+        assert np.array_equal(a, b), op
+        with np.errstate(over="ignore", under="ignore"):
+            ref = exact[op](x.astype(np.float64)).astype(np.float32)
+        assert int((a != ref).sum()) == 0, (op, int((a != ref).sum()))
+    edge = np.float32([0.0, 1.0, np.inf, 1e-45, 3.4e38])
+    assert np.array_equal(Oracle.libm("log", edge), np.log(edge.astype(np.float64)).astype(np.float32))
+    assert np.array_equal(Oracle.libm("exp", np.float32([-200, -104.5, 0, 89, 1e9])), np.float32([0, 0, 1, np.inf, np.inf]))
+    neg = rng.uniform(-50, 50, 100000).astype(np.float32)          # sphericalDirection takes any angle
+    assert np.array_equal(Oracle.libm("sin", neg), np.sin(neg.astype(np.float64)).astype(np.float32))
+
+
+def test_emulated_device_paths_equal_the_oracle_bitwise():
+    """With the transcendental functions pinned, the per-lane device code (compiled for the CPU) and the oracle
+    produce the same radiance for every path, bit for bit -- the CPU-side twin of tests/test_gpu_parity.py."""
+    from nori_amd.scene import Bsdf
+    from tests import scenes
+    from tests.backends import Emu, Oracle
+    rng = np.random.default_rng(11)
+    for integ, sb in [("path_mis", [Bsdf("mirror"), Bsdf("dielectric")]), ("path_ems", [Bsdf("microfacet", (0.2, 0.3, 0.1), 0.2), Bsdf("diffuse")]),
+                      ("whitted", [Bsdf("mirror"), Bsdf("dielectric")])]:
+        sc = scenes.cornell_box(16, 16, 1, integ, sphere_bsdfs=sb)
+        e, o = Emu(sc), Oracle(sc, use_bvh=True)
+        n = 20000
+        rays = o.sample_rays(rng.uniform(0, 16, (n, 2)).astype(np.float32))
+        ss = rng.integers(0, 2 ** 62, n, dtype=np.uint64); sq = rng.integers(0, 2 ** 62, n, dtype=np.uint64)
+        assert np.array_equal(o.li(rays, ss, sq), e.li(rays, ss, sq)), integ
