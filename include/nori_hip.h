@@ -247,6 +247,8 @@ typedef struct nori_accel_info {
     uint64_t total_bytes;    /* nodes + leaf triangles in HBM        */
     float build_ms;
     float sah_cost;
+    uint32_t node_children;  /* boxes one node record holds: 2 (BVH2) or 4 (wide nodes, quantised boxes) */
+    uint32_t reserved;
 } nori_accel_info;
 
 typedef struct nori_hip_ctx nori_hip_ctx;
@@ -275,6 +277,9 @@ int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out);
  *   "engine"          "auto" (default: wavefront for >= 2^24 camera samples per call,
  *                     else megakernel) | "megakernel" | "wavefront"
  *   "wavefront_paths" paths in flight per wavefront batch (default 2^28, ~180 B of HBM each)
+ *   "accel_layout"    node layout of the NEXT nori_hip_build_accel: "bvh2" (64-B node = two full-precision child
+ *                     boxes) | "bvh4q" (64-B node = four child boxes quantised to 8 bits: half the node fetches,
+ *                     for trees that do not fit the caches) | "auto" (default: bvh4q from 2^20 triangles)
  * Unknown keys return NORI_ERR_INVALID_ARGUMENT. */
 int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value);
 

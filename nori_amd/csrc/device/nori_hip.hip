@@ -352,6 +352,7 @@ struct nori_hip_ctx {
     int stack_depth = 32;
     uint64_t lbvh_bytes = 0;
     int engine = -1;                /* -1 auto, 0 megakernel, 1 wavefront */
+    int accel_layout = -1;          /* -1 auto (wide from 2^20 triangles), 0 bvh2, 1 bvh4q (wide nodes) */
     size_t wavefront_paths = (size_t) 1 << 28;     /* 240 B of state each (two copies) + film: ~80 GB of the 288 GB */
     /* render-time resources of THIS context (never shared, freed in nori_hip_destroy): the wavefront
        engine's state pool / streams / events and the film's sample store + tile accumulators */
@@ -486,7 +487,11 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
         ctx->dev.nodes = res.d_nodes; ctx->dev.tris = res.d_tris;
         ctx->lbvh_bytes = (uint64_t) std::max<uint32_t>(res.n_nodes, 1) * kNodeQuads * 16 + (uint64_t) res.n_pairs * kPairQuads * 16;
     } else {
-        std::string err = build_bvh_sah(ctx->host, 64, ctx->bvh);
+        int layout = ctx->accel_layout;
+        if (const char *e = getenv("NORI_HIP_ACCEL_LAYOUT")) layout = std::string(e) == "bvh4q" ? 1 : (std::string(e) == "bvh2" ? 0 : -1);
+        const bool wide = layout == 1 || (layout < 0 && ctx->dev.n_triangles >= (1u << 20));
+        std::string err = build_bvh_sah(ctx->host, 64, ctx->bvh, wide);
+        if (!err.empty() && wide) err = build_bvh_sah(ctx->host, 64, ctx->bvh, false);      /* wide tree too deep for the stack: BVH2 */
         if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
         int rc;
         if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.nodes, &ctx->dev.nodes))) return rc;
@@ -494,12 +499,14 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
         ctx->lbvh_bytes = 0;
     }
     ctx->dev.root = ctx->bvh.root;
+    ctx->dev.wide = ctx->bvh.wide ? 1u : 0u;
     ctx->stack_depth = ctx->bvh.max_depth + 1 <= 32 ? 32 : 64;
     nori_accel_info &in = ctx->info;
     in.n_triangles = ctx->dev.n_triangles; in.n_nodes = ctx->bvh.n_nodes; in.n_leaves = ctx->bvh.n_leaves;
     in.max_depth = ctx->bvh.max_depth; in.node_bytes = kNodeQuads * 16; in.tri_bytes = kPairQuads * 16 / 2;
     in.total_bytes = ctx->lbvh_bytes ? ctx->lbvh_bytes : (uint64_t) ctx->bvh.nodes.size() * 16 + (uint64_t) ctx->bvh.tris.size() * 16;
     in.build_ms = ctx->bvh.build_ms; in.sah_cost = ctx->bvh.sah_cost;
+    in.node_children = ctx->bvh.wide ? 4u : 2u; in.reserved = 0u;
     ctx->have_accel = true;
     return NORI_OK;
 }
@@ -518,6 +525,13 @@ int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value) {
         const long long n = atoll(value);
         if (n < 256) { ctx->error = "set_option: wavefront_paths must be >= 256"; return NORI_ERR_INVALID_ARGUMENT; }
         ctx->wavefront_paths = (size_t) n;
+        return NORI_OK;
+    }
+    if (k == "accel_layout") {
+        if (v == "bvh2") ctx->accel_layout = 0;
+        else if (v == "bvh4q") ctx->accel_layout = 1;
+        else if (v == "auto") ctx->accel_layout = -1;
+        else { ctx->error = "set_option: accel_layout must be auto, bvh2 or bvh4q"; return NORI_ERR_INVALID_ARGUMENT; }
         return NORI_OK;
     }
     ctx->error = "set_option: unknown key " + k;
@@ -830,6 +844,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
     /* auto: the wavefront engine wins once there are enough paths to keep its kernels full
        (measured on pa4 cbox: 7.3 vs 6.8 Grays/s at 2.7e8 paths); small jobs avoid its launch train */
     if (engine < 0) engine = (size_t) a.n_sel_tiles * 256 * a.spp_count >= ((size_t) 1 << 24) ? 1 : 0;
+    if (ctx->dev.wide) engine = 1;      /* wide nodes are walked by the wavefront engine (and the batch twins) only */
     if (engine == 1 && a.n_sel_tiles > 0 && a.spp_count > 0) {
         WfLaunch wl;
         wl.spp_begin = a.spp_begin; wl.spp_count = a.spp_count; wl.tile_mod = a.tile_mod; wl.tile_rem = a.tile_rem;

@@ -33,6 +33,17 @@ NORI_HD float slab_rcp(float d) {
     return r;
 }
 
+/* The same for WIDE trees: the clamp is 2^60, a power of two, so that products with it are exact and the
+ * quantised-plane form t = q * (r 2^e) + (origin - o) * r cannot run into inf - inf. */
+NORI_HD float slab_rcp_wide(float d) {
+    float r = 1.0f / d;
+    if (!(fabsf(r) <= 1.152921504606846976e18f)) r = (f2u(d) >> 31) ? -1.152921504606846976e18f : 1.152921504606846976e18f;
+    return r;
+}
+
+/* byte k of a dword as float (v_cvt_f32_ubyte0..3 on the device) */
+NORI_HD float byte_to_float(uint32_t w, int k) { return (float) ((w >> (8 * k)) & 255u); }
+
 /* Moeller-Trumbore on a pre-gathered leaf record; src/mesh.cpp:39-76 */
 NORI_HD bool tri_test(f3 p0, f3 edge1, f3 edge2, f3 o, f3 d, float &u, float &v, float &t) {
     f3 pvec = cross(d, edge2);
@@ -95,10 +106,16 @@ NORI_HD bool trav_at_inner(const Trav &tv) { return tv.node >= 0; }
 NORI_HD bool trav_at_leaf(const Trav &tv) { return (uint32_t) tv.node > 0x80000000u; }
 NORI_HD void trav_idle(Trav &tv) { tv.node = kTravDone; tv.any = false; }
 
-template <class Stack>
+/* node layout a kernel is compiled for: BVH2 nodes, WIDE nodes (rt_types.h), or whichever the scene has (run-time
+   branch; the batch twins and wf_finish, where registers are not the limit) */
+enum { kLayoutBvh2 = 0, kLayoutWide = 1, kLayoutAny = 2 };
+
+template <int LAYOUT = kLayoutBvh2, class Stack>
 NORI_HD void trav_begin(const DevScene &sc, const RayIn &ray, bool any, Stack &stack, Trav &tv) {
     tv.o = ray.o; tv.d = ray.d;
-    tv.rcp = mk3(slab_rcp(ray.d.x), slab_rcp(ray.d.y), slab_rcp(ray.d.z));
+    const bool wide = LAYOUT == kLayoutWide || (LAYOUT == kLayoutAny && sc.wide != 0u);
+    tv.rcp = wide ? mk3(slab_rcp_wide(ray.d.x), slab_rcp_wide(ray.d.y), slab_rcp_wide(ray.d.z))
+                  : mk3(slab_rcp(ray.d.x), slab_rcp(ray.d.y), slab_rcp(ray.d.z));
     tv.mint = ray.mint;
     tv.hit.tri = kNoHit; tv.hit.mesh = kNoHit; tv.hit.t = ray.maxt; tv.hit.u = 0.0f; tv.hit.v = 0.0f;
     tv.any = any;
@@ -138,6 +155,79 @@ NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, Travers
     } else {
         trav_pop(stack, tv);
     }
+}
+
+/* One WIDE-node step (rt_types.h): the four quantised child boxes of one 64-B record.
+ *   t = q * A + B per plane, A = r 2^e (exact), B = (origin - o) r: one v_cvt_f32_ubyte + one v_fma per plane;
+ *   the ray's direction signs pick which plane dword is the near one per axis -- no per-child min / max.
+ * Conservative by construction, not by tuned factors.  With u = 2^-24 the computed t of a plane on axis i differs
+ * from the exact one by at most 2u |t| + 2u |B_i| <= S_i = 4e-7 (255 |A_i| + |B_i|) (B carries two roundings plus the one of B -+ S, the
+ * fma one, r half an ulp).  The slack is applied PER AXIS, folded into B: near planes use B_i - S_i, far planes
+ * B_i + S_i, so every computed near / far value lies on the safe side of the exact one and the plain interval test
+ * never skips a child whose exact interval overlaps [0, limit].  (A single slack for all axes would let the axis
+ * with the smallest direction component -- huge |B_i| -- switch culling off for the whole ray.)
+ * Closest child first; the others go to the stack in slot order along the node's axis, reversed for rays that
+ * travel against it, so that the nearer ones pop first. */
+/* the four planes t = q A + B of one plane dword (child k in byte k), as explicit scalars: no arrays, nothing for
+   the compiler to index dynamically */
+struct Wide4 { float a, b, c, d; };
+NORI_HD Wide4 wide_planes(uint32_t w, float A, float B) {
+    /* explicit fused multiply-add (IEEE, one rounding -- the same bits on the device and in the CPU twins); the node
+       test is not part of the reference's arithmetic, only its conservativeness matters */
+    Wide4 r;
+    r.a = __builtin_fmaf(byte_to_float(w, 0), A, B); r.b = __builtin_fmaf(byte_to_float(w, 1), A, B);
+    r.c = __builtin_fmaf(byte_to_float(w, 2), A, B); r.d = __builtin_fmaf(byte_to_float(w, 3), A, B);
+    return r;
+}
+
+template <bool COUNT, class Stack>
+NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt) {
+    const f4 *nq = sc.nodes + (size_t) tv.node * kNodeQuads;
+    const f4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+    if (COUNT) cnt.nodes++;
+    const uint32_t meta = f2u(q0.w);
+    const int l0 = (int) f2u(q3.x), l1 = (int) f2u(q3.y), l2 = (int) f2u(q3.z), l3 = (int) f2u(q3.w);
+    bool h0, h1, h2, h3;
+    float n0 = 0.0f, n1 = 0.0f, n2 = 0.0f, n3 = 0.0f;
+    const bool nx = tv.rcp.x < 0.0f, ny = tv.rcp.y < 0.0f, nz = tv.rcp.z < 0.0f;
+    if (meta & kWideAllHit) {
+        h0 = l0 != kWideEmpty; h1 = l1 != kWideEmpty; h2 = l2 != kWideEmpty; h3 = l3 != kWideEmpty;
+    } else {
+        const float Ax = ldexpf(tv.rcp.x, (int) (meta & 255u) - 128), Ay = ldexpf(tv.rcp.y, (int) ((meta >> 8) & 255u) - 128),
+                    Az = ldexpf(tv.rcp.z, (int) ((meta >> 16) & 255u) - 128);
+        const float Bx = (q0.x - tv.o.x) * tv.rcp.x, By = (q0.y - tv.o.y) * tv.rcp.y, Bz = (q0.z - tv.o.z) * tv.rcp.z;
+        const float Sx = __builtin_fmaf(fabsf(Ax), 255.0f * 4e-7f, fabsf(Bx) * 4e-7f), Sy = __builtin_fmaf(fabsf(Ay), 255.0f * 4e-7f, fabsf(By) * 4e-7f),
+                    Sz = __builtin_fmaf(fabsf(Az), 255.0f * 4e-7f, fabsf(Bz) * 4e-7f);
+        const float limit = tv.hit.t;
+        const uint32_t loX = f2u(q1.x), loY = f2u(q1.y), loZ = f2u(q1.z), hiX = f2u(q1.w), hiY = f2u(q2.x), hiZ = f2u(q2.y);
+        const Wide4 nX = wide_planes(nx ? hiX : loX, Ax, Bx - Sx), fX = wide_planes(nx ? loX : hiX, Ax, Bx + Sx);
+        const Wide4 nY = wide_planes(ny ? hiY : loY, Ay, By - Sy), fY = wide_planes(ny ? loY : hiY, Ay, By + Sy);
+        const Wide4 nZ = wide_planes(nz ? hiZ : loZ, Az, Bz - Sz), fZ = wide_planes(nz ? loZ : hiZ, Az, Bz + Sz);
+        n0 = fmaxf(nX.a, fmaxf(nY.a, nZ.a)); n1 = fmaxf(nX.b, fmaxf(nY.b, nZ.b));
+        n2 = fmaxf(nX.c, fmaxf(nY.c, nZ.c)); n3 = fmaxf(nX.d, fmaxf(nY.d, nZ.d));
+        const float f0 = fminf(fX.a, fminf(fY.a, fZ.a)), f1 = fminf(fX.b, fminf(fY.b, fZ.b));
+        const float f2 = fminf(fX.c, fminf(fY.c, fZ.c)), f3 = fminf(fX.d, fminf(fY.d, fZ.d));
+        h0 = (n0 <= f0) && (f0 >= 0.0f) && (n0 <= limit); h1 = (n1 <= f1) && (f1 >= 0.0f) && (n1 <= limit);
+        h2 = (n2 <= f2) && (f2 >= 0.0f) && (n2 <= limit); h3 = (n3 <= f3) && (f3 >= 0.0f) && (n3 <= limit);
+    }
+    /* slot order along the node's axis, reversed for a ray that travels against it; walk the slots from the far end:
+       whatever is pushed later pops earlier; the nearest child found so far is kept for the next step */
+    const uint32_t axis = (meta >> 24) & 3u;
+    const bool rev = (axis == 0u && nx) || (axis == 1u && ny) || (axis == 2u && nz);      /* booleans only: selecting a component
+                                                                                            of tv.rcp by index would send tv to scratch */
+    int first = kTravDone; float firstKey = 0.0f; bool have = false;
+    auto visit = [&](bool h, float key, int lk) {
+        if (!h) return;
+        if (!have) { first = lk; firstKey = key; have = true; }
+        else if (key <= firstKey) { stack.push(first); first = lk; firstKey = key; }
+        else stack.push(lk);
+    };
+    visit(rev ? h0 : h3, rev ? n0 : n3, rev ? l0 : l3);
+    visit(rev ? h1 : h2, rev ? n1 : n2, rev ? l1 : l2);
+    visit(rev ? h2 : h1, rev ? n2 : n1, rev ? l2 : l1);
+    visit(rev ? h3 : h0, rev ? n3 : n0, rev ? l3 : l0);
+    if (have) tv.node = first;
+    else trav_pop(stack, tv);
 }
 
 /* Moeller-Trumbore (src/mesh.cpp:39-76) on TWO triangles at once: every quantity is a 2-wide vector
@@ -208,10 +298,12 @@ NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
 template <bool COUNT, class Stack>
 NORI_HD bool traverse(const DevScene &sc, const RayIn &ray, bool any, Stack &stack, Hit &hit, TraversalCounters &cnt) {
     Trav tv;
-    trav_begin(sc, ray, any, stack, tv);
+    trav_begin<kLayoutAny>(sc, ray, any, stack, tv);
     while (trav_active(tv)) {
-        if (trav_at_inner(tv)) trav_inner_step<COUNT>(sc, stack, tv, cnt);
-        else trav_leaf_step<COUNT>(sc, stack, tv, cnt);
+        if (trav_at_inner(tv)) {
+            if (sc.wide) trav_wide_step<COUNT>(sc, stack, tv, cnt);
+            else trav_inner_step<COUNT>(sc, stack, tv, cnt);
+        } else trav_leaf_step<COUNT>(sc, stack, tv, cnt);
     }
     hit = tv.hit;
     return hit.tri != kNoHit;

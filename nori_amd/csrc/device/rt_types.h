@@ -141,6 +141,25 @@ NORI_HD void node_pack(const float lmn[3], const float lmx[3], const float rmn[3
 }
 constexpr int kMaxLeafTris = 8;      /* = 4 pairs */
 
+/* WIDE node = BVH4 with quantised child boxes, also 64 B = 4 x dwordx4: the layout for scenes whose tree does not
+ * fit L2 + Infinity Cache (traversal is bound by HBM bytes and dependent fetches there): half the
+ * node visits of the BVH2 at the same bytes per visit.
+ *   q0 = (origin.x, origin.y, origin.z, bits meta)   meta = ex | ey << 8 | ez << 16 | axis << 24 | kWideAllHit
+ *                                                     scale of axis a = 2^(e_a - 128); axis = the node's widest axis
+ *   q1 = (bits loX, bits loY, bits loZ, bits hiX)     one dword per plane set: child k's 8-bit coordinate in byte k
+ *   q2 = (bits hiY, bits hiZ, 0, 0)
+ *   q3 = (bits link0, link1, link2, link3)            child links as in the BVH2 node (>= 0 inner, < 0 leaf)
+ * Child k covers [origin_a + lo_a[k] 2^(e_a-128), origin_a + hi_a[k] 2^(e_a-128)] on axis a, a superset of its true
+ * (padded) box: origin = the node box's lower corner, lo rounded down, hi rounded up (scene_prep.cpp, wide_pack).
+ * The children are stored in ascending order of their centre along `axis`: slot order = front-to-back order for a
+ * ray that travels in +axis, back-to-front otherwise.  An unused slot has lo = 255, hi = 0 (never hit) and link
+ * kWideEmpty = the leaf code of pair record 0, which wide trees reserve as an all-zero pair (never hit).
+ * kWideAllHit: a child box is unbounded (the subtree of numerically collinear triangles, tri_box_pad): no box test,
+ * every child is visited. */
+constexpr uint32_t kWideAllHit = 1u << 26;
+constexpr int32_t kWideEmpty = -1;           /* ~((0 << 3) | 0): first_pair 0, one pair */
+constexpr float kWideInfinite = 1e37f;       /* |coordinate| beyond this: the box counts as unbounded */
+
 /* Leaf triangles are stored in PAIRS, 96 B = 6 x dwordx4 per pair, de-indexed and pre-gathered in leaf
  * order, so that one leaf step is one contiguous read and tests two triangles (a, b) with packed-f32
  * math (rt_trace.h, tri_pair_test).  e1 = p1 - p0, e2 = p2 - p0: the IEEE subtraction mesh.cpp:43
@@ -223,6 +242,7 @@ struct DevScene {
     uint32_t n_triangles;
     uint32_t n_cdf;             /* entries of emitter_cdf */
     int32_t root;               /* child-link code of the root */
+    uint32_t wide;              /* nodes are WIDE nodes (BVH4, quantised boxes) instead of BVH2 nodes */
     CameraRec camera;
     FilterRec filter;
     IntegratorRec integrator;

@@ -156,8 +156,8 @@ __device__ __forceinline__ bool first_vertex(const DevScene &sc, const WfBatch &
 
 /* Accel::rayIntersect for every path of copy `cur`: the shadow ray (if any) first, then the
    continuation ray, by the same lane; one 16-B hit record per path. */
-template <int STACK, bool SPILL, bool COUNT, bool FIRST>
-__global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
+template <int STACK, bool SPILL, bool COUNT, bool FIRST, bool WIDE>
+__global__ __launch_bounds__(kB, WIDE ? 5 : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStackW<STACK, SPILL> stack;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
                     if (first_vertex(sc, bt, i, ps, ray, rng)) {
                         b.samp_pos[i] = ps;
                         rid = i << 2;
-                        trav_begin(sc, ray, false, stack, tv);
+                        trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, false, stack, tv);
                         ++nClosest; ++nCam;
                         if (!trav_active(tv)) {
                             b.hit[i] = hit_pack(nullptr, false);
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
                     RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z);
                     ray.mint = any ? kEpsilon : o.w; ray.maxt = d.w;
                     rid = pend ? (rid & ~2u) : ((i << 2) | ((any && (fl & F_HAS_A)) ? 2u : 0u));
-                    trav_begin(sc, ray, any, stack, tv);
+                    trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, any, stack, tv);
                     if (any) ++nShadow; else ++nClosest;
                     if (!trav_active(tv)) {            /* empty scene: nothing occludes, nothing is hit */
                         if (rid & 2u) { ++nClosest; rid &= ~2u; }
@@ -252,7 +252,10 @@ __global__ __launch_bounds__(kB, 8) void wf_extend(DevScene sc, WfBuf b, int cur
         /* inner-node steps run every trip; the (rarer) triangle step only when enough lanes
            wait at a leaf or nobody has an inner node to test */
         if (COUNT) { const int ni = __popcll(__ballot(trav_at_inner(tv))); zc[Z_TRIPS]++; if (ni) { zc[Z_INNER_TRIPS]++; zc[Z_INNER_LANES] += (uint32_t) ni; } }
-        if (trav_at_inner(tv)) trav_inner_step<COUNT>(sc, stack, tv, tc);
+        if (trav_at_inner(tv)) {
+            if (WIDE) trav_wide_step<COUNT>(sc, stack, tv, tc);      /* BVH4, quantised boxes: scenes beyond the caches */
+            else trav_inner_step<COUNT>(sc, stack, tv, tc);
+        }
         const bool atLeaf = trav_at_leaf(tv);
         const int nLeaf = __popcll(__ballot(atLeaf));
         const bool innerLeft = __ballot(trav_at_inner(tv)) != 0ull;
@@ -509,7 +512,12 @@ std::string ensure_pool(Pool &pool, size_t records) {
 template <int STACK, bool SPILL, bool COUNT, bool FIRST>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, const WfBatch &bt, hipStream_t s) {
     const size_t lds = (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int);
-    hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill, bt);
+    if (sc.wide) {
+        /* wide trees push up to three children per step: always the spilling stack */
+        if (SPILL) hipLaunchKernelGGL((wf_extend<STACK, true, COUNT, FIRST, true>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill, bt);
+    } else {
+        hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST, false>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill, bt);
+    }
 }
 
 /* lds_stack: entries kept in LDS (16 / 24 / 32); spill: the tree is deeper than that;
@@ -682,11 +690,14 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     /* traversal stack: what the tree needs, at most `lds_stack` entries of it in LDS */
     int lds_stack = L.stack_depth <= 16 ? 16 : 24;
     if (const char *e = getenv("NORI_HIP_WF_STACK")) lds_stack = atoi(e) <= 16 ? 16 : atoi(e) <= 24 ? 24 : 32;
-    const bool spill = L.stack_depth > lds_stack;
+    const bool spill = L.stack_depth > lds_stack || sc.wide != 0;
     int finish_paths = 524288;           /* fewer live paths than this: wf_finish ends the batch */
     if (const char *e = getenv("NORI_HIP_WF_FINISH_PATHS")) finish_paths = std::max(256, atoi(e)) & ~255;
     const int finish_grid = finish_paths / kB;
     int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + 64))));
+    /* every workgroup of the persistent grid must be resident from the start (a workgroup that starts late owns a
+       static share of the paths and works it off alone): the wide-node kernels are built for 5 waves per SIMD */
+    if (sc.wide) per_cu = std::min(per_cu, 5);
     if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(8, std::max(1, atoi(e)));
     const int extend_grid = eng.n_cus * per_cu;

@@ -57,6 +57,7 @@ static void bind(emu_ctx *c) {
     d.n_triangles = (uint32_t) h.tri_mesh.size();
     d.n_cdf = (uint32_t) h.emitter_cdf.size();
     d.root = c->bvh.root;
+    d.wide = c->bvh.wide ? 1u : 0u;
     d.camera = h.camera; d.filter = h.filter; d.integrator = h.integrator;
 }
 
@@ -136,7 +137,11 @@ extern "C" {
 int emu_create(const nori_scene_desc *scene, emu_ctx **out) {
     emu_ctx *c = new emu_ctx();
     std::string err = prepare_scene(*scene, c->host);
-    if (err.empty()) err = build_bvh_sah(c->host, 64, c->bvh);
+    /* node layout as the library picks it (nori_hip_build_accel): NORI_HIP_ACCEL_LAYOUT=bvh4q forces wide nodes */
+    const char *lay = std::getenv("NORI_HIP_ACCEL_LAYOUT");
+    const bool wide = lay ? std::string(lay) == "bvh4q" : c->host.tri_mesh.size() >= ((size_t) 1 << 20);
+    if (err.empty()) err = build_bvh_sah(c->host, 64, c->bvh, wide);
+    if (!err.empty() && wide) err = build_bvh_sah(c->host, 64, c->bvh, false);
     if (!err.empty()) { fprintf(stderr, "emu_create: %s\n", err.c_str()); delete c; return NORI_ERR_INVALID_ARGUMENT; }
     bind(c);
     *out = c;
@@ -150,6 +155,7 @@ int emu_accel_info(const emu_ctx *c, nori_accel_info *in) {
     in->max_depth = c->bvh.max_depth; in->node_bytes = kNodeQuads * 16; in->tri_bytes = kPairQuads * 16 / 2;
     in->total_bytes = (uint64_t) (c->bvh.nodes.size() + c->bvh.tris.size()) * 16;
     in->build_ms = c->bvh.build_ms; in->sah_cost = c->bvh.sah_cost;
+    in->node_children = c->bvh.wide ? 4u : 2u;
     return NORI_OK;
 }
 int emu_border_size(const emu_ctx *c) { return c->host.filter.border; }

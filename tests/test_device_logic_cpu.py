@@ -237,3 +237,67 @@ def test_emulated_device_paths_equal_the_oracle_bitwise():
         rays = o.sample_rays(rng.uniform(0, 16, (n, 2)).astype(np.float32))
         ss = rng.integers(0, 2 ** 62, n, dtype=np.uint64); sq = rng.integers(0, 2 ** 62, n, dtype=np.uint64)
         assert np.array_equal(o.li(rays, ss, sq), e.li(rays, ss, sq)), integ
+
+
+def _with_layout(layout, fn):
+    import os
+    old = os.environ.get("NORI_HIP_ACCEL_LAYOUT")
+    os.environ["NORI_HIP_ACCEL_LAYOUT"] = layout
+    try:
+        return fn()
+    finally:
+        if old is None:
+            os.environ.pop("NORI_HIP_ACCEL_LAYOUT", None)
+        else:
+            os.environ["NORI_HIP_ACCEL_LAYOUT"] = old
+
+
+@pytest.mark.parametrize("n_tris,seed", [(1, 3), (2, 4), (5, 5), (9, 8), (300, 6), (20000, 7)])
+def test_wide_nodes_same_hits_as_brute_force(n_tris, seed):
+    """WIDE nodes (BVH4, child boxes quantised to 8 bits; rt_types.h, rt_trace.h trav_wide_step) through the emulated
+    device code: the hit records of closest-hit and any-hit queries are bit-identical to the oracle's linear scan
+    (src/accel.cpp:30-40) -- a quantised box may only ever be larger than the box it stands for."""
+    sc = scenes.soup_scene(n_tris, seed)
+    rays = scenes.random_rays(30000, seed=seed + 10)
+    rays["d"][:500, 0] = 0.0                                  # zero direction components: the 2^60 reciprocal clamp
+    rays["d"][500:1000] = np.float32([0, -1, 0])
+    e = _with_layout("bvh4q", lambda: Emu(sc))
+    o = Oracle(sc)
+    info = e.accel_info()
+    assert info["node_children"] == (4 if n_tris > 4 else 2) or n_tris <= 8
+    a, b = o.intersect(rays), e.intersect(rays)
+    for k in a.dtype.names:
+        assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), k
+    assert np.array_equal(o.intersect(rays, True)["mesh"], e.intersect(rays, True)["mesh"])
+
+
+def test_wide_nodes_fuzz_and_render():
+    """The fuzzer's scene shapes (degenerate and numerically collinear triangles -> the all-hit subtree, duplicates,
+    sheets, scales 1e-3 .. 1e3) through wide nodes, and a whole render: same frame, same ray counts as the BVH2 layout."""
+    from tests import fuzz_intersect
+
+    class R:
+        def __init__(self, dev):
+            pass
+
+        def upload(self, sc, builder=0):
+            self.e = _with_layout("bvh4q", lambda: Emu(sc))
+            return self
+
+        def intersect(self, rays, shadow=False):
+            return self.e.intersect(rays, shadow)
+
+        def close(self):
+            self.e.close()
+
+    fuzz_intersect.TOLERATED[0] = 0
+    hits = sum(fuzz_intersect.one_round(seed, R, n_rays=3000) for seed in range(7000, 7040))
+    assert hits > 20000 and fuzz_intersect.TOLERATED[0] == 0
+    sc = scenes.cornell_box(40, 24, 4, "path_mis", sphere_bsdfs=[Bsdf("mirror"), Bsdf("dielectric")])
+    a, sa = _with_layout("bvh2", lambda: Emu(sc)).render_host(count_traversal=True)
+    w = _with_layout("bvh4q", lambda: Emu(sc))
+    assert w.accel_info()["node_children"] == 4
+    b, sb = w.render_host(count_traversal=True)
+    assert np.array_equal(a, b)
+    assert (sa["n_closest_rays"], sa["n_shadow_rays"]) == (sb["n_closest_rays"], sb["n_shadow_rays"])
+    assert sb["n_node_tests"] < 0.75 * sa["n_node_tests"]          # four boxes per node record: far fewer node visits

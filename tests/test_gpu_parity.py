@@ -347,3 +347,37 @@ def test_nori_block_seeding_zscore(renderer_factory):
     print(f"[parity] nori-block seeding: {beyond:.3%} of pixels beyond 4 sigma, image means {cpu.mean():.5f} / {gpu.mean():.5f}")
     assert beyond <= 0.01, beyond
     assert abs(cpu.mean() - gpu.mean()) <= 5e-3 * cpu.mean()
+
+
+
+def test_wide_nodes_on_device(renderer_factory):
+    """accel_layout = bvh4q (WIDE nodes: BVH4, quantised child boxes, the layout of scenes beyond the caches) on the
+    GPU: fuzzed hit records bit-identical to the oracle's linear scan, and a render equal -- frame bits and ray counts --
+    to the BVH2 layout with about half the node visits."""
+    from nori_amd.render import Renderer
+    from nori_amd.scene import Scene
+    from tests import fuzz_intersect
+    import os
+
+    class WideRenderer(Renderer):
+        def upload(self, sc, build=True, builder=0):
+            self.set_option("accel_layout", "bvh4q")
+            return super().upload(sc, build, 0)
+
+    fuzz_intersect.TOLERATED[0] = 0
+    hits = sum(fuzz_intersect.one_round(seed, WideRenderer, n_rays=8000) for seed in range(3000, 3012))
+    print(f"[fuzz] wide nodes: {hits} hits bit-identical, {fuzz_intersect.TOLERATED[0]} ill-posed rays exempted")
+    assert hits > 10000 and fuzz_intersect.TOLERATED[0] == 0
+    sc = Scene.load_npz(os.path.join(os.path.dirname(__file__), "golden", "pa5-table_mis.npz"))
+    sc.camera.width, sc.camera.height, sc.sample_count = 200, 150, 4
+    a = Renderer(0); a.set_option("accel_layout", "bvh2"); a.upload(sc); a.set_option("engine", "wavefront")
+    b = Renderer(0); b.set_option("accel_layout", "bvh4q"); b.upload(sc)          # engine: wide trees always take the wavefront engine
+    assert a.accel_info()["node_children"] == 2 and b.accel_info()["node_children"] == 4
+    A, sa = a.render_host(count_traversal=True)
+    B, sb = b.render_host(count_traversal=True)
+    assert np.array_equal(A, B)
+    for k in ("n_closest_rays", "n_shadow_rays", "n_camera_samples"):
+        assert sa[k] == sb[k], k
+    assert sb["n_node_tests"] < 0.6 * sa["n_node_tests"]
+    assert_image_parity(Oracle(sc, use_bvh=True).render_host()[0], B, b.border, "pa5-table_mis wide nodes")
+    a.close(); b.close()
