@@ -157,7 +157,7 @@ __device__ __forceinline__ bool first_vertex(const DevScene &sc, const WfBatch &
 /* Accel::rayIntersect for every path of copy `cur`: the shadow ray (if any) first, then the
    continuation ray, by the same lane; one 16-B hit record per path. */
 template <int STACK, bool SPILL, bool COUNT, bool FIRST, bool WIDE>
-__global__ __launch_bounds__(kB, WIDE ? 5 : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
+__global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStackW<STACK, SPILL> stack;
@@ -688,7 +688,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     /* persistent extend grid: fill the CUs, but with two pipes leave half of the wave slots to
        the other pipe's kernels */
     /* traversal stack: what the tree needs, at most `lds_stack` entries of it in LDS */
-    int lds_stack = L.stack_depth <= 16 ? 16 : 24;
+    int lds_stack = (L.stack_depth <= 16 || sc.wide) ? 16 : 24;      /* wide trees: 16 measured best on the 10 M-triangle terrain (6 workgroups per CU) */
     if (const char *e = getenv("NORI_HIP_WF_STACK")) lds_stack = atoi(e) <= 16 ? 16 : atoi(e) <= 24 ? 24 : 32;
     const bool spill = L.stack_depth > lds_stack || sc.wide != 0;
     int finish_paths = 524288;           /* fewer live paths than this: wf_finish ends the batch */
@@ -696,8 +696,9 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     const int finish_grid = finish_paths / kB;
     int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + 64))));
     /* every workgroup of the persistent grid must be resident from the start (a workgroup that starts late owns a
-       static share of the paths and works it off alone): the wide-node kernels are built for 5 waves per SIMD */
-    if (sc.wide) per_cu = std::min(per_cu, 5);
+       static share of the paths and works it off alone): the wide-node kernels are built for 6 waves per SIMD
+       (their first-pass variant for 5: measured 3.47 vs 3.29 Grays/s on the terrain against 5 everywhere) */
+    if (sc.wide) per_cu = std::min(per_cu, 6);
     if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(8, std::max(1, atoi(e)));
     const int extend_grid = eng.n_cus * per_cu;
