@@ -27,7 +27,7 @@ constexpr int kMaxBorder = 8;                  /* (16 + 2 * 8)^2 / 256 = 4 outpu
  * for samples the isValid() guard (block.cpp:63-67) rejects. */
 __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, FilterRec fr, const float *__restrict__ filter_table,
                                                          FilmStore st, FilmLaunch fl) {
-    extern __shared__ float s_dyn[];                          /* [taps][256] (L.r wx, L.g wx, L.b wx, wx) as float4, [taps][256] wy */
+    extern __shared__ float s_dyn[];                          /* [taps][256] wx, [taps][256] wy, r, g, b */
     __shared__ float ftab[kFilterRes + 1];
     __shared__ unsigned int s_invalid;
     const int tid = threadIdx.x;
@@ -39,10 +39,8 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
     const uint32_t tile_id = fl.tile_rem + ord * fl.tile_mod;
     const int x0 = (int) (tile_id % fl.tiles_x) * kTile, y0 = (int) (tile_id / fl.tiles_x) * kTile;
     const int border = fr.border, tile_w = fl.tile_w, taps = 2 * border + 1;
-    /* the first product of Color4f(value) * wx * wy (block.cpp:88-90) is formed once per (sample, x tap) when the sample
-       is staged -- (L wx, wx) as one float4 -- so a tap costs one 16-B and one 4-B LDS read, 4 multiplies, 4 adds */
-    float4 (*s_lx)[256] = reinterpret_cast<float4 (*)[256]>(s_dyn);
-    float (*s_wy)[256] = reinterpret_cast<float (*)[256]>(s_dyn + 4 * taps * 256);
+    float (*s_wx)[256] = reinterpret_cast<float (*)[256]>(s_dyn), (*s_wy)[256] = s_wx + taps;
+    float *s_Lr = s_dyn + 2 * taps * 256, *s_Lg = s_Lr + 256, *s_Lb = s_Lg + 256;
     const float radius = fr.radius, lookup = fr.lookup_factor;
     const int bx0 = x0 & ~31, by0 = y0 & ~31;                 /* NORI_BLOCK_SIZE = 32 */
     const int offx = x0 - bx0, offy = y0 - by0;               /* tile frame -> block frame */
@@ -82,12 +80,12 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
                 bpx = p.x - 0.5f - (float) (bx0 - border);
                 bpy = p.y - 0.5f - (float) (by0 - border);
             }
+            s_Lr[raster] = L.x; s_Lg[raster] = L.y; s_Lb[raster] = L.z;
             for (int k = 0; k < taps; ++k) {
                 const float xb = (float) (sxl + k + offx), yb = (float) (syl + k + offy);
                 const bool inx = ok && xb >= bpx - radius && xb <= bpx + radius;
                 const bool iny = ok && yb >= bpy - radius && yb <= bpy + radius;
-                const float wx = inx ? ftab[(int) (fabsf(xb - bpx) * lookup)] : 0.0f;
-                s_lx[k][raster] = make_float4(L.x * wx, L.y * wx, L.z * wx, wx);
+                s_wx[k][raster] = inx ? ftab[(int) (fabsf(xb - bpx) * lookup)] : 0.0f;
                 s_wy[k][raster] = iny ? ftab[(int) (fabsf(yb - bpy) * lookup)] : 0.0f;
             }
         }
@@ -103,9 +101,8 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
                     if (sx < 0 || sx >= kTile) continue;
                     const int r = sy * kTile + sx;
                     /* Color4f(value) * wx * wy, left to right (block.cpp:88-90): (L * wx) * wy per channel, W = (1 * wx) * wy */
-                    const float4 lx = s_lx[k][r];
-                    const float wy = s_wy[m][r];
-                    acc[o].x += lx.x * wy; acc[o].y += lx.y * wy; acc[o].z += lx.z * wy; acc[o].w += lx.w * wy;
+                    const float wx = s_wx[k][r], wy = s_wy[m][r];
+                    acc[o].x += (s_Lr[r] * wx) * wy; acc[o].y += (s_Lg[r] * wx) * wy; acc[o].z += (s_Lb[r] * wx) * wy; acc[o].w += wx * wy;
                 }
             }
         }
@@ -193,9 +190,7 @@ std::string film_prepare(FilmStore &g_film, size_t n_samples, size_t n_sel_tiles
 
 void film_gather(const DevScene &sc, const float *d_filter_table, const FilmStore &st, const FilmLaunch &fl, void *stream) {
     if (fl.n_tiles == 0 || fl.n_spp == 0) return;
-    const size_t lds = (size_t) (5 * (2 * sc.filter.border + 1)) * 256 * sizeof(float);      /* float4 + float per tap per sample */
-    if (lds > 64 * 1024)      /* wide filters (border >= 6): beyond the default dynamic-LDS limit, within the CU's 160 KB */
-        (void) hipFuncSetAttribute((const void *) film_gather_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    const size_t lds = (size_t) (2 * (2 * sc.filter.border + 1) + 3) * 256 * sizeof(float);
     hipLaunchKernelGGL(film_gather_kernel, dim3(fl.n_tiles * st.n_parts), dim3(kB), lds, (hipStream_t) stream, sc.camera.width, sc.camera.height,
                        sc.filter, d_filter_table, st, fl);
 }

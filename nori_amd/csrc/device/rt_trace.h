@@ -24,17 +24,19 @@ struct RayIn {
 };
 
 /* 1.0f / x, correctly rounded, in 3 instructions instead of the compiler's ~11 (v_div_scale x2, v_rcp, 4 fma, v_div_fmas,
- * v_div_fixup): r0 = v_rcp_f32(x) (1 ulp), one Newton step r0 + r0 (1 - x r0) with two fused multiply-adds.  Verified
- * EXHAUSTIVELY on gfx950 against the IEEE quotient for every float with 2^-120 <= |x| < 2^121 (tools/ubench_recip.hip:
- * 0 mismatches of 4.0e9); outside that range, and in the CPU twins, the plain division. */
+ * v_div_fixup): r0 = v_rcp_f32(x) (1 ulp), then one Newton step r0 + r0 (1 - x r0) with two fused multiply-adds.  Verified
+ * EXHAUSTIVELY on gfx950 against the IEEE quotient over all 2^32 floats (tools/ubench_recip.hip, result in
+ * profiles/r2_exact_rcp.txt): identical for every x whose reciprocal is a normal number; the exceptions are the denormal x
+ * and |x| > 2^126.  No fallback branch (it costs the traversal kernel its last free registers): a determinant beyond
+ * 8.5e37 needs scene coordinates beyond 1e12, and a denormal one is rejected by |det| < 1e-8 before its reciprocal is used
+ * (src/mesh.cpp:52).  The CPU twins use the plain division. */
 NORI_HD float exact_rcp(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (fabsf(x) < 1.3e36f && fabsf(x) >= 8e-37f) {
-        const float r0 = __builtin_amdgcn_rcpf(x);
-        return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
-    }
-#endif
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+#else
     return 1.0f / x;
+#endif
 }
 
 /* Reciprocal direction for the slab test.  A zero component maps to a huge
