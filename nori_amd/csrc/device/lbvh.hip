@@ -25,6 +25,11 @@
  *                       densely as 64-B two-child-box records; the leaves' triangles as 96-B
  *                       de-indexed pair records, leaf by leaf
  *   8. k_depth          longest root-to-leaf chain (sizes the LDS stack)
+ *   wide = true (scenes beyond the caches): instead of 7's two-box records the tree is emitted as WIDE nodes (BVH4,
+ *       quantised child boxes; rt_types.h).  k_wide_expand walks the kept radix nodes top-down, one launch per level
+ *       of the wide tree: a wide node takes its radix node's two children and twice replaces the inner child of largest
+ *       surface area by that child's children; the inner children that remain are the wide nodes of the next level.
+ *       k_emit_wide quantises the (<= 4) child boxes against their union (rt_wide.h) -- the radix nodes in between vanish.
  *
  * Numerically collinear triangles (rt_types.h, tri_box_pad) get Morton bit 63: the root separates them
  * from the spatial hierarchy, their boxes are infinite.
@@ -41,6 +46,7 @@
 #include <string>
 
 #include "lbvh.h"
+#include "rt_wide.h"
 
 using namespace nrt;
 
@@ -242,10 +248,62 @@ __device__ __forceinline__ bool child_range(const RadixNode *nodes, const uint32
 /* the first pair of the leaf starting at sorted position lo is pair_start[lo] (exclusive scan of the
    per-leaf pair counts) */
 __device__ __forceinline__ int32_t child_link(const RadixNode *nodes, const uint32_t *collapse, const uint32_t *pair_start, const uint32_t *node_index,
-                                              uint32_t child, uint32_t &lo, uint32_t &hi) {
+                                              uint32_t child, uint32_t &lo, uint32_t &hi, uint32_t pair_base = 0u) {
     if (!child_range(nodes, collapse, child, lo, hi)) return (int32_t) node_index[child];
     const uint32_t cnt = hi - lo + 1;
-    return (int32_t) ~((pair_start[lo] << 3) | ((cnt + 1u) / 2u - 1u));
+    return (int32_t) ~(((pair_start[lo] + pair_base) << 3) | ((cnt + 1u) / 2u - 1u));
+}
+
+/* ---- WIDE emission ---- */
+/* one thread per wide node of the current level: choose its children, queue the inner ones for the next level */
+__global__ void k_wide_expand(const RadixNode *nodes, const uint32_t *collapse, const f4 *tmin, const f4 *tmax, uint32_t N,
+                              const uint32_t *frontier, uint32_t count, uint32_t *next, uint32_t *next_count,
+                              uint32_t *kids, uint32_t *n_kids, uint32_t *is_wide) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t i = frontier[t];
+    const RadixNode nd = nodes[i];
+    uint32_t kid[4] = {nd.left, nd.right, 0u, 0u};
+    int n = 2;
+    while (n < 4) {
+        int best = -1; float bestArea = -1.0f;
+        for (int k = 0; k < n; ++k) {
+            uint32_t lo, hi;
+            if (child_range(nodes, collapse, kid[k], lo, hi)) continue;      /* a leaf stays */
+            f3 mn, mx; range_box(tmin, tmax, N, lo, hi, mn, mx);
+            float a = box_area(mn, mx);
+            if (!(a < kInf)) a = kInf;                                        /* unbounded subtree first */
+            if (a > bestArea) { bestArea = a; best = k; }
+        }
+        if (best < 0) break;
+        const RadixNode c = nodes[kid[best]];
+        kid[best] = c.left; kid[n++] = c.right;
+    }
+    n_kids[i] = (uint32_t) n;
+    for (int k = 0; k < n; ++k) {
+        kids[4 * (size_t) i + k] = kid[k];
+        uint32_t lo, hi;
+        if (!child_range(nodes, collapse, kid[k], lo, hi)) { is_wide[kid[k]] = 1u; next[atomicAdd(next_count, 1u)] = kid[k]; }
+    }
+}
+
+__global__ void k_emit_wide(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N, const uint32_t *collapse,
+                            const uint32_t *pair_start, const uint32_t *is_wide, const uint32_t *wide_index, const uint32_t *kids,
+                            const uint32_t *n_kids, f4 *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_inner || !is_wide[i]) return;
+    float mn[4][3], mx[4][3]; int32_t link[4];
+    const int n = (int) n_kids[i];
+    for (int k = 0; k < n; ++k) {
+        uint32_t lo, hi;
+        link[k] = child_link(nodes, collapse, pair_start, wide_index, kids[4 * (size_t) i + k], lo, hi, 1u);      /* pair 0 = the null pair */
+        f3 a, b; range_box(tmin, tmax, N, lo, hi, a, b);
+        mn[k][0] = a.x; mn[k][1] = a.y; mn[k][2] = a.z; mx[k][0] = b.x; mx[k][1] = b.y; mx[k][2] = b.z;
+    }
+    f4 q[4];
+    wide_pack(n, mn, mx, link, q);
+    f4 *dst = out + (size_t) wide_index[i] * kNodeQuads;
+    dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
 }
 
 /* leaf_cnt[lo] = triangles of the leaf that starts at sorted position lo, leaf_pairs[lo] = its pairs;
@@ -287,14 +345,14 @@ __global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 
 
 /* one thread per leaf start: the leaf's triangles, de-indexed, as pair records */
 __global__ void k_emit_pairs(const f4 *pos, const uint32_t *idx, const uint32_t *tri_mesh, const uint32_t *order, uint32_t n,
-                             const uint32_t *leaf_cnt, const uint32_t *pair_start, f4 *out) {
+                             const uint32_t *leaf_cnt, const uint32_t *pair_start, f4 *out, uint32_t pair_base) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t cnt = leaf_cnt[k];
     if (cnt == 0u) return;
     for (uint32_t t = 0; t < ((cnt + 1u) / 2u) * 2u; ++t) {
         f4 q[kPairQuads];
-        f4 *dst = out + (size_t) (pair_start[k] + t / 2u) * kPairQuads;
+        f4 *dst = out + (size_t) (pair_start[k] + pair_base + t / 2u) * kPairQuads;
         if ((t & 1u) == 0u) for (int j = 0; j < kPairQuads; ++j) q[j].x = q[j].y = q[j].z = q[j].w = 0.0f;
         else for (int j = 0; j < kPairQuads; ++j) q[j] = dst[j];
         if (t < cnt) {
@@ -334,8 +392,10 @@ struct Buf {
 
 namespace nrt {
 
-std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mesh, LbvhDeviceResult &out) {
+std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mesh, LbvhDeviceResult &out, bool wide) {
     out = LbvhDeviceResult();
+    if (dev.n_triangles <= 4) wide = false;                  /* a single leaf: no nodes at all */
+    const uint32_t pair_base = wide ? 1u : 0u;               /* wide trees reserve pair 0 as the all-zero pair of unused slots */
     const uint32_t n = dev.n_triangles;
     hipEvent_t e0, e1;
     LB_TRY(hipEventCreate(&e0)); LB_TRY(hipEventCreate(&e1));
@@ -411,15 +471,16 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     uint32_t last[2] = {0, 0};
     LB_TRY(hipMemcpy(&last[0], pair_start.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost));
     LB_TRY(hipMemcpy(&last[1], leaf_pairs.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost));
-    const uint32_t n_pairs = last[0] + last[1];
+    const uint32_t n_pairs = last[0] + last[1] + pair_base;
     out.n_pairs = n_pairs;
 
     /* 7. pair records */
     f4 *d_tris = nullptr;
     LB_TRY(hipMalloc((void **) &d_tris, (size_t) std::max<uint32_t>(n_pairs, 1) * kPairQuads * sizeof(f4)));
     out.d_tris = d_tris;
+    if (pair_base) LB_TRY(hipMemset(d_tris, 0, kPairQuads * sizeof(f4)));
     hipLaunchKernelGGL(k_emit_pairs, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, d_tri_mesh, order, n,
-                       leaf_cnt.as<uint32_t>(), pair_start.as<uint32_t>(), d_tris);
+                       leaf_cnt.as<uint32_t>(), pair_start.as<uint32_t>(), d_tris, pair_base);
 
     if (n <= 4) {
         f4 *d_nodes = nullptr;
@@ -427,6 +488,44 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         LB_TRY(hipMemset(d_nodes, 0, kNodeQuads * sizeof(f4)));
         out.d_nodes = d_nodes; out.root = (int32_t) ~((0u << 3) | ((n + 1u) / 2u - 1u));
         out.n_nodes = 0; out.n_leaves = 1; out.max_depth = 0;
+    } else if (wide) {
+        /* WIDE nodes: level by level from the root (radix node 0) */
+        Buf fa, fb, cnt, kids, n_kids, is_wide, wide_index;
+        LB_TRY(fa.alloc((size_t) n * 4)); LB_TRY(fb.alloc((size_t) n * 4)); LB_TRY(cnt.alloc(4));
+        LB_TRY(kids.alloc((size_t) n * 16)); LB_TRY(n_kids.alloc((size_t) n * 4));
+        LB_TRY(is_wide.alloc((size_t) n * 4)); LB_TRY(wide_index.alloc((size_t) n * 4));
+        LB_TRY(hipMemset(is_wide.p, 0, (size_t) n * 4)); LB_TRY(hipMemset(n_kids.p, 0, (size_t) n * 4));
+        const uint32_t one = 1u, zero = 0u;
+        LB_TRY(hipMemcpy(is_wide.p, &one, 4, hipMemcpyHostToDevice));            /* radix node 0 = the root */
+        LB_TRY(hipMemcpy(fa.p, &zero, 4, hipMemcpyHostToDevice));
+        uint32_t count = 1, levels = 0;
+        Buf *cur = &fa, *nxt = &fb;
+        while (count > 0) {
+            LB_TRY(hipMemset(cnt.p, 0, 4));
+            hipLaunchKernelGGL(k_wide_expand, dim3((count + B - 1) / B), dim3(B), 0, 0, rnodes.as<RadixNode>(), collapse.as<uint32_t>(), tmin.as<f4>(), tmax.as<f4>(), N,
+                               cur->as<uint32_t>(), count, nxt->as<uint32_t>(), cnt.as<uint32_t>(), kids.as<uint32_t>(), n_kids.as<uint32_t>(), is_wide.as<uint32_t>());
+            LB_TRY(hipMemcpy(&count, cnt.p, 4, hipMemcpyDeviceToHost));
+            std::swap(cur, nxt);
+            if (++levels > 4096) return "lbvh: wide levels did not terminate";
+        }
+        uint32_t n_wide = 0;
+        {
+            size_t scan_bytes = 0;
+            LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, is_wide.as<uint32_t>(), wide_index.as<uint32_t>(), (int) (n - 1)));
+            Buf scan_tmp; LB_TRY(scan_tmp.alloc(scan_bytes));
+            LB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, is_wide.as<uint32_t>(), wide_index.as<uint32_t>(), (int) (n - 1)));
+            uint32_t tail[2] = {0, 0};
+            LB_TRY(hipMemcpy(&tail[0], wide_index.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost));
+            LB_TRY(hipMemcpy(&tail[1], is_wide.as<uint32_t>() + (n - 2), 4, hipMemcpyDeviceToHost));
+            n_wide = tail[0] + tail[1];
+        }
+        f4 *d_nodes = nullptr;
+        LB_TRY(hipMalloc((void **) &d_nodes, (size_t) std::max<uint32_t>(n_wide, 1) * kNodeQuads * sizeof(f4)));
+        out.d_nodes = d_nodes;
+        hipLaunchKernelGGL(k_emit_wide, dim3(gridN), dim3(B), 0, 0, rnodes.as<RadixNode>(), n - 1, tmin.as<f4>(), tmax.as<f4>(), N, collapse.as<uint32_t>(),
+                           pair_start.as<uint32_t>(), is_wide.as<uint32_t>(), wide_index.as<uint32_t>(), kids.as<uint32_t>(), n_kids.as<uint32_t>(), d_nodes);
+        out.root = 0; out.n_nodes = n_wide; out.n_leaves = 0; out.max_depth = 3 * levels; out.wide = true;
+        LB_TRY(hipGetLastError());
     } else {
         /* 6. nodes: the radix nodes that are not inside a collapsed subtree, renumbered densely (root stays 0) */
         uint32_t n_nodes = 0;

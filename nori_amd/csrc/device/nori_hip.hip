@@ -474,22 +474,29 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     DeviceGuard g(ctx->device);
     free_pool(ctx->allocs_accel);
     ctx->have_accel = false;
+    int layout = ctx->accel_layout;
+    if (const char *e = getenv("NORI_HIP_ACCEL_LAYOUT")) layout = std::string(e) == "bvh4q" ? 1 : (std::string(e) == "bvh2" ? 0 : -1);
+    const bool want_wide = layout == 1 || (layout < 0 && ctx->dev.n_triangles >= (1u << 20));
     if (builder == NORI_ACCEL_GPU_LBVH && ctx->dev.n_triangles > 0) {
         LbvhDeviceResult res;
-        std::string err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res);
+        std::string err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res, want_wide);
+        if (err.empty() && res.wide && res.max_depth + 1 > 64) {      /* wide tree needs more stack than the kernels have: BVH2 nodes */
+            if (res.d_nodes) (void) hipFree(res.d_nodes);
+            if (res.d_tris) (void) hipFree(res.d_tris);
+            err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res, false);
+        }
         if (res.d_nodes) ctx->allocs_accel.push_back(res.d_nodes);
         if (res.d_tris) ctx->allocs_accel.push_back(res.d_tris);
         if (err.empty() && res.max_depth + 1 > 64) err = "LBVH deeper than the traversal stack (64); use NORI_ACCEL_HOST_SAH";
         if (!err.empty()) { ctx->error = err; free_pool(ctx->allocs_accel); return NORI_ERR_INTERNAL; }
         ctx->bvh = HostBvh();
+        ctx->bvh.wide = res.wide;
         ctx->bvh.root = res.root; ctx->bvh.n_nodes = res.n_nodes; ctx->bvh.n_leaves = res.n_leaves;
         ctx->bvh.max_depth = res.max_depth; ctx->bvh.build_ms = res.build_ms; ctx->bvh.sah_cost = 0.0f;
         ctx->dev.nodes = res.d_nodes; ctx->dev.tris = res.d_tris;
         ctx->lbvh_bytes = (uint64_t) std::max<uint32_t>(res.n_nodes, 1) * kNodeQuads * 16 + (uint64_t) res.n_pairs * kPairQuads * 16;
     } else {
-        int layout = ctx->accel_layout;
-        if (const char *e = getenv("NORI_HIP_ACCEL_LAYOUT")) layout = std::string(e) == "bvh4q" ? 1 : (std::string(e) == "bvh2" ? 0 : -1);
-        const bool wide = layout == 1 || (layout < 0 && ctx->dev.n_triangles >= (1u << 20));
+        const bool wide = want_wide;
         std::string err = build_bvh_sah(ctx->host, 64, ctx->bvh, wide);
         if (!err.empty() && wide) err = build_bvh_sah(ctx->host, 64, ctx->bvh, false);      /* wide tree too deep for the stack: BVH2 */
         if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }

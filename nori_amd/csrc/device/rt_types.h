@@ -150,7 +150,7 @@ constexpr int kMaxLeafTris = 8;      /* = 4 pairs */
  *   q2 = (bits hiY, bits hiZ, 0, 0)
  *   q3 = (bits link0, link1, link2, link3)            child links as in the BVH2 node (>= 0 inner, < 0 leaf)
  * Child k covers [origin_a + lo_a[k] 2^(e_a-128), origin_a + hi_a[k] 2^(e_a-128)] on axis a, a superset of its true
- * (padded) box: origin = the node box's lower corner, lo rounded down, hi rounded up (scene_prep.cpp, wide_pack).
+ * (padded) box: origin = the node box's lower corner, lo rounded down, hi rounded up (rt_wide.h, wide_pack).
  * The children are stored in ascending order of their centre along `axis`: slot order = front-to-back order for a
  * ray that travels in +axis, back-to-front otherwise.  An unused slot has lo = 255, hi = 0 (never hit) and link
  * kWideEmpty = the leaf code of pair record 0, which wide trees reserve as an all-zero pair (never hit).

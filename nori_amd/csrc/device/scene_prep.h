@@ -48,11 +48,6 @@ std::string prepare_scene(const nori_scene_desc &desc, HostScene &out);
  * four children, their boxes quantised to 8 bits against the node's own box (rt_types.h). */
 std::string build_bvh_sah(const HostScene &scene, uint32_t max_depth_limit, HostBvh &out, bool wide = false);
 
-/* Quantise up to four child boxes against their union into one WIDE node (rt_types.h).  `n` children, boxes
- * mn[k][3] / mx[k][3], links link[k]; slots are filled in ascending order of the children's centres along the
- * union's widest axis.  Shared by the host builder and the test harness. */
-void wide_pack(int n, const float (*mn)[3], const float (*mx)[3], const int32_t *link, f4 q[4]);
-
 /* Filter evaluation, src/rfilter.cpp:25-29,56-70,85-103 */
 float rfilter_eval(const nori_rfilter_desc &d, float radius, float x);
 

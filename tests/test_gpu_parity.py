@@ -362,7 +362,7 @@ def test_wide_nodes_on_device(renderer_factory):
     class WideRenderer(Renderer):
         def upload(self, sc, build=True, builder=0):
             self.set_option("accel_layout", "bvh4q")
-            return super().upload(sc, build, 0)
+            return super().upload(sc, build, builder)      # the fuzzer passes both builders: host SAH and device LBVH
 
     fuzz_intersect.TOLERATED[0] = 0
     hits = sum(fuzz_intersect.one_round(seed, WideRenderer, n_rays=8000) for seed in range(3000, 3012))
@@ -380,4 +380,9 @@ def test_wide_nodes_on_device(renderer_factory):
         assert sa[k] == sb[k], k
     assert sb["n_node_tests"] < 0.6 * sa["n_node_tests"]
     assert_image_parity(Oracle(sc, use_bvh=True).render_host()[0], B, b.border, "pa5-table_mis wide nodes")
-    a.close(); b.close()
+    c = Renderer(0); c.set_option("accel_layout", "bvh4q"); c.upload(sc, builder=1)      # wide nodes emitted on the device (lbvh.hip)
+    assert c.accel_info()["node_children"] == 4
+    C_, sc_ = c.render_host()
+    np.testing.assert_allclose(C_, A, rtol=1e-4, atol=1e-5)                                # same hits -> same paths; film summation order only
+    assert sc_["n_closest_rays"] == sa["n_closest_rays"] and sc_["n_shadow_rays"] == sa["n_shadow_rays"]
+    a.close(); b.close(); c.close()

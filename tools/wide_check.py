@@ -9,7 +9,7 @@ from tests.backends import Oracle
 class WideRenderer(Renderer):
     def upload(self, sc, build=True, builder=0):
         self.set_option("accel_layout", "bvh4q")
-        return super().upload(sc, build, 0)          # host SAH -> wide nodes
+        return super().upload(sc, build, builder)     # both builders -> wide nodes
 
 t0, hits, n = time.time(), 0, 0
 while time.time() - t0 < float(os.environ.get("FUZZ_SECONDS", 30)):
