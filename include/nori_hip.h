@@ -93,7 +93,10 @@ typedef enum nori_warp_type {
  *               compared sample for sample.
  *  NORI_BLOCK : the reference's scheme, src/independent.cpp:36-41 -- one
  *               stream per 32x32 block seeded with (offset.x, offset.y) and
- *               consumed serially over y, x, sample.  Oracle only. */
+ *               consumed serially over y, x, sample.  On the device this runs
+ *               one lane per block (whole frames from sample 0 only; slow by
+ *               design): every camera sample then carries exactly the
+ *               radiance of a render with the reference's own sampler. */
 typedef enum nori_seed_mode {
     NORI_SEED_PER_SAMPLE = 0,
     NORI_SEED_NORI_BLOCK = 1
@@ -205,7 +208,7 @@ typedef struct nori_render_params {
     uint32_t spp_count;
     uint32_t tile_mod;      /* >= 1 */
     uint32_t tile_rem;      /* <  tile_mod */
-    int32_t seed_mode;      /* nori_seed_mode; the device supports PER_SAMPLE */
+    int32_t seed_mode;      /* nori_seed_mode */
     int32_t count_traversal;/* != 0: also count node/triangle tests (slower) */
     int32_t time_kernels;   /* != 0: HIP events around every kernel launch, summed per
                                kernel class into nori_render_stats.*_ms          */

@@ -254,6 +254,62 @@ __global__ __launch_bounds__(kBlock) void li_kernel(DevScene sc, const nori_ray 
     }
 }
 
+/* NORI_SEED_NORI_BLOCK -- the reference's own sampler streams.  Independent::prepare(block) seeds ONE pcg32 stream per
+   32x32 block with (offset.x, offset.y) (src/independent.cpp:36-41) and renderBlock (src/main.cpp:27-56) consumes it
+   serially: for y, for x, for sample: next2D (pixel jitter), next2D (aperture, unused), then whatever Li draws.  The
+   number of draws per sample depends on the path, so the stream cannot be split: this mode runs ONE LANE PER BLOCK,
+   each walking its block's pixels and samples in the reference's order with the block's stream.  Slow by design (a
+   1024^2 frame is 1024 lanes of work) -- it exists for bit-level comparison with a render of the reference / the
+   oracle in its native seeding, not for throughput.  Samples go to the film's store like everywhere else. */
+constexpr int kNoriBlock = 32;        /* NORI_BLOCK_SIZE, include/nori/block.h:17 */
+
+template <int INTEG, int STACK>
+__global__ __launch_bounds__(64) void render_block_serial_kernel(DevScene sc, uint32_t blocks_x, uint32_t n_blocks, uint32_t spp,
+                                                                 uint32_t tiles_x, FilmStore film, unsigned long long *stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    LdsStack<STACK, 64> stack;
+    stack.base = reinterpret_cast<int *>(smem) + threadIdx.x; stack.sp = 0;
+    TraversalCounters tc; tc.nodes = tc.tris = 0;
+    const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+    unsigned long long nCam = 0, nClosest = 0, nShadow = 0;
+    if (b < n_blocks) {
+        const int ox = (int) (b % blocks_x) * kNoriBlock, oy = (int) (b / blocks_x) * kNoriBlock;
+        const int sx = min(kNoriBlock, sc.camera.width - ox), sy = min(kNoriBlock, sc.camera.height - oy);
+        Rng rng; rng_seed(rng, (uint64_t) ox, (uint64_t) oy);
+        for (int y = 0; y < sy; ++y)
+            for (int x = 0; x < sx; ++x) {
+                const int px = x + ox, py = y + oy;
+                const uint32_t tile = (uint32_t) (py / kTile) * tiles_x + (uint32_t) (px / kTile);
+                const int lx = px % kTile, ly = py % kTile;
+                const uint32_t pix = (uint32_t) ((((lx >> 3) | ((ly >> 3) << 1)) << 6) | ((lx & 7) | ((ly & 7) << 3)));      /* inverse of film_tile_pixel */
+                for (uint32_t i = 0; i < spp; ++i) {
+                    const f2 j = rng_next_2d(rng);
+                    const f2 ps = mk2((float) px + j.x, (float) py + j.y);
+                    (void) rng_next_2d(rng);                       /* apertureSample */
+                    RayIn cam; camera_sample_ray(sc.camera, ps, cam);
+                    PathState st; st.rng = rng;
+                    path_begin(st, cam);
+                    while (true) {
+                        const bool any = st.phase == PH_SHADOW;
+                        Hit hit;
+                        const f3 qo = st.ray.o, qd = st.ray.d;
+                        if (any) ++nShadow; else ++nClosest;
+                        const bool found = traverse<false>(sc, st.ray, any, stack, hit, tc);
+                        const bool done = any ? path_on_shadow(st, found, qo) : path_on_closest<INTEG>(sc, st, hit, found, qd);
+                        if (done) break;
+                    }
+                    rng = st.rng;                                  /* the stream goes on where Li left it */
+                    const size_t idx = ((size_t) tile * spp + i) * 256u + pix;
+                    film.pos[idx] = ps;
+                    f4 L; L.x = st.L.x; L.y = st.L.y; L.z = st.L.z; L.w = 0.0f;
+                    film.L[idx] = L;
+                    ++nCam;
+                }
+            }
+    }
+    if (nCam) { atomicAdd(&stats[0], nCam); atomicAdd(&stats[1], nClosest); atomicAdd(&stats[2], nShadow); }
+}
+
 __global__ void sample_rays_kernel(CameraRec cam, const float *ps, size_t n, nori_ray *rays) {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -813,7 +869,11 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
     REQUIRE_ACCEL(ctx);
     if (!params || !d_rgbw) return NORI_ERR_INVALID_ARGUMENT;
     if (params->tile_mod == 0 || params->tile_rem >= params->tile_mod) { ctx->error = "render: bad tile_mod/tile_rem"; return NORI_ERR_INVALID_ARGUMENT; }
-    if (params->seed_mode != NORI_SEED_PER_SAMPLE) { ctx->error = "render: the device implements NORI_SEED_PER_SAMPLE only"; return NORI_ERR_UNSUPPORTED; }
+    if (params->seed_mode != NORI_SEED_PER_SAMPLE && params->seed_mode != NORI_SEED_NORI_BLOCK) { ctx->error = "render: unknown seed_mode"; return NORI_ERR_INVALID_ARGUMENT; }
+    if (params->seed_mode == NORI_SEED_NORI_BLOCK && (params->tile_mod != 1 || params->spp_begin != 0)) {
+        ctx->error = "render: NORI_SEED_NORI_BLOCK renders whole frames from sample 0 (a block's stream is serial: src/independent.cpp:36-41)";
+        return NORI_ERR_UNSUPPORTED;
+    }
     if (ctx->host.filter.border > 8) { ctx->error = "render: reconstruction filter radius too large for the LDS tile"; return NORI_ERR_UNSUPPORTED; }
     DeviceGuard g(ctx->device);
     hipStream_t s = (hipStream_t) params->stream;
@@ -852,6 +912,37 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
        (measured on pa4 cbox: 7.3 vs 6.8 Grays/s at 2.7e8 paths); small jobs avoid its launch train */
     if (engine < 0) engine = (size_t) a.n_sel_tiles * 256 * a.spp_count >= ((size_t) 1 << 24) ? 1 : 0;
     if (ctx->dev.wide) engine = 1;      /* wide nodes are walked by the wavefront engine (and the batch twins) only */
+    if (params->seed_mode == NORI_SEED_NORI_BLOCK && a.n_sel_tiles > 0 && a.spp_count > 0) {
+        /* one lane per 32x32 block, the block's own pcg32 stream (render_block_serial_kernel) */
+        const size_t n_samples = (size_t) a.n_sel_tiles * 256 * a.spp_count;
+        if (n_samples > ((size_t) 1 << 30)) { ctx->error = "render: NORI_SEED_NORI_BLOCK keeps the whole frame's samples in the film store (limit 2^30)"; return NORI_ERR_UNSUPPORTED; }
+        FilmStore film;
+        std::string ferr = film_prepare(ctx->film, n_samples, a.n_sel_tiles, a.tile_w, s, film);
+        if (!ferr.empty()) { ctx->error = ferr; return NORI_ERR_OUT_OF_MEMORY; }
+        /* (slots of edge-tile pixels outside the image stay unwritten: film_gather never reads them) */
+        const uint32_t bx = (uint32_t) ((ctx->host.camera.width + kNoriBlock - 1) / kNoriBlock), by = (uint32_t) ((ctx->host.camera.height + kNoriBlock - 1) / kNoriBlock);
+        const uint32_t n_blocks = bx * by;
+        const uint32_t need = ctx->bvh.max_depth + 1;
+        timer.begin(KC_TRACE, s);
+        switch (ctx->dev.integrator.type) {
+#define SB(I) case I: if (need <= 32) hipLaunchKernelGGL((render_block_serial_kernel<I, 32>), dim3((n_blocks + 63) / 64), dim3(64), 32 * 64 * sizeof(int), s, ctx->dev, bx, n_blocks, a.spp_count, a.tiles_x, film, ctx->d_stats); \
+                      else hipLaunchKernelGGL((render_block_serial_kernel<I, 64>), dim3((n_blocks + 63) / 64), dim3(64), 64 * 64 * sizeof(int), s, ctx->dev, bx, n_blocks, a.spp_count, a.tiles_x, film, ctx->d_stats); break;
+            SB(0) SB(1) SB(2) SB(3) SB(4) SB(5) SB(6)
+#undef SB
+        }
+        timer.end(s);
+        HIP_TRY(ctx, hipGetLastError());
+        FilmLaunch fl;
+        fl.tile_first = 0; fl.store_tile_first = 0; fl.n_tiles = a.n_sel_tiles; fl.tile_mod = 1; fl.tile_rem = 0;
+        fl.tiles_x = a.tiles_x; fl.tiles_y = a.tiles_y; fl.tile_w = a.tile_w; fl.n_spp = a.spp_count;
+        timer.begin(KC_FILM, s);
+        film_gather(ctx->dev, ctx->d_filter, film, fl, s);
+        film_resolve(ctx->dev, film, fl, (float *) d_rgbw, s);
+        timer.end(s);
+        HIP_TRY(ctx, hipGetLastError());
+        if (stats) n_invalid = film_invalid_count(film, s);
+        engine = 0;      /* stats come from ctx->d_stats like the megakernel's */
+    } else
     if (engine == 1 && a.n_sel_tiles > 0 && a.spp_count > 0) {
         WfLaunch wl;
         wl.spp_begin = a.spp_begin; wl.spp_count = a.spp_count; wl.tile_mod = a.tile_mod; wl.tile_rem = a.tile_rem;

@@ -1,8 +1,11 @@
 /*
- * main.cpp -- `nori <scene.xml> [--no-gui] [--threads N]`
+ * main.cpp -- `nori <scene.xml> [--no-gui] [--threads N] [--seed sample|block]`
  * Command line of the reference (src/main.cpp:150-246).  There is no GUI on a
  * compute node: --no-gui is accepted and implied; --threads is accepted for
- * compatibility (the work runs on the GPU).  A <test> root runs during parsing
+ * compatibility (the work runs on the GPU).  --seed block renders with the
+ * reference's sampler streams (one pcg32 stream per 32x32 block,
+ * src/independent.cpp:36-41; one GPU lane per block, slow by design) instead of
+ * one stream per camera sample.  A <test> root runs during parsing
  * (its activate()), as in the reference; failures exit with -1.
  */
 #include <nori/bitmap.h>
@@ -12,7 +15,7 @@ using namespace nori;
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        cerr << "Syntax: " << argv[0] << " <scene.xml> [--no-gui] [--threads N]" << endl;
+        cerr << "Syntax: " << argv[0] << " <scene.xml> [--no-gui] [--threads N] [--seed sample|block]" << endl;
         return -1;
     }
     std::string sceneName;
@@ -26,6 +29,13 @@ int main(int argc, char **argv) {
             ++i;
             continue;
         } else if (token == "--no-gui") {
+            continue;
+        } else if (token == "--seed") {
+            if (i + 1 >= argc || (std::string(argv[i + 1]) != "sample" && std::string(argv[i + 1]) != "block")) {
+                cerr << "\"--seed\" expects \"sample\" or \"block\"." << endl;
+                return -1;
+            }
+            setenv("NORI_SEED", argv[++i], 1);
             continue;
         }
         if (endsWith(token, ".xml")) {

@@ -49,7 +49,11 @@ std::unique_ptr<ImageBlock> renderScene(Scene *scene, nori_render_stats *stats) 
     params.spp_begin = 0;
     params.spp_count = (uint32_t) scene->getSampler()->getSampleCount();
     params.tile_mod = 1; params.tile_rem = 0;
-    params.seed_mode = NORI_SEED_PER_SAMPLE;
+    /* sampler streams: one pcg32 stream per camera sample (default), or -- NORI_SEED=block in the environment, `--seed block`
+       on the nori command line -- the reference's own scheme, one serial stream per 32x32 block seeded by
+       Independent::prepare (src/independent.cpp:36-41), which the device then runs one lane per block */
+    const char *seed = std::getenv("NORI_SEED");
+    params.seed_mode = (seed && std::string(seed) == "block") ? NORI_SEED_NORI_BLOCK : NORI_SEED_PER_SAMPLE;
     nori_render_stats local;
     dev.check(nori_hip_render_host(dev.ctx(), &params, result->data(), stats ? stats : &local), "nori_hip_render_host");
     return result;

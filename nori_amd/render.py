@@ -171,20 +171,21 @@ class Renderer:
 
     # ------------------------------------------------------------ hot path
     @staticmethod
-    def _params(spp_begin, spp_count, tile_mod, tile_rem, count_traversal, stream, time_kernels=False):
+    def _params(spp_begin, spp_count, tile_mod, tile_rem, count_traversal, stream, time_kernels=False, seed_mode=capi.SEED_PER_SAMPLE):
         p = capi.RenderParams()
         p.spp_begin, p.spp_count = int(spp_begin), int(spp_count)
         p.tile_mod, p.tile_rem = int(tile_mod), int(tile_rem)
-        p.seed_mode = capi.SEED_PER_SAMPLE
+        p.seed_mode = int(seed_mode)
         p.count_traversal = int(bool(count_traversal))
         p.time_kernels = int(bool(time_kernels))
         p.stream = stream
         return p
 
-    def render_host(self, spp_count=None, spp_begin=0, tile_mod=1, tile_rem=0, count_traversal=False):
-        """Render into a fresh host RGBW frame; returns (rgbw, stats dict)."""
+    def render_host(self, spp_count=None, spp_begin=0, tile_mod=1, tile_rem=0, count_traversal=False, seed_mode=capi.SEED_PER_SAMPLE):
+        """Render into a fresh host RGBW frame; returns (rgbw, stats dict).  seed_mode: capi.SEED_PER_SAMPLE (default)
+        or capi.SEED_NORI_BLOCK -- the reference's one-stream-per-32x32-block sampler (src/independent.cpp:36-41)."""
         spp = self.scene.sample_count if spp_count is None else spp_count
-        p = self._params(spp_begin, spp, tile_mod, tile_rem, count_traversal, None)
+        p = self._params(spp_begin, spp, tile_mod, tile_rem, count_traversal, None, seed_mode=seed_mode)
         rgbw = np.zeros(self.frame_shape(), np.float32)
         st = capi.RenderStats()
         self._check(self._lib.nori_hip_render_host(self._h, C.byref(p), ptr(rgbw), C.byref(st)), "render_host")
