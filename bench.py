@@ -45,6 +45,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TOPS = 78.6          # 256 CUs x 4 SIMD-32 x 2.4 GHz: one non-FMA f32 lane-operation per lane per clock
 OPS_NODE, OPS_TRI, OPS_RAY = 52, 54, 9      # algorithmic f32 vector ops per two-box node test / triangle test / ray setup
+OPS_NODE_WIDE = 103                          # ... per WIDE node test (four quantised boxes: 21 setup + 6 selects + 48 planes + 16 min/max + 12 compares)
 CACHE_RESIDENT_BYTES = 256 << 20             # a BVH below this lives in L2 + Infinity Cache: HBM is not its bound
 
 
@@ -152,7 +153,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not args.emulate and not torch.cuda.is_available():
         raise SystemExit("bench.py: no GPU (torch.cuda.is_available() is False); the hot path has no CPU fallback")
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:      # under a launcher: a process group even for one rank (exercises RCCL)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.emulate:
@@ -192,7 +193,7 @@ def main():
     stream = None if args.emulate else torch.cuda.current_stream(dev)
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         if not args.emulate:
             torch.cuda.synchronize(dev)
@@ -237,7 +238,6 @@ def main():
         if t_ms <= 0.0:
             t_ms = k_ms
         rays_c = counted["n_closest_rays"] + counted["n_shadow_rays"]
-        ops = counted["n_node_tests"] * OPS_NODE + counted["n_tri_tests"] * OPS_TRI + rays_c * OPS_RAY
         trav_bytes = counted["n_node_tests"] * info["node_bytes"] + counted["n_tri_tests"] * info["tri_bytes"]
         if engine == "wavefront":
             dom_name = "wf_extend (all launches of one render pass)"
@@ -249,33 +249,46 @@ def main():
             rec_bytes = counted["n_closest_rays"] * 96 + counted["n_camera_samples"] * 24
         ctr = measured_counters(wl.name, engine)
         cache_resident = info["total_bytes"] <= CACHE_RESIDENT_BYTES
-        roof = {"kernel": dom_name, "kernel_ms": round(t_ms, 3), "launches": int(trace_launches),
-                "node_tests": int(counted["n_node_tests"]), "tri_tests": int(counted["n_tri_tests"]), "rays": int(rays_c),
-                "bvh_bytes": int(info["total_bytes"])}
-        hbm_alg = (trav_bytes + rec_bytes) / (t_ms * 1e-3) / 1e9
-        valu_ach = ops / (t_ms * 1e-3) / 1e12
-        if cache_resident:
-            roof.update({"bound": "valu", "achieved": round(valu_ach, 3), "peak": VALU_PEAK_TOPS, "unit": "Tops/s",
-                         "frac": round(valu_ach / VALU_PEAK_TOPS, 5), "algorithmic_ops": int(ops),
-                         "note": "BVH (%.1f MB) is L2 / Infinity-Cache resident: the ray-query kernel is VALU-issue bound, not HBM bound; "
-                                 "ops = %d/node test + %d/triangle test + %d/ray (f32 vector operations as written in rt_trace.h), "
-                                 "peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz" % (info["total_bytes"] / 1e6, OPS_NODE, OPS_TRI, OPS_RAY)})
+        wide = info.get("node_children", 2) == 4
+        ops_node = OPS_NODE_WIDE if wide else OPS_NODE
+        ops = counted["n_node_tests"] * ops_node + counted["n_tri_tests"] * OPS_TRI + rays_c * OPS_RAY
+        hbm_alg = (trav_bytes + rec_bytes) / (t_ms * 1e-3) / 1e9               # GB/s of algorithmic bytes
+        valu_ach = ops / (t_ms * 1e-3) / 1e12                                   # Tops/s of algorithmic vector operations
+        fr_hbm, fr_valu = hbm_alg / HBM_PEAK_GBS, valu_ach / VALU_PEAK_TOPS
+        cd = ctr[1].get("dominant_kernel", {}) if ctr else {}
+        traffic = ctr[1].get("dominant_kernel_hbm_bytes") if ctr else None
+        fr_hbm_measured = traffic / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
+        # which roof binds: the counters of this build if they are committed (share of SIMD time issuing VALU vs share of the
+        # HBM peak actually moved), else the structural rule: a cache-resident tree cannot be HBM bound
+        if cd.get("valu_busy_frac") is not None and fr_hbm_measured is not None:
+            bound = "valu" if cd["valu_busy_frac"] >= fr_hbm_measured else "hbm"
         else:
-            roof.update({"bound": "hbm", "achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(hbm_alg / HBM_PEAK_GBS, 5), "algorithmic_bytes": int(trav_bytes + rec_bytes),
-                         "valu_frac": round(valu_ach / VALU_PEAK_TOPS, 5),
+            bound = "valu" if (cache_resident or fr_hbm > 1.0) else "hbm"
+        roof = {"kernel": dom_name, "kernel_ms": round(t_ms, 3), "launches": int(trace_launches), "bound": bound,
+                "node_tests": int(counted["n_node_tests"]), "node_children": 4 if wide else 2, "tri_tests": int(counted["n_tri_tests"]),
+                "rays": int(rays_c), "bvh_bytes": int(info["total_bytes"])}
+        if bound == "valu":
+            roof.update({"achieved": round(valu_ach, 3), "peak": VALU_PEAK_TOPS, "unit": "Tops/s", "frac": round(fr_valu, 5),
+                         "algorithmic_ops": int(ops),
+                         "note": "VALU-issue bound (%s); ops = %d per node test + %d per triangle test + %d per ray (f32 vector operations as "
+                                 "written in rt_trace.h), peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"
+                                 % ("BVH of %.1f MB is L2 / Infinity-Cache resident" % (info["total_bytes"] / 1e6) if cache_resident
+                                    else "counters: VALU busier than HBM" if cd else "algorithmic bytes exceed what HBM can deliver: cache-served",
+                                    ops_node, OPS_TRI, OPS_RAY)})
+        else:
+            roof.update({"achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fr_hbm, 5),
+                         "algorithmic_bytes": int(trav_bytes + rec_bytes),
                          "note": "algorithmic bytes per SURVEY 8(d): N_node x %d + N_tri x %d + ray / hit records; the BVH (%.0f MB) "
                                  "exceeds L2 + Infinity Cache" % (info["node_bytes"], info["tri_bytes"], info["total_bytes"] / 1e6)})
-        roof["traffic"] = None
+        roof["valu_frac"], roof["hbm_algorithmic_frac"] = round(fr_valu, 5), round(fr_hbm, 5)
+        roof["traffic"] = traffic
         if ctr:
-            f, d = ctr
-            roof["traffic"] = d.get("dominant_kernel_hbm_bytes")
-            roof["traffic_source"] = os.path.relpath(f, ROOT)
-            if roof["traffic"]:
-                roof["hbm_measured_frac"] = round(roof["traffic"] / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)
-            for k in ("valu_busy_frac", "valu_lanes_per_instr", "valu_useful_frac"):
-                if k in d.get("dominant_kernel", {}):
-                    roof[k] = d["dominant_kernel"][k]
+            roof["traffic_source"] = os.path.relpath(ctr[0], ROOT)
+            if fr_hbm_measured is not None:
+                roof["hbm_measured_frac"] = round(fr_hbm_measured, 5)
+            for k in ("valu_busy_frac", "valu_lanes_per_instr", "valu_useful_frac", "l2_hit_rate"):
+                if k in cd:
+                    roof[k] = cd[k]
         out = {
             "metric": "Mrays/sec (primary+secondary) at 1024x1024 256spp" if wl.name == "pa4-cbox-path_mis" else "Mrays/sec (primary+secondary)",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -297,7 +310,7 @@ def main():
             out["cpu_baseline"] = cpu
             out["parity"] = parity
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -36,15 +36,16 @@ def shard(mode: str, rank: int, world: int, spp: int):
     raise ValueError(f"unknown shard mode {mode!r}")
 
 
-def _world():
+def _group_up() -> bool:
     import torch.distributed as dist
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return dist.is_available() and dist.is_initialized()
 
 
 def reduce_frame(frame, dst: int = 0):
-    """SUM-reduce the RGBW frame tensor to rank `dst` (in place there)."""
+    """SUM-reduce the RGBW frame tensor to rank `dst` (in place there).  Runs whenever a process group exists --
+    also for a group of one rank, so that a single-GPU launch under torch.distributed exercises the RCCL call."""
     import torch.distributed as dist
-    if _world() > 1:
+    if _group_up():
         dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
     return frame
 
@@ -63,10 +64,10 @@ def gather_frame(frame, rank: int, world: int, tiles_x: int, border: int, dst: i
     """Tile-split merge by ONE gather of every rank's column strips (see module docstring)."""
     import torch
     import torch.distributed as dist
-    if world <= 1:
-        return frame
     if tiles_x % world != 0:
         raise ValueError(f"gather merge needs tiles_x ({tiles_x}) divisible by the world size ({world}); use merge='reduce'")
+    if not _group_up():
+        return frame
     x, valid = column_strips(rank, world, tiles_x, border, frame.shape[1], frame.device)
     pack = (frame[:, x, :] * valid[None, :, None].to(frame.dtype)).contiguous()
     parts = [torch.empty_like(pack) for _ in range(world)] if rank == dst else None
