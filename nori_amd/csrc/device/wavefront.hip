@@ -170,6 +170,7 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
     const int lane = lane_id();
     Trav tv; trav_idle(tv);
     uint32_t rid = 0;            /* path << 2 | continuation pending << 1 | shadow ray occluded */
+    bool unsaved = false;        /* the lane's last query is answered (tv.hit) but its record is not written yet */
     bool exhausted = n == 0;
     /* Paths are handed to waves in chunks: every wave starts with a static chunk (no atomic), the
        rest -- about half, for load balance -- is claimed dynamically with one atomic per chunk.  The
@@ -203,6 +204,14 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                 chunk_pos = base; chunk_end = min(base + kChunk, n);
                 if (base >= n) { exhausted = true; chunk_pos = chunk_end = 0u; }
             }
+            /* Results are written HERE, not in the trip a query ends: on average five lanes of a wave finish per trip,
+               so storing right away ran the record packing at 5 / 64 lanes nearly every trip; at a refill >= 32 lanes are
+               idle and write together.  An idle lane keeps its answer in tv.hit until then. */
+            if (unsaved && !trav_active(tv)) {
+                if (pend) rid |= tv.hit.tri != kNoHit ? 1u : 0u;      /* the shadow ray is answered; the continuation ray of the same vertex is next */
+                else b.hit[rid >> 2] = tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u);
+                unsaved = false;
+            }
             const unsigned long long fresh = idle & ~pending;
             if (COUNT) { zc[Z_REFILLS]++; zc[Z_REFILL_LANES] += (uint32_t) nIdle; }
             const uint32_t avail = chunk_end - chunk_pos;
@@ -216,6 +225,7 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                         rid = i << 2;
                         trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, false, stack, tv);
                         ++nClosest; ++nCam;
+                        unsaved = trav_active(tv);
                         if (!trav_active(tv)) {
                             b.hit[i] = hit_pack(nullptr, false);
                         }
@@ -236,6 +246,7 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                     rid = pend ? (rid & ~2u) : ((i << 2) | ((any && (fl & F_HAS_A)) ? 2u : 0u));
                     trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, any, stack, tv);
                     if (any) ++nShadow; else ++nClosest;
+                    unsaved = trav_active(tv);
                     if (!trav_active(tv)) {            /* empty scene: nothing occludes, nothing is hit */
                         if (rid & 2u) { ++nClosest; rid &= ~2u; }
                         b.hit[i] = hit_pack(nullptr, false);
@@ -248,7 +259,6 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
             if (exhausted && __ballot((rid & 2u) != 0u) == 0ull) break;
             continue;
         }
-        const bool was = trav_active(tv);
         /* inner-node steps run every trip; the (rarer) triangle step only when enough lanes
            wait at a leaf or nobody has an inner node to test */
         if (COUNT) { const int ni = __popcll(__ballot(trav_at_inner(tv))); zc[Z_TRIPS]++; if (ni) { zc[Z_INNER_TRIPS]++; zc[Z_INNER_LANES] += (uint32_t) ni; } }
@@ -261,15 +271,11 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
         const bool innerLeft = __ballot(trav_at_inner(tv)) != 0ull;
         if (COUNT && nLeaf && (nLeaf >= leaf_threshold || !innerLeft)) { zc[Z_LEAF_TRIPS]++; zc[Z_LEAF_LANES] += (uint32_t) nLeaf; }
         if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT>(sc, stack, tv, tc);
-        if (was && !trav_active(tv)) {
-            if (rid & 2u) {      /* the shadow ray is answered; the continuation ray of the same vertex is next */
-                rid |= tv.hit.tri != kNoHit ? 1u : 0u;
-            } else {
-                /* a path with a shadow ray only ends on it (tv.any); otherwise the closest hit + the shadow answer */
-                b.hit[rid >> 2] = tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u);
-            }
-        }
     }
+    /* the answers still held in registers when the wave ran out of paths (no lane is pending here: the loop ends only
+       when no continuation ray is left): a path with a shadow ray only ends on it (tv.any); otherwise the closest hit
+       + the shadow answer */
+    if (unsaved) b.hit[rid >> 2] = tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u);
     /* counters: one atomic per wave */
     for (int off = 32; off > 0; off >>= 1) {
         nClosest += (uint32_t) __shfl_down((int) nClosest, off);
