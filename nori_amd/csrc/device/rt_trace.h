@@ -39,23 +39,16 @@ NORI_HD float exact_rcp(float x) {
 #endif
 }
 
-/* Reciprocal direction for the slab test.  A zero component maps to a huge
- * finite value so that (plane - o) * rcp is +-inf off the plane and exactly 0
- * on it -- the containment rule of bbox.h:331-333 (boundary inclusive) without
- * producing 0 * inf = NaN. */
+/* Reciprocal direction for the slab tests.  A zero (or denormal) component maps to +-2^60: huge, so that (plane - o) * rcp
+ * is astronomically far off the plane and exactly 0 on it -- the containment rule of bbox.h:331-333 (boundary inclusive)
+ * -- yet a power of two small enough that every product the node tests form with it (centre and half-extent form of
+ * the BVH2 node, quantised-plane form of the wide node) stays finite: no inf - inf, no 0 * inf. */
 NORI_HD float slab_rcp(float d) {
-    float r = exact_rcp(d);
-    if (!(fabsf(r) <= 3.0e38f)) r = (f2u(d) >> 31) ? -3.0e38f : 3.0e38f;
-    return r;
-}
-
-/* The same for WIDE trees: the clamp is 2^60, a power of two, so that products with it are exact and the
- * quantised-plane form t = q * (r 2^e) + (origin - o) * r cannot run into inf - inf. */
-NORI_HD float slab_rcp_wide(float d) {
     float r = exact_rcp(d);
     if (!(fabsf(r) <= 1.152921504606846976e18f)) r = (f2u(d) >> 31) ? -1.152921504606846976e18f : 1.152921504606846976e18f;
     return r;
 }
+NORI_HD float slab_rcp_wide(float d) { return slab_rcp(d); }
 
 /* byte k of a dword as float (v_cvt_f32_ubyte0..3 on the device) */
 NORI_HD float byte_to_float(uint32_t w, int k) { return (float) ((w >> (8 * k)) & 255u); }
@@ -76,24 +69,24 @@ NORI_HD bool tri_test(f3 p0, f3 edge1, f3 edge2, f3 o, f3 d, float &u, float &v,
     return true;
 }
 
-/* Slab test (include/nori/bbox.h:323-350) of BOTH child boxes of a node.  The x and y planes are
- * processed as 2-wide vectors against (o.x, o.y) / (rcp.x, rcp.y), the z planes of each child as
- * (min, max) pairs: 6 v_pk_add_f32 + 6 v_pk_mul_f32 (full rate on gfx950: two floats per lane per
- * issue) instead of 24 scalar VALU ops.  Element-wise IEEE -- same bits as the scalar form.  No NaN
- * can occur (slab_rcp is finite, boxes are finite), so the first axis initialises the interval. */
+/* Slab test (include/nori/bbox.h:323-350) of BOTH child boxes of a node, boxes in centre / half-extent form
+ * (rt_types.h): per axis  m = (c - o) r,  near = m - h |r|,  far = m + h |r|.  The centres pair up as 2-wide vectors
+ * (x, y of a child against (o.x, o.y); the two z's against o.z): 3 v_pk_add_f32 + 3 v_pk_mul_f32; near / far are one
+ * v_fma_f32 each with |r| as a source modifier -- 12 per node, full rate -- and one v_max3 / v_min3 per child:
+ * 22 VALU instructions where the min / max form of the two-plane test needs 34 (16 of them half rate).
+ * The fused multiply-add is explicit (IEEE: same bits on the device and in the CPU twins); the node test is not part
+ * of the reference's arithmetic -- it only has to be conservative, see trav_inner_step. */
 typedef float v2f __attribute__((vector_size(8)));
 
 NORI_HD void slab_two(const f4 &q0, const f4 &q1, const f4 &q2, f3 o, f3 rcp, float &nl, float &fl, float &nr, float &fr) {
     const v2f oxy = {o.x, o.y}, rxy = {rcp.x, rcp.y}, ozz = {o.z, o.z}, rzz = {rcp.z, rcp.z};
-    const v2f lmn = {q0.x, q0.y}, lmx = {q0.z, q0.w}, rmn = {q1.x, q1.y}, rmx = {q1.z, q1.w};
-    const v2f lz = {q2.x, q2.y}, rz = {q2.z, q2.w};
-    const v2f a = (lmn - oxy) * rxy, b = (lmx - oxy) * rxy;
-    const v2f c = (rmn - oxy) * rxy, d = (rmx - oxy) * rxy;
-    const v2f e = (lz - ozz) * rzz, f = (rz - ozz) * rzz;
-    nl = fmaxf(fmaxf(fminf(a[0], b[0]), fminf(a[1], b[1])), fminf(e[0], e[1]));
-    fl = fminf(fminf(fmaxf(a[0], b[0]), fmaxf(a[1], b[1])), fmaxf(e[0], e[1]));
-    nr = fmaxf(fmaxf(fminf(c[0], d[0]), fminf(c[1], d[1])), fminf(f[0], f[1]));
-    fr = fminf(fminf(fmaxf(c[0], d[0]), fmaxf(c[1], d[1])), fmaxf(f[0], f[1]));
+    const v2f lc = {q0.x, q0.y}, rc = {q0.z, q0.w}, cz = {q1.x, q1.y};
+    const v2f ml = (lc - oxy) * rxy, mr = (rc - oxy) * rxy, mz = (cz - ozz) * rzz;
+    const float ax = fabsf(rcp.x), ay = fabsf(rcp.y), az = fabsf(rcp.z);
+    nl = fmaxf(fmaxf(__builtin_fmaf(-ax, q2.x, ml[0]), __builtin_fmaf(-ay, q2.y, ml[1])), __builtin_fmaf(-az, q1.z, mz[0]));
+    fl = fminf(fminf(__builtin_fmaf(ax, q2.x, ml[0]), __builtin_fmaf(ay, q2.y, ml[1])), __builtin_fmaf(az, q1.z, mz[0]));
+    nr = fmaxf(fmaxf(__builtin_fmaf(-ax, q2.z, mr[0]), __builtin_fmaf(-ay, q2.w, mr[1])), __builtin_fmaf(-az, q1.w, mz[1]));
+    fr = fminf(fminf(__builtin_fmaf(ax, q2.z, mr[0]), __builtin_fmaf(ay, q2.w, mr[1])), __builtin_fmaf(az, q1.w, mz[1]));
 }
 
 /* Traversal state of one ray, advanced ONE step at a time so that a kernel can
@@ -153,7 +146,10 @@ NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, Travers
     if (COUNT) cnt.nodes++;
     float nl, fl, nr, fr;
     slab_two(q0, q1, q2, tv.o, tv.rcp, nl, fl, nr, fr);
-    fl *= 1.0000004f; fr *= 1.0000004f;
+    /* conservative: m carries 2.5 ulp/2 of relative error, the fma one rounding -- a far side widened by 10 u covers a ray
+       that meets the box far from its origin; where the origin is close to a large box the error is absolute,
+       <= 4 u (|c - o| + h) |r|, a tenth of the padding every leaf box carries (kBoxPadRel) for origins within the scene */
+    fl *= 1.0000006f; fr *= 1.0000006f;
     /* the box interval is clipped against [0, far limit], not [mint, ...]: a ray that leaves a surface at a
        grazing angle can re-hit its own triangle at a t that is pure rounding noise yet >= mint (the
        reference's scan reports it), while the ray is outside the triangle's box by then */

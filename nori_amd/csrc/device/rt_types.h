@@ -122,21 +122,39 @@ NORI_HD float tri_box_pad(f3 e1, f3 e2, float pad, bool &unbounded) {
     return s2 >= 1.0f ? pad : pad / sqrtf(s2);
 }
 
-/* One BVH2 node = 64 B = 4 x dwordx4: both child boxes + both child links, so
- * one fetch decides both children.
- *   q0 = (lmin.x, lmin.y, lmax.x, lmax.y)      x/y planes pair up with (o.x, o.y), the z planes of a
- *   q1 = (rmin.x, rmin.y, rmax.x, rmax.y)      child with each other: the slab test (rt_trace.h,
- *   q2 = (lmin.z, lmax.z, rmin.z, rmax.z)      slab_two) runs on packed f32 instructions
+/* One BVH2 node = 64 B = 4 x dwordx4: both child boxes + both child links, so one fetch decides both children.
+ * A child box is stored as CENTRE c and HALF-EXTENT h per axis: for a ray o + t d with r = 1 / d the slab interval of
+ * an axis is  (c - o) r -+ h |r|  -- near and far come out of ONE multiply and two fused multiply-adds whose |r| is a free
+ * source modifier, with no min / max to sort the two planes (on gfx950 v_min / v_max issue at half the rate of
+ * v_fma; the min / max form cost 16 of them per node, rt_trace.h slab_two).
+ *   q0 = (lc.x, lc.y, rc.x, rc.y)      the x / y centres pair up with (o.x, o.y) / (r.x, r.y): packed f32 subtract, multiply
+ *   q1 = (lc.z, rc.z, lh.z, rh.z)
+ *   q2 = (lh.x, lh.y, rh.x, rh.y)
  *   q3 = (bits left, bits right, 0, 0)
+ * [c - h, c + h] contains the child's (padded) box: c = the rounded midpoint, h rounded up from max(hi - c, c - lo)
+ * evaluated in binary64.  An unbounded box (numerically collinear triangles, tri_box_pad) is c = 0, h = kBoxHalfInf.
  * child link >= 0: inner node index; < 0: leaf, ~link = (first_tri << 3) | (count - 1)
  */
 constexpr int kNodeQuads = 4;
+constexpr float kBoxHalfInf = 5.76460752303423488e17f;      /* 2^59: with |r| <= 2^60 (slab_rcp) the products stay finite */
+
+NORI_HD void box_centre_half(float mn, float mx, float &c, float &h) {
+    if (!(fabsf(mn) < 1e37f) || !(fabsf(mx) < 1e37f)) { c = 0.0f; h = kBoxHalfInf; return; }
+    c = 0.5f * mn + 0.5f * mx;
+    const double lo = (double) c - (double) mn, hi = (double) mx - (double) c;
+    const double hd = lo > hi ? lo : hi;
+    h = (float) hd;
+    if ((double) h < hd) h = u2f(f2u(h) + 1u);      /* next float up (h >= 0) */
+    if (!(h >= 0.0f)) h = 0.0f;
+}
 
 NORI_HD void node_pack(const float lmn[3], const float lmx[3], const float rmn[3], const float rmx[3],
                        int32_t left, int32_t right, f4 q[4]) {
-    q[0].x = lmn[0]; q[0].y = lmn[1]; q[0].z = lmx[0]; q[0].w = lmx[1];
-    q[1].x = rmn[0]; q[1].y = rmn[1]; q[1].z = rmx[0]; q[1].w = rmx[1];
-    q[2].x = lmn[2]; q[2].y = lmx[2]; q[2].z = rmn[2]; q[2].w = rmx[2];
+    float lc[3], lh[3], rc[3], rh[3];
+    for (int a = 0; a < 3; ++a) { box_centre_half(lmn[a], lmx[a], lc[a], lh[a]); box_centre_half(rmn[a], rmx[a], rc[a], rh[a]); }
+    q[0].x = lc[0]; q[0].y = lc[1]; q[0].z = rc[0]; q[0].w = rc[1];
+    q[1].x = lc[2]; q[1].y = rc[2]; q[1].z = lh[2]; q[1].w = rh[2];
+    q[2].x = lh[0]; q[2].y = lh[1]; q[2].z = rh[0]; q[2].w = rh[1];
     q[3].x = u2f((uint32_t) left); q[3].y = u2f((uint32_t) right); q[3].z = 0.0f; q[3].w = 0.0f;
 }
 constexpr int kMaxLeafTris = 8;      /* = 4 pairs */

@@ -331,26 +331,37 @@ size_t emu_packed_vs_scalar(size_t n, uint64_t seed) {
             if (ok != h.ok[k]) ++bad;
             else if (ok && (f2u(u) != f2u(h.u[k]) || f2u(v) != f2u(h.v[k]) || f2u(t) != f2u(h.t[k]))) ++bad;
         }
-        /* node test: packed slab_two against the scalar slab of bbox.h:323-350 */
+        /* node test: slab_two (centre / half-extent boxes, fused multiply-adds) must be CONSERVATIVE against the exact slab test
+           of bbox.h:323-350 evaluated in binary64: whenever the ray meets the box shrunk by a seventh of the padding every leaf
+           box carries (kBoxPadRel x scene diagonal ~ 7e-6 x scale here), the device's test must report the box */
         f4 n[4]; float lmn[3], lmx[3], rmn[3], rmx[3];
         for (int a = 0; a < 3; ++a) {
             float x0 = rnd(-scale, scale), x1 = rnd(-scale, scale), y0 = rnd(-scale, scale), y1 = rnd(-scale, scale);
+            if (i % 4 == 1) { x1 = x0 + rnd(0.0f, 1e-3f) * scale; y1 = y0 + rnd(0.0f, 2e-5f) * scale; }      /* thin boxes */
             lmn[a] = fminf(x0, x1); lmx[a] = i % 9 == 4 ? lmn[a] : fmaxf(x0, x1); rmn[a] = fminf(y0, y1); rmx[a] = fmaxf(y0, y1);
         }
         node_pack(lmn, lmx, rmn, rmx, 1, 2, n);
         const f3 rcp = mk3(slab_rcp(d.x), slab_rcp(d.y), slab_rcp(d.z));
         float nl, fl, nr, fr;
         slab_two(n[0], n[1], n[2], o, rcp, nl, fl, nr, fr);
-        const float oo[3] = {o.x, o.y, o.z}, rr[3] = {rcp.x, rcp.y, rcp.z};
+        fl *= 1.0000006f; fr *= 1.0000006f;                          /* as trav_inner_step */
+        const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+        const double shrink = 1e-6 * scale;
         for (int side = 0; side < 2; ++side) {
             const float *mn = side ? rmn : lmn, *mx = side ? rmx : lmx;
-            float tn = -kInf, tf = kInf;
+            double tn = -1e300, tf = 1e300;
+            bool miss = false;
             for (int a = 0; a < 3; ++a) {
-                const float t1 = (mn[a] - oo[a]) * rr[a], t2 = (mx[a] - oo[a]) * rr[a];
-                tn = fmaxf(tn, fminf(t1, t2)); tf = fminf(tf, fmaxf(t1, t2));
+                const double lo = (double) mn[a] + shrink, hi = (double) mx[a] - shrink;
+                if (lo > hi) { miss = true; break; }                 /* thinner than the margin: nothing to demand */
+                if (dd[a] == 0.0) { if (oo[a] < lo || oo[a] > hi) miss = true; continue; }
+                const double t1 = (lo - oo[a]) / dd[a], t2 = (hi - oo[a]) / dd[a];
+                tn = std::max(tn, std::min(t1, t2)); tf = std::min(tf, std::max(t1, t2));
             }
+            const bool exact_hit = !miss && tn <= tf && tf >= 0.0 && tn <= (double) maxt;
             const float gn = side ? nr : nl, gf = side ? fr : fl;
-            if (f2u(tn) != f2u(gn) || f2u(tf) != f2u(gf)) ++bad;
+            const bool dev_hit = (gn <= gf) && (gf >= 0.0f) && (gn <= maxt);
+            if (exact_hit && !dev_hit) ++bad;
         }
     }
     return bad;
