@@ -138,11 +138,32 @@ NORI_HD void trav_pop(Stack &stack, Trav &tv) {
     tv.node = stack.pop_or(kTravDone);
 }
 
+/* The top of the tree in LDS.  Every ray starts at the root, so the few nodes of the first levels are fetched by every lane
+ * of every wave -- and a per-lane 64-B node fetch is four 16-B accesses of the CU's vector L1, which serves ONE access per
+ * clock: counters show wf_extend at 1.04 L1 accesses per clock per CU (profiles/r2_02_*tcp*), i.e. bound by the L1's tag
+ * rate, not by VALU or HBM.  A kernel that keeps the first kTopNodes nodes (breadth first from the root) in LDS takes the
+ * first ~5 of a ray's ~9 node steps out of the L1.  Links to cached nodes carry kTopBit and the LDS slot; cached records
+ * are kTopStrideQuads * 16 B apart (80 B: consecutive slots start in different banks). */
+constexpr int kTopNodes = 32;
+constexpr int kTopStrideQuads = 5;
+constexpr int kTopBit = 0x40000000;          /* node indices stay below 2^30 */
+
+/* the four quads of node `node`: from the LDS cache (`top` non-null and the link carries kTopBit) or from memory */
+NORI_HD void node_fetch(const DevScene &sc, const f4 *top, int node, f4 &q0, f4 &q1, f4 &q2, f4 &q3) {
+    if (top != nullptr && (node & kTopBit)) {
+        const f4 *nq = top + (node & (kTopNodes - 1)) * kTopStrideQuads;
+        q0 = nq[0]; q1 = nq[1]; q2 = nq[2]; q3 = nq[3];
+    } else {
+        const f4 *nq = sc.nodes + (size_t) node * kNodeQuads;
+        q0 = nq[0]; q1 = nq[1]; q2 = nq[2]; q3 = nq[3];
+    }
+}
+
 /* one inner-node step: both child boxes from one 64-B record */
 template <bool COUNT, class Stack>
-NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt) {
-    const f4 *nq = sc.nodes + (size_t) tv.node * kNodeQuads;
-    const f4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, const f4 *top = nullptr) {
+    f4 q0, q1, q2, q3;
+    node_fetch(sc, top, tv.node, q0, q1, q2, q3);
     if (COUNT) cnt.nodes++;
     float nl, fl, nr, fr;
     slab_two(q0, q1, q2, tv.o, tv.rcp, nl, fl, nr, fr);
@@ -193,9 +214,9 @@ NORI_HD Wide4 wide_planes(uint32_t w, float A, float B) {
 }
 
 template <bool COUNT, class Stack>
-NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt) {
-    const f4 *nq = sc.nodes + (size_t) tv.node * kNodeQuads;
-    const f4 q0 = nq[0], q1 = nq[1], q2 = nq[2], q3 = nq[3];
+NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, const f4 *top = nullptr) {
+    f4 q0, q1, q2, q3;
+    node_fetch(sc, top, tv.node, q0, q1, q2, q3);
     if (COUNT) cnt.nodes++;
     const uint32_t meta = f2u(q0.w);
     const int l0 = (int) f2u(q3.x), l1 = (int) f2u(q3.y), l2 = (int) f2u(q3.z), l3 = (int) f2u(q3.w);

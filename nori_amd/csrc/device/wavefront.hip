@@ -134,6 +134,42 @@ struct LdsStackW<DEPTH, false> {
 
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
 
+/* Copies the first kTopNodes nodes of the tree, breadth first from the root, into the workgroup's LDS cache (rt_trace.h,
+   node_fetch) and rewrites the links between cached nodes to kTopBit | slot.  Works on any node order (host SAH: depth
+   first; device LBVH: radix order) and both layouts (links are q3.x, q3.y [, q3.z, q3.w]; inner = non-negative).
+   Returns the link a walk starts with.  s_q / s_cnt: 32 + 2 ints of LDS scratch. */
+__device__ int top_nodes_to_lds(const DevScene &sc, f4 *top, int *s_q, int *s_cnt) {
+    if (sc.n_triangles == 0u || sc.root < 0) return sc.root;            /* empty scene, or the root is a leaf */
+    const int tid = (int) threadIdx.x, n_links = sc.wide ? 4 : 2;
+    if (tid == 0) { s_q[0] = sc.root; s_cnt[0] = 1; }
+    __syncthreads();
+    int head = 0;
+    while (true) {
+        const int end = min(s_cnt[0], kTopNodes);                        /* this level: slots [head, end) */
+        __syncthreads();
+        if (head >= end) break;
+        if (head + tid < end) {
+            const int slot = head + tid;
+            const f4 *nq = sc.nodes + (size_t) s_q[slot] * kNodeQuads;
+            const f4 q0 = nq[0], q1 = nq[1], q2 = nq[2];
+            f4 q3 = nq[3];
+            auto adopt = [&](float &link_bits) {                          /* an inner child gets a slot while there is room */
+                const int child = (int) __float_as_uint(link_bits);
+                if (child < 0) return;                                   /* leaf (or unused wide slot) */
+                const int s = atomicAdd(&s_cnt[0], 1);
+                if (s < kTopNodes) { s_q[s] = child; link_bits = __uint_as_float((uint32_t) (kTopBit | s)); }
+            };
+            adopt(q3.x); adopt(q3.y);
+            if (n_links == 4) { adopt(q3.z); adopt(q3.w); }
+            f4 *dst = top + slot * kTopStrideQuads;
+            dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
+        }
+        head = end;
+        __syncthreads();
+    }
+    return kTopBit | 0;
+}
+
 /* The first vertex of the batch's path p is never stored: its camera sample (renderBlock,
    src/main.cpp:41-46) is recomputed where it is needed -- by the first wf_extend (ray) and the first
    wf_shade (direction, pcg32 state) -- which costs ~100 instructions twice and saves writing and
@@ -162,6 +198,10 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     LdsStackW<STACK, SPILL> stack;
     stack.init(smem, b.stack_spill, gridDim.x * kB);
+    /* the first levels of the tree in LDS (rt_trace.h, node_fetch): behind the stacks */
+    f4 *top = reinterpret_cast<f4 *>(smem + (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int));
+    int *top_scratch = reinterpret_cast<int *>(top + kTopNodes * kTopStrideQuads);
+    const int root_link = top_nodes_to_lds(sc, top, top_scratch, top_scratch + kTopNodes);
     const WfState S = b.st[cur];
     const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
     /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
@@ -226,6 +266,7 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                         trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, false, stack, tv);
                         ++nClosest; ++nCam;
                         unsaved = trav_active(tv);
+                        if (unsaved) tv.node = root_link;
                         if (!trav_active(tv)) {
                             b.hit[i] = hit_pack(nullptr, false);
                         }
@@ -247,6 +288,7 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                     trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, any, stack, tv);
                     if (any) ++nShadow; else ++nClosest;
                     unsaved = trav_active(tv);
+                    if (unsaved) tv.node = root_link;
                     if (!trav_active(tv)) {            /* empty scene: nothing occludes, nothing is hit */
                         if (rid & 2u) { ++nClosest; rid &= ~2u; }
                         b.hit[i] = hit_pack(nullptr, false);
@@ -263,8 +305,8 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
            wait at a leaf or nobody has an inner node to test */
         if (COUNT) { const int ni = __popcll(__ballot(trav_at_inner(tv))); zc[Z_TRIPS]++; if (ni) { zc[Z_INNER_TRIPS]++; zc[Z_INNER_LANES] += (uint32_t) ni; } }
         if (trav_at_inner(tv)) {
-            if (WIDE) trav_wide_step<COUNT>(sc, stack, tv, tc);      /* BVH4, quantised boxes: scenes beyond the caches */
-            else trav_inner_step<COUNT>(sc, stack, tv, tc);
+            if (WIDE) trav_wide_step<COUNT>(sc, stack, tv, tc, top);      /* BVH4, quantised boxes: scenes beyond the caches */
+            else trav_inner_step<COUNT>(sc, stack, tv, tc, top);
         }
         const bool atLeaf = trav_at_leaf(tv);
         const int nLeaf = __popcll(__ballot(atLeaf));
@@ -517,7 +559,7 @@ std::string ensure_pool(Pool &pool, size_t records) {
 
 template <int STACK, bool SPILL, bool COUNT, bool FIRST>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, const WfBatch &bt, hipStream_t s) {
-    const size_t lds = (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int);
+    const size_t lds = (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int) + kTopNodes * kTopStrideQuads * sizeof(f4) + (kTopNodes + 2) * sizeof(int);
     if (sc.wide) {
         /* wide trees push up to three children per step: always the spilling stack */
         if (SPILL) hipLaunchKernelGGL((wf_extend<STACK, true, COUNT, FIRST, true>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill, bt);
@@ -700,7 +742,8 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     int finish_paths = 524288;           /* fewer live paths than this: wf_finish ends the batch */
     if (const char *e = getenv("NORI_HIP_WF_FINISH_PATHS")) finish_paths = std::max(256, atoi(e)) & ~255;
     const int finish_grid = finish_paths / kB;
-    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + 64))));
+    /* LDS per workgroup: stack entries (+1: the "done" marker of the non-spilling stack) + the top-node cache */
+    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + kTopNodes * kTopStrideQuads * sizeof(f4) + (kTopNodes + 2) * sizeof(int)))));
     /* every workgroup of the persistent grid must be resident from the start (a workgroup that starts late owns a
        static share of the paths and works it off alone): the wide-node kernels are built for 6 waves per SIMD
        (their first-pass variant for 5: measured 3.47 vs 3.29 Grays/s on the terrain against 5 everywhere) */
