@@ -274,10 +274,14 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                 }
             } else if (pend || (!trav_active(tv) && rank < avail)) {
                 const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
-                /* flags, origin and both directions are requested together: one round trip to HBM instead
-                   of two (the direction a path needs first depends on its flags) */
-                const uint32_t fl0 = S.flags[i];
-                const f4 o = S.o[i], dA0 = S.dA[i], dB0 = S.dB[i];
+                /* a fresh path: flags, origin and both directions are requested together -- one round trip to HBM
+                   instead of two (the direction a path needs first depends on its flags).  A path whose shadow ray
+                   was just answered needs its origin and continuation direction again (32 B; its lane could not
+                   afford to keep them in registers during the shadow walk), not its flags or shadow direction. */
+                uint32_t fl0 = 0u;
+                f4 dB0; dB0.x = dB0.y = dB0.z = dB0.w = 0.0f;
+                if (!pend) { fl0 = S.flags[i]; dB0 = S.dB[i]; }
+                const f4 o = S.o[i], dA0 = S.dA[i];
                 const uint32_t fl = pend ? F_HAS_A : fl0;
                 if (fl & (F_HAS_A | F_HAS_B)) {      /* 0: empty slot */
                     const bool any = (fl & F_HAS_B) != 0u;
