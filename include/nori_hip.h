@@ -9,7 +9,12 @@
  * through the entry points declared here.  Plain pointers and sizes only; no
  * C++ types, no torch types.  Every function returns 0 on success or a
  * negative `nori_status`; nothing throws across the boundary.  A context is
- * bound to one GPU and is not thread safe (one host thread per GPU).
+ * bound to one GPU and is not thread safe (one host thread per context).  A
+ * context owns every device buffer it uses -- scene, tree, the wavefront
+ * engine's path-state pool and streams, the film's sample store -- so any
+ * number of contexts may live in one process (one per GPU, or several on one
+ * GPU) without sharing or freeing each other's memory; nori_hip_destroy frees
+ * exactly its context's.
  *
  * Each entry point cites the reference interface it replaces
  * (paths relative to the wjakob/nori tree).
