@@ -198,3 +198,30 @@ def test_fuzz_engines_short():
     from tests import fuzz_engines
     for seed in range(2000, 2012):
         fuzz_engines.one_round(seed, Renderer, oracle=seed % 2 == 0)
+
+
+def test_contexts_own_their_buffers():
+    """Two contexts in one process (here on the same GPU): the wavefront engine's state pool, its streams and the film
+    store belong to the context (include/nori_hip.h), so interleaved renders do not disturb each other and destroying
+    one context leaves the other's buffers alone."""
+    from nori_amd.render import Renderer
+    sc1 = scenes.cornell_box(96, 64, 6, "path_mis")
+    sc2 = scenes.cornell_box(48, 80, 5, "path_ems", sphere_bsdfs=[Bsdf("microfacet", (0.2, 0.3, 0.1), 0.2), Bsdf("diffuse")])
+    a, b = Renderer(0).upload(sc1), Renderer(0).upload(sc2)
+    for r in (a, b):
+        r.set_option("engine", "wavefront")
+    A1, _ = a.render_host()
+    B1, _ = b.render_host()
+    A2, _ = a.render_host()
+    assert np.array_equal(A1, A2)
+    b.set_option("wavefront_paths", 256 * 7)          # b regrows / rebatches its own pool; a is untouched
+    B2, _ = b.render_host()
+    np.testing.assert_allclose(B2, B1, rtol=1e-4, atol=1e-5)
+    assert np.array_equal(a.render_host()[0], A1)
+    a.close()                                           # frees a's pool, film store, streams -- not b's
+    B3, _ = b.render_host()
+    assert np.array_equal(B3, B2)
+    c = Renderer(0).upload(sc1)
+    c.set_option("engine", "wavefront")
+    assert np.array_equal(c.render_host()[0], A1)
+    b.close(); c.close()
