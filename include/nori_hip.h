@@ -288,6 +288,10 @@ int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out);
  *   "accel_layout"    node layout of the NEXT nori_hip_build_accel: "bvh2" (64-B node = two full-precision child
  *                     boxes) | "bvh4q" (64-B node = four child boxes quantised to 8 bits: half the node fetches,
  *                     for trees that do not fit the caches) | "auto" (default: bvh4q from 2^20 triangles)
+ *   "film_order"      "fast" (default: the film adds a pixel's samples round by round in LDS tiles) | "reference" (the
+ *                     samples are added in the order of renderBlock / ImageBlock::put / BlockGenerator,
+ *                     src/main.cpp:33-53, src/block.cpp:62-152: whole frames only, slower -- the frame is then
+ *                     bit-identical to a single-threaded render of the same samples by the reference's loops)
  * Unknown keys return NORI_ERR_INVALID_ARGUMENT. */
 int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value);
 

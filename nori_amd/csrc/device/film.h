@@ -15,6 +15,18 @@
  *   film_resolve  ImageBlock::put(ImageBlock&) (src/block.cpp:93-102): every
  *                 frame pixel gathers the <= 4 tile accumulators that cover it.
  * Deterministic: the same inputs give the same bits, independent of scheduling.
+ *
+ * REFERENCE ORDER (option film_order = "reference").  The fast path above adds a pixel's samples round by round and
+ * tap by tap; the reference adds them in the order of renderBlock / ImageBlock::put (src/main.cpp:33-53,
+ * src/block.cpp:62-102): per 32x32 block, source pixel after source pixel in raster order, sample after sample, each
+ * (value * wx) * wy into the block's own accumulator -- and the blocks into the frame in BlockGenerator's spiral order
+ * (src/block.cpp:109-152).  Float addition is not associative, so the two differ in the last bits.
+ * film_reference_order reproduces the reference's order: one workgroup per 32x32 block, one thread per pixel of the
+ * block's bordered accumulator walking the source pixels that reach it in raster order and their samples in index
+ * order; then every frame pixel adds the (at most four) blocks that cover it by ascending spiral rank.  With
+ * bit-identical radiance per camera sample the FRAME is then bit-identical to a single-threaded
+ * render of the CPU oracle.  Slower (every sample is read by up to 25 threads straight from the store): a mode for
+ * comparisons, not the default.
  */
 #pragma once
 #include <string>
@@ -32,6 +44,10 @@ struct FilmStore {
                                    into its own accumulator (few tiles per GPU: keeps all CUs busy); fixed per render */
     size_t acc_floats = 0;
     unsigned long long *d_invalid = nullptr;
+    float *block_acc = nullptr;          /* reference order: n_blocks x (32 + 2 border)^2 x 4 */
+    size_t block_floats = 0;
+    uint32_t *spiral_rank = nullptr;     /* reference order: position of every 32x32 block in BlockGenerator's sequence */
+    size_t n_rank = 0;
 };
 
 struct FilmLaunch {
@@ -56,6 +72,11 @@ std::string film_prepare(FilmStore &store, size_t n_samples, size_t n_sel_tiles,
 void film_gather(const DevScene &sc, const float *d_filter_table, const FilmStore &st, const FilmLaunch &fl, void *stream);
 /* add all accumulators into the caller's RGBW frame */
 void film_resolve(const DevScene &sc, const FilmStore &st, const FilmLaunch &fl, float *d_rgbw, void *stream);
+/* Reference-order film (see the header comment): the store must hold EVERY sample of the frame -- all tiles, samples
+   [0, n_spp) of every pixel, index (tile * n_spp + s) * 256 + pixel -- because a pixel's samples are added
+   consecutively.  Accumulates into d_rgbw.  "" or an error. */
+std::string film_reference_order(FilmStore &store, const FilmStore &view, const DevScene &sc, const float *d_filter_table,
+                                 uint32_t n_spp, uint32_t tiles_x, float *d_rgbw, void *stream);
 /* samples dropped by the isValid() guard (src/block.cpp:63-67) since film_prepare; synchronises `stream` */
 unsigned long long film_invalid_count(const FilmStore &st, void *stream);
 void film_release(FilmStore &store);

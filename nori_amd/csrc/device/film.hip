@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "film.h"
 
@@ -151,6 +152,116 @@ __global__ void film_resolve_kernel(int width, int height, int border, int tile_
     *dst = cur;
 }
 
+/* ---- reference order ---- */
+constexpr int kBlock32 = 32;          /* NORI_BLOCK_SIZE, include/nori/block.h:17 */
+
+/* one workgroup per 32x32 block; a thread owns pixels of the block's bordered accumulator and adds, for each, the
+   samples that reach it in the reference's order: source pixels in raster order (renderBlock's y, x loops,
+   src/main.cpp:33-34), samples in index order (:35), each as ImageBlock::put does (src/block.cpp:62-91) */
+__global__ __launch_bounds__(kB) void film_block_reference_kernel(int width, int height, FilterRec fr, const float *__restrict__ filter_table,
+                                                                  FilmStore st, uint32_t n_spp, uint32_t tiles_x, uint32_t blocks_x) {
+    __shared__ float ftab[kFilterRes + 1];
+    if (threadIdx.x <= kFilterRes) ftab[threadIdx.x] = filter_table[threadIdx.x];
+    __syncthreads();
+    const int bx = (int) (blockIdx.x % blocks_x), by = (int) (blockIdx.x / blocks_x);
+    const int offx = bx * kBlock32, offy = by * kBlock32;
+    const int bw = min(kBlock32, width - offx), bh = min(kBlock32, height - offy);
+    const int border = fr.border, cols = bw + 2 * border, rows = bh + 2 * border;
+    const float radius = fr.radius, lookup = fr.lookup_factor;
+    float4 *dst = reinterpret_cast<float4 *>(st.block_acc) + (size_t) blockIdx.x * (kBlock32 + 2 * border) * (kBlock32 + 2 * border);
+    unsigned long long invalid = 0;
+    for (int i = (int) threadIdx.x; i < cols * rows; i += kB) {
+        const int oy = i / cols, ox = i - oy * cols;
+        const float fx = (float) ox, fy = (float) oy;
+        float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int sy = max(0, oy - 2 * border); sy <= min(bh - 1, oy); ++sy)
+            for (int sx = max(0, ox - 2 * border); sx <= min(bw - 1, ox); ++sx) {
+                const int px = offx + sx, py = offy + sy;
+                const uint32_t tile = (uint32_t) (py / kTile) * tiles_x + (uint32_t) (px / kTile);
+                const int lx = px % kTile, ly = py % kTile;
+                const uint32_t pix = (uint32_t) ((((lx >> 3) | ((ly >> 3) << 1)) << 6) | ((lx & 7) | ((ly & 7) << 3)));      /* inverse of film_tile_pixel */
+                const bool centre = ox == sx + border && oy == sy + border;      /* one thread per source pixel counts its invalid samples */
+                const size_t idx0 = (size_t) tile * n_spp * 256u + pix;
+                /* branch-free body, four samples in flight: a sample outside its bounding box (block.cpp:76-80) or rejected
+                   by the isValid() guard (:63-67) is given weight 0 and radiance 0 -- adding (0 * 0) * wy = +0 leaves the
+                   accumulator's bits alone (it can never be -0), exactly as skipping it does */
+                auto term = [&](size_t idx, float4 &a) {
+                    f4 L = st.L[idx];
+                    const f2 p = st.pos[idx];
+                    const bool ok = color_valid(mk3(L.x, L.y, L.z));
+                    if (centre && !ok) ++invalid;
+                    const float bpx = p.x - 0.5f - (float) (offx - border), bpy = p.y - 0.5f - (float) (offy - border);
+                    const bool in = ok && fx >= bpx - radius && fx <= bpx + radius && fy >= bpy - radius && fy <= bpy + radius;
+                    const float wx = in ? ftab[(int) (fabsf(fx - bpx) * lookup)] : 0.0f, wy = in ? ftab[(int) (fabsf(fy - bpy) * lookup)] : 0.0f;
+                    if (!in) L.x = L.y = L.z = 0.0f;
+                    a.x += (L.x * wx) * wy; a.y += (L.y * wx) * wy; a.z += (L.z * wx) * wy; a.w += (1.0f * wx) * wy;
+                };
+                uint32_t s = 0;
+                for (; s + 4u <= n_spp; s += 4u) {
+                    term(idx0 + (size_t) s * 256u, acc); term(idx0 + (size_t) (s + 1u) * 256u, acc);
+                    term(idx0 + (size_t) (s + 2u) * 256u, acc); term(idx0 + (size_t) (s + 3u) * 256u, acc);
+                }
+                for (; s < n_spp; ++s) term(idx0 + (size_t) s * 256u, acc);
+            }
+        dst[oy * (kBlock32 + 2 * border) + ox] = acc;
+    }
+    for (int off = 32; off > 0; off >>= 1) invalid += __shfl_down(invalid, off);
+    if ((threadIdx.x & 63u) == 0u && invalid) atomicAdd(st.d_invalid, invalid);
+}
+
+/* ImageBlock::put(ImageBlock&) in the order the blocks arrive from BlockGenerator: every frame pixel adds the blocks
+   covering it by ascending spiral rank */
+__global__ void film_resolve_reference_kernel(int width, int height, int border, uint32_t blocks_x, uint32_t blocks_y,
+                                              const float *block_acc, const uint32_t *spiral_rank, float *rgbw) {
+    const int cols = width + 2 * border, rows = height + 2 * border;
+    const int gx = blockIdx.x * blockDim.x + threadIdx.x, gy = blockIdx.y;
+    if (gx >= cols || gy >= rows) return;
+    const int stride = kBlock32 + 2 * border;
+    float4 val[4]; uint32_t rank[4]; int n = 0;
+    const int bx1 = min(gx / kBlock32, (int) blocks_x - 1), by1 = min(gy / kBlock32, (int) blocks_y - 1);
+    const int bx0 = max(0, (gx - 2 * border) / kBlock32), by0 = max(0, (gy - 2 * border) / kBlock32);
+    for (int by = by0; by <= by1; ++by)
+        for (int bx = bx0; bx <= bx1; ++bx) {
+            const int bw = min(kBlock32, width - bx * kBlock32), bh = min(kBlock32, height - by * kBlock32);
+            const int lx = gx - bx * kBlock32, ly = gy - by * kBlock32;
+            if (lx < 0 || ly < 0 || lx >= bw + 2 * border || ly >= bh + 2 * border || n >= 4) continue;
+            const uint32_t b = (uint32_t) by * blocks_x + (uint32_t) bx;
+            val[n] = *reinterpret_cast<const float4 *>(block_acc + (((size_t) b * stride + (size_t) ly) * stride + lx) * 4);
+            rank[n] = spiral_rank[b]; ++n;
+        }
+    for (int i = 1; i < n; ++i)                                   /* insertion sort by spiral rank */
+        for (int j = i; j > 0 && rank[j] < rank[j - 1]; --j) {
+            const uint32_t tr = rank[j]; rank[j] = rank[j - 1]; rank[j - 1] = tr;
+            const float4 tv = val[j]; val[j] = val[j - 1]; val[j - 1] = tv;
+        }
+    float4 sum = make_float4(0.0f, 0.0f, 0.0f, 0.0f);              /* the frame starts cleared (main.cpp:68) */
+    for (int i = 0; i < n; ++i) { sum.x += val[i].x; sum.y += val[i].y; sum.z += val[i].z; sum.w += val[i].w; }
+    float4 *dst = reinterpret_cast<float4 *>(rgbw) + (size_t) gy * cols + gx;
+    float4 cur = *dst;
+    cur.x += sum.x; cur.y += sum.y; cur.z += sum.z; cur.w += sum.w;
+    *dst = cur;
+}
+
+/* BlockGenerator (src/block.cpp:109-152): from the centre block (nbx / 2, nby / 2) a square spiral -- right 1, down 1,
+   left 2, up 2, right 3, ... -- skipping positions outside the grid; rank = position in that sequence */
+std::vector<uint32_t> spiral_ranks(int nbx, int nby) {
+    std::vector<uint32_t> rank((size_t) nbx * nby, 0u);
+    int x = nbx / 2, y = nby / 2, placed = 0, run = 1, dir = 0;      /* dir: 0 right, 1 down, 2 left, 3 up */
+    const int dx[4] = {1, 0, -1, 0}, dy[4] = {0, 1, 0, -1};
+    if (x >= 0 && y >= 0 && x < nbx && y < nby) rank[(size_t) y * nbx + x] = (uint32_t) placed++;
+    while (placed < nbx * nby) {
+        for (int leg = 0; leg < 2 && placed < nbx * nby; ++leg) {    /* two legs share a run length */
+            for (int k = 0; k < run && placed < nbx * nby; ++k) {
+                x += dx[dir]; y += dy[dir];
+                if (x >= 0 && y >= 0 && x < nbx && y < nby) rank[(size_t) y * nbx + x] = (uint32_t) placed++;
+            }
+            dir = (dir + 1) & 3;
+        }
+        ++run;
+    }
+    return rank;
+}
+
 } // namespace
 
 namespace nrt {
@@ -158,6 +269,8 @@ namespace nrt {
 #define FILM_TRY(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) return std::string(#expr) + ": " + hipGetErrorString(e__); } while (0)
 
 void film_release(FilmStore &g_film) {
+    if (g_film.block_acc) (void) hipFree(g_film.block_acc);
+    if (g_film.spiral_rank) (void) hipFree(g_film.spiral_rank);
     if (g_film.pos) (void) hipFree(g_film.pos);
     if (g_film.L) (void) hipFree(g_film.L);
     if (g_film.tile_acc) (void) hipFree(g_film.tile_acc);
@@ -202,6 +315,35 @@ void film_resolve(const DevScene &sc, const FilmStore &st, const FilmLaunch &fl,
     hipLaunchKernelGGL(film_resolve_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, (hipStream_t) stream, sc.camera.width,
                        sc.camera.height, border, fl.tile_w, fl.tiles_x, fl.tiles_y, fl.tile_mod, fl.tile_rem, st.n_parts,
                        (const float *) st.tile_acc, d_rgbw);
+}
+
+std::string film_reference_order(FilmStore &store, const FilmStore &view, const DevScene &sc, const float *d_filter_table,
+                                 uint32_t n_spp, uint32_t tiles_x, float *d_rgbw, void *stream) {
+    const int w = sc.camera.width, h = sc.camera.height, border = sc.filter.border;
+    const uint32_t bxn = (uint32_t) ((w + kBlock32 - 1) / kBlock32), byn = (uint32_t) ((h + kBlock32 - 1) / kBlock32), nb = bxn * byn;
+    const size_t floats = (size_t) nb * (kBlock32 + 2 * border) * (kBlock32 + 2 * border) * 4;
+    if (store.block_floats < floats) {
+        if (store.block_acc) (void) hipFree(store.block_acc);
+        store.block_acc = nullptr; store.block_floats = 0;
+        FILM_TRY(hipMalloc((void **) &store.block_acc, floats * sizeof(float)));
+        store.block_floats = floats;
+    }
+    if (store.n_rank != nb) {
+        if (store.spiral_rank) (void) hipFree(store.spiral_rank);
+        store.spiral_rank = nullptr; store.n_rank = 0;
+        FILM_TRY(hipMalloc((void **) &store.spiral_rank, (size_t) nb * sizeof(uint32_t)));
+        store.n_rank = nb;
+    }
+    const std::vector<uint32_t> rank = spiral_ranks((int) bxn, (int) byn);       /* the frame size may have changed: cheap, recomputed per call */
+    FILM_TRY(hipMemcpyAsync(store.spiral_rank, rank.data(), (size_t) nb * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t) stream));
+    FILM_TRY(hipStreamSynchronize((hipStream_t) stream));                       /* `rank` is a host temporary */
+    FilmStore v = view; v.block_acc = store.block_acc; v.spiral_rank = store.spiral_rank;
+    hipLaunchKernelGGL(film_block_reference_kernel, dim3(nb), dim3(kB), 0, (hipStream_t) stream, w, h, sc.filter, d_filter_table, v, n_spp, tiles_x, bxn);
+    const int cols = w + 2 * border, rows = h + 2 * border;
+    hipLaunchKernelGGL(film_resolve_reference_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, (hipStream_t) stream, w, h, border, bxn, byn,
+                       (const float *) store.block_acc, (const uint32_t *) store.spiral_rank, d_rgbw);
+    FILM_TRY(hipGetLastError());
+    return std::string();
 }
 
 unsigned long long film_invalid_count(const FilmStore &st, void *stream) {

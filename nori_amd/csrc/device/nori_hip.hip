@@ -409,6 +409,7 @@ struct nori_hip_ctx {
     uint64_t lbvh_bytes = 0;
     int engine = -1;                /* -1 auto, 0 megakernel, 1 wavefront */
     int accel_layout = -1;          /* -1 auto (wide from 2^20 triangles), 0 bvh2, 1 bvh4q (wide nodes) */
+    bool film_reference = false;    /* film_order = reference: samples added in the reference's own order (film.h) */
     size_t wavefront_paths = (size_t) 1 << 28;     /* 240 B of state each (two copies) + film: ~80 GB of the 288 GB */
     /* render-time resources of THIS context (never shared, freed in nori_hip_destroy): the wavefront
        engine's state pool / streams / events and the film's sample store + tile accumulators */
@@ -588,6 +589,12 @@ int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value) {
         const long long n = atoll(value);
         if (n < 256) { ctx->error = "set_option: wavefront_paths must be >= 256"; return NORI_ERR_INVALID_ARGUMENT; }
         ctx->wavefront_paths = (size_t) n;
+        return NORI_OK;
+    }
+    if (k == "film_order") {
+        if (v == "fast") ctx->film_reference = false;
+        else if (v == "reference") ctx->film_reference = true;
+        else { ctx->error = "set_option: film_order must be fast or reference"; return NORI_ERR_INVALID_ARGUMENT; }
         return NORI_OK;
     }
     if (k == "accel_layout") {
@@ -875,6 +882,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         return NORI_ERR_UNSUPPORTED;
     }
     if (ctx->host.filter.border > 8) { ctx->error = "render: reconstruction filter radius too large for the LDS tile"; return NORI_ERR_UNSUPPORTED; }
+    if (ctx->film_reference && params->tile_mod != 1) { ctx->error = "render: film_order = reference renders whole frames (a block's samples are added consecutively)"; return NORI_ERR_UNSUPPORTED; }
     DeviceGuard g(ctx->device);
     hipStream_t s = (hipStream_t) params->stream;
 
@@ -936,8 +944,13 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         fl.tile_first = 0; fl.store_tile_first = 0; fl.n_tiles = a.n_sel_tiles; fl.tile_mod = 1; fl.tile_rem = 0;
         fl.tiles_x = a.tiles_x; fl.tiles_y = a.tiles_y; fl.tile_w = a.tile_w; fl.n_spp = a.spp_count;
         timer.begin(KC_FILM, s);
-        film_gather(ctx->dev, ctx->d_filter, film, fl, s);
-        film_resolve(ctx->dev, film, fl, (float *) d_rgbw, s);
+        if (ctx->film_reference) {
+            std::string rerr = film_reference_order(ctx->film, film, ctx->dev, ctx->d_filter, a.spp_count, a.tiles_x, (float *) d_rgbw, s);
+            if (!rerr.empty()) { ctx->error = rerr; return NORI_ERR_INTERNAL; }
+        } else {
+            film_gather(ctx->dev, ctx->d_filter, film, fl, s);
+            film_resolve(ctx->dev, film, fl, (float *) d_rgbw, s);
+        }
         timer.end(s);
         HIP_TRY(ctx, hipGetLastError());
         if (stats) n_invalid = film_invalid_count(film, s);
@@ -953,6 +966,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         wl.time_kernels = stats && params->time_kernels != 0;
         /* paths in flight: the option, bounded by what this GPU has free right now (state already held by
            this context counts as free) -- a second context or another process may own part of the HBM */
+        wl.film_reference = ctx->film_reference;
         wl.max_paths = ctx->wavefront_paths;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -971,6 +985,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         size_t cap = (size_t) 1 << 29;
         if (const char *e = getenv("NORI_HIP_FILM_SAMPLES")) cap = (size_t) std::max(256ll, atoll(e));
         const uint32_t spp_per_launch = (uint32_t) std::max<size_t>(1, std::min<size_t>(a.spp_count, cap / ((size_t) a.n_sel_tiles * 256)));
+        if (ctx->film_reference && spp_per_launch != a.spp_count) { ctx->error = "render: film_order = reference needs all samples of the frame in the film store at once"; return NORI_ERR_UNSUPPORTED; }
         FilmStore film;
         std::string ferr = film_prepare(ctx->film, (size_t) a.n_sel_tiles * 256 * spp_per_launch, a.n_sel_tiles, a.tile_w, s, film);
         if (!ferr.empty()) { ctx->error = ferr; return NORI_ERR_OUT_OF_MEMORY; }
@@ -994,12 +1009,15 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
             HIP_TRY(ctx, e);
             fl.n_spp = a2.spp_count;
             timer.begin(KC_FILM, s);
-            if (!(a.debug_flags & 1u)) film_gather(ctx->dev, ctx->d_filter, film, fl, s);
+            if (!(a.debug_flags & 1u) && !ctx->film_reference) film_gather(ctx->dev, ctx->d_filter, film, fl, s);
             timer.end(s);
             n_workgroups += a2.n_sel_tiles * a2.n_chunks;
         }
         timer.begin(KC_FILM, s);
-        film_resolve(ctx->dev, film, fl, (float *) d_rgbw, s);
+        if (ctx->film_reference) {
+            std::string rerr = film_reference_order(ctx->film, film, ctx->dev, ctx->d_filter, a.spp_count, a.tiles_x, (float *) d_rgbw, s);
+            if (!rerr.empty()) { ctx->error = rerr; return NORI_ERR_INTERNAL; }
+        } else film_resolve(ctx->dev, film, fl, (float *) d_rgbw, s);
         timer.end(s);
         HIP_TRY(ctx, hipGetLastError());
         if (stats) n_invalid = film_invalid_count(film, s);

@@ -17,6 +17,7 @@ struct WfLaunch {
     bool count_traversal;
     bool time_kernels;          /* HIP events around every launch (ktimer.h) */
     size_t max_paths;           /* paths in flight per batch */
+    bool film_reference;        /* add the samples in the reference's order (film.h): needs the whole frame in ONE batch */
 };
 
 struct WfStats {

@@ -699,6 +699,8 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
         need[k] = (size_t) P.tiles_b * 256 * P.spp_b;
         P.t0 = P.tile_lo; P.s0 = 0;
     }
+    if (L.film_reference && (n_pipes != 1 || pipes[0].tiles_b != L.n_sel_tiles || pipes[0].spp_b != L.spp_count || L.tile_mod != 1))
+        return "wavefront: film_order = reference needs the whole frame in one batch (tile_mod 1, wavefront_paths >= pixels x samples)";
     const size_t per_pipe = std::max(need[0], need[1]);
     const size_t records = state_capacity(per_pipe);            /* per pipe, per state copy */
     const int sh_grid = shade_grid(per_pipe);
@@ -835,7 +837,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             /* batch done: splat its samples (each pipe owns its tiles' accumulators) */
             fl.tile_first = P.bt.tile_first; fl.store_tile_first = P.bt.tile_first; fl.n_tiles = P.bt.n_tiles; fl.n_spp = P.bt.n_spp;
             timer.begin(KC_FILM, P.stream);
-            film_gather(sc, d_filter_table, P.film, fl, P.stream);
+            if (!L.film_reference) film_gather(sc, d_filter_table, P.film, fl, P.stream);
             timer.end(P.stream);
             stats.n_launches++;
             P.active = false;
@@ -853,7 +855,10 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             WF_TRY(hipStreamWaitEvent(s, g_events[k], 0));
         }
     timer.begin(KC_FILM, s);
-    film_resolve(sc, film, fl, d_rgbw, s);
+    if (L.film_reference) {
+        err = film_reference_order(film_store, film, sc, d_filter_table, L.spp_count, L.tiles_x, d_rgbw, s);
+        if (!err.empty()) return err;
+    } else film_resolve(sc, film, fl, d_rgbw, s);
     timer.end(s);
     stats.n_launches++;
     WF_TRY(hipGetLastError());

@@ -411,3 +411,56 @@ def test_nori_block_seeding_on_device(renderer_factory, integ, size, spp):
         r.render_host(seed_mode=capi.SEED_NORI_BLOCK, tile_mod=2)
     with pytest.raises(NoriError, match="UNSUPPORTED|whole frames"):
         r.render_host(seed_mode=capi.SEED_NORI_BLOCK, spp_begin=1, spp_count=2)
+
+
+@pytest.mark.parametrize("engine,integ,rf,size,spp", [("wavefront", "path_mis", "gaussian", (72, 40), 6), ("megakernel", "path_ems", "mitchell", (64, 64), 5),
+                                                      ("wavefront", "whitted", "tent", (33, 17), 4), ("megakernel", "normals", "box", (45, 37), 3)])
+def test_reference_film_order_gives_bit_identical_frames(renderer_factory, engine, integ, rf, size, spp):
+    """film_order = reference: the device adds the samples of a frame in the order of renderBlock / ImageBlock::put /
+    BlockGenerator (src/main.cpp:33-53, src/block.cpp:62-152).  With bit-identical radiance per camera sample the whole
+    RGBW frame -- every bit of every pixel, the W channel included -- equals a single-threaded render of the oracle;
+    frame sizes that are no multiple of the 32-pixel block or the 16-pixel tile included."""
+    from nori_amd import NoriError
+    sb = [Bsdf("mirror"), Bsdf("dielectric")] if integ in ("whitted", "path_mis") else [Bsdf("microfacet", (0.2, 0.3, 0.1), 0.2), Bsdf("diffuse")]
+    sc = scenes.cornell_box(size[0], size[1], spp, integ, sphere_bsdfs=sb, rfilter=RFilter(rf))
+    r, o = renderer_factory(sc), Oracle(sc, use_bvh=True)
+    r.set_option("engine", engine)
+    r.set_option("film_order", "reference")
+    A, sa = o.render_host(threads=1)
+    B, sb_ = r.render_host()
+    assert sa["n_closest_rays"] == sb_["n_closest_rays"] and sa["n_shadow_rays"] == sb_["n_shadow_rays"]
+    assert np.array_equal(A, B), f"{int((A != B).sum())} of {A.size} floats differ, max {np.abs(A - B).max():.3e}"
+    with pytest.raises(NoriError, match="UNSUPPORTED|whole frames"):
+        r.render_host(tile_mod=2)
+    r.set_option("film_order", "fast")
+    C_, _ = r.render_host()
+    np.testing.assert_allclose(C_, B, rtol=1e-4, atol=1e-5)            # same samples, the fast film's summation order
+
+
+def test_reference_film_order_with_the_reference_sampler(renderer_factory):
+    """Both compatibility modes together: the reference's sampler streams (one pcg32 stream per 32x32 block) and the
+    reference's film order -- the frame a single-threaded run of the reference's loops produces, bit for bit."""
+    from nori_amd import _capi as capi
+    sc = scenes.cornell_box(80, 48, 5, "path_mis", sphere_bsdfs=[Bsdf("mirror"), Bsdf("dielectric")])
+    r, o = renderer_factory(sc), Oracle(sc, use_bvh=True)
+    r.set_option("film_order", "reference")
+    A, _ = o.render_host(seed_mode=capi.SEED_NORI_BLOCK, threads=1)
+    B, _ = r.render_host(seed_mode=capi.SEED_NORI_BLOCK)
+    assert np.array_equal(A, B)
+
+
+def test_headline_geometry_frame_is_bit_identical_in_reference_order(renderer_factory):
+    """The headline workload's scene and full 1024 x 1024 frame (1,024 blocks of 32 x 32, 4,096 tiles), 2 samples per
+    pixel so that the single-threaded oracle finishes in seconds: wavefront engine + film_order = reference -> the RGBW
+    frame equals the oracle's bit for bit."""
+    import os
+    from nori_amd.scene import Scene
+    sc = Scene.load_npz(os.path.join(os.path.dirname(__file__), "golden", "pa4-cbox-path_mis.npz"))
+    sc.sample_count = 2
+    r, o = renderer_factory(sc), Oracle(sc, use_bvh=True)
+    r.set_option("engine", "wavefront")
+    r.set_option("film_order", "reference")
+    B, sb = r.render_host()
+    A, sa = o.render_host(threads=1)
+    assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
+    assert np.array_equal(A, B), f"{int((A != B).sum())} of {A.size} floats differ"
