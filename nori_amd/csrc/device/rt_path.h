@@ -77,9 +77,9 @@ NORI_HD bool sample_direct(const DevScene &sc, Rng &rng, const Surface &s, const
     uint32_t ei = (uint32_t) (xiE * (float) nE);
     if (ei > nE - 1) ei = nE - 1;
     const MeshRec &m = sc.meshes[sc.emitters[ei]];
-    const float pdfPick = 1.0f / (float) nE;
+    const float pdfPick = exact_rcp((float) nE);
     const uint32_t tri = cdf_sample(sc.emitter_cdf + m.cdf_offset, m.n_triangles, xiT);
-    const float su = sqrtf(1.0f - xi.x);
+    const float su = exact_sqrt(1.0f - xi.x);
     const float alpha = 1.0f - su, beta = xi.y * su;
     const float gamma = 1.0f - alpha - beta;
     const f4 *rec = sc.shade_tris + (size_t) (m.tri_offset + tri) * kShadeQuads;
@@ -92,7 +92,7 @@ NORI_HD bool sample_direct(const DevScene &sc, Rng &rng, const Surface &s, const
         n = normalized(cross(p1 - p0, p2 - p0));
     const f3 dvec = p - s.p;
     const float dist2 = dot(dvec, dvec);
-    const float dist = sqrtf(dist2);
+    const float dist = exact_sqrt(dist2);
     const f3 dir = dvec / dist;
     const float cosY = dot(n, -dir);
     if (!(cosY > 0.0f)) return false;
@@ -100,11 +100,11 @@ NORI_HD bool sample_direct(const DevScene &sc, Rng &rng, const Surface &s, const
     const f3 f = bsdf_eval(bsdf, wi, wo);
     if (is_zero(f)) return false;
     const float pdfA = m.inv_area * pdfPick;
-    out.pdf_em = pdfA * dist2 / cosY;
+    out.pdf_em = exact_div(pdfA * dist2, cosY);
     out.pdf_bsdf = bsdf_pdf(bsdf, wi, wo);
     const float cosX = wo.z;
     const f3 rad = mk3(m.radiance[0], m.radiance[1], m.radiance[2]);
-    out.Ld = f * rad * (cosX * cosY / (dist2 * pdfA));
+    out.Ld = f * rad * exact_div(cosX * cosY, dist2 * pdfA);
     out.dir = dir;
     out.maxt = dist - kEpsilon;
     return true;
@@ -137,11 +137,11 @@ NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, 
         const f3 lp = mk3(sc.integrator.position[0], sc.integrator.position[1], sc.integrator.position[2]);
         const f3 energy = mk3(sc.integrator.energy[0], sc.integrator.energy[1], sc.integrator.energy[2]);
         const f3 dvec = lp - sf.p;
-        const float dist2 = dot(dvec, dvec), dist = sqrtf(dist2);
+        const float dist2 = dot(dvec, dvec), dist = exact_sqrt(dist2);
         const f3 dir = dvec / dist;
         const float cosTheta = dot(sf.ns, dir);
         if (!(cosTheta > 0.0f)) return true;
-        st.Ld = energy * ((kInvPi * kInvPi * 0.25f) * cosTheta / dist2);
+        st.Ld = energy * exact_div((kInvPi * kInvPi * 0.25f) * cosTheta, dist2);
         st.ray.o = sf.p; st.ray.d = dir; st.ray.mint = kEpsilon; st.ray.maxt = dist;
         st.phase = PH_SHADOW; st.end_after_shadow = 1;
         return false;
@@ -185,10 +185,10 @@ NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, 
             float pdfEm = 0.0f;
             const float cosY = dot(sf.ns, -d);
             if (cosY > 0.0f) {
-                const float pdfA = m.inv_area / (float) sc.n_emitters;
-                pdfEm = pdfA * hit.t * hit.t / cosY;
+                const float pdfA = exact_div(m.inv_area, (float) sc.n_emitters);
+                pdfEm = exact_div(pdfA * hit.t * hit.t, cosY);
             }
-            wMat = (st.pdf_mat + pdfEm) > 0.0f ? st.pdf_mat / (st.pdf_mat + pdfEm) : 0.0f;
+            wMat = (st.pdf_mat + pdfEm) > 0.0f ? exact_div(st.pdf_mat, st.pdf_mat + pdfEm) : 0.0f;
         }
     }
     if (emitter && wMat > 0.0f) {
@@ -206,7 +206,7 @@ NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, 
         needShadow = sample_direct(sc, st.rng, sf, fr, bsdf, wi, nee);
         if (needShadow) {
             float w = 1.0f;
-            if (MIS) w = (nee.pdf_em + nee.pdf_bsdf) > 0.0f ? nee.pdf_em / (nee.pdf_em + nee.pdf_bsdf) : 0.0f;
+            if (MIS) w = (nee.pdf_em + nee.pdf_bsdf) > 0.0f ? exact_div(nee.pdf_em, nee.pdf_em + nee.pdf_bsdf) : 0.0f;
             st.Ld = st.T * nee.Ld * w;
         }
     }

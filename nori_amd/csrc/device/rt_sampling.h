@@ -55,7 +55,7 @@ NORI_HD f2 rng_next_2d(Rng &r) {
 
 /* ------------------------------------------------------------------ warps */
 NORI_HD float warp_tent_1d(float xi) {
-    return xi < 0.5f ? sqrtf(2.0f * xi) - 1.0f : 1.0f - sqrtf(2.0f - 2.0f * xi);
+    return xi < 0.5f ? exact_sqrt(2.0f * xi) - 1.0f : 1.0f - exact_sqrt(2.0f - 2.0f * xi);
 }
 NORI_HD f2 square_to_tent(f2 s) { return mk2(warp_tent_1d(s.x), warp_tent_1d(s.y)); }
 NORI_HD float square_to_tent_pdf(f2 p) {
@@ -64,7 +64,7 @@ NORI_HD float square_to_tent_pdf(f2 p) {
     return (1.0f - ax) * (1.0f - ay);
 }
 NORI_HD f2 square_to_uniform_disk(f2 s) {
-    float r = sqrtf(s.x);
+    float r = exact_sqrt(s.x);
     float sp, cp;
     det_sincosf(2.0f * kPi * s.y, &sp, &cp);
     return mk2(r * cp, r * sp);
@@ -74,21 +74,21 @@ NORI_HD float square_to_uniform_disk_pdf(f2 p) {
 }
 NORI_HD f3 square_to_uniform_sphere(f2 s) {
     float z = 1.0f - 2.0f * s.x;
-    float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float r = exact_sqrt(fmaxf(0.0f, 1.0f - z * z));
     float sp, cp;
     det_sincosf(2.0f * kPi * s.y, &sp, &cp);
     return mk3(r * cp, r * sp, z);
 }
 NORI_HD f3 square_to_uniform_hemisphere(f2 s) {
     float z = s.x;
-    float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float r = exact_sqrt(fmaxf(0.0f, 1.0f - z * z));
     float sp, cp;
     det_sincosf(2.0f * kPi * s.y, &sp, &cp);
     return mk3(r * cp, r * sp, z);
 }
 NORI_HD f3 square_to_cosine_hemisphere(f2 s) {
     f2 d = square_to_uniform_disk(s);
-    float z = sqrtf(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
+    float z = exact_sqrt(fmaxf(0.0f, 1.0f - d.x * d.x - d.y * d.y));
     return mk3(d.x, d.y, z);
 }
 NORI_HD float square_to_cosine_hemisphere_pdf(f3 v) { return v.z > 0.0f ? v.z * kInvPi : 0.0f; }
@@ -96,16 +96,16 @@ NORI_HD f3 square_to_beckmann(f2 s, float alpha) {
     float sp, cp;
     det_sincosf(2.0f * kPi * s.x, &sp, &cp);
     float tan2 = -alpha * alpha * det_logf(1.0f - s.y);
-    float cosTheta = 1.0f / sqrtf(1.0f + tan2);
-    float sinTheta = sqrtf(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
+    float cosTheta = exact_rcp(exact_sqrt(1.0f + tan2));
+    float sinTheta = exact_sqrt(fmaxf(0.0f, 1.0f - cosTheta * cosTheta));
     return mk3(sinTheta * cp, sinTheta * sp, cosTheta);
 }
 NORI_HD float square_to_beckmann_pdf(f3 m, float alpha) {
     if (m.z <= 0.0f) return 0.0f;
     float cos2 = m.z * m.z;
-    float tan2 = (1.0f - cos2) / cos2;
+    float tan2 = exact_div(1.0f - cos2, cos2);
     float a2 = alpha * alpha;
-    return det_expf(-tan2 / a2) / (kPi * a2 * cos2 * m.z);
+    return det_expf(exact_div(-tan2, a2)) / (kPi * a2 * cos2 * m.z);      /* plain division: the numerator reaches the denormals */
 }
 
 NORI_HD f3 warp_dispatch(int warp, float param, f2 s) {
@@ -139,11 +139,11 @@ NORI_HD float fresnel(float cosThetaI, float extIOR, float intIOR) {
         float tmp = etaI; etaI = etaT; etaT = tmp;
         cosThetaI = -cosThetaI;
     }
-    float eta = etaI / etaT, sinThetaTSqr = eta * eta * (1.0f - cosThetaI * cosThetaI);
+    float eta = exact_div(etaI, etaT), sinThetaTSqr = eta * eta * (1.0f - cosThetaI * cosThetaI);
     if (sinThetaTSqr > 1.0f) return 1.0f;
-    float cosThetaT = sqrtf(1.0f - sinThetaTSqr);
-    float Rs = (etaI * cosThetaI - etaT * cosThetaT) / (etaI * cosThetaI + etaT * cosThetaT);
-    float Rp = (etaT * cosThetaI - etaI * cosThetaT) / (etaT * cosThetaI + etaI * cosThetaT);
+    float cosThetaT = exact_sqrt(1.0f - sinThetaTSqr);
+    float Rs = exact_div(etaI * cosThetaI - etaT * cosThetaT, etaI * cosThetaI + etaT * cosThetaT);
+    float Rp = exact_div(etaT * cosThetaI - etaI * cosThetaT, etaT * cosThetaI + etaI * cosThetaT);
     return (Rs * Rs + Rp * Rp) / 2.0f;
 }
 
@@ -165,7 +165,7 @@ NORI_HD bool bsdf_is_diffuse(int32_t type) { return type == 0 || type == 3; }
 NORI_HD float frame_tan_theta(f3 v) {   /* include/nori/frame.h:68-73 */
     float temp = 1.0f - v.z * v.z;
     if (temp <= 0.0f) return 0.0f;
-    return sqrtf(temp) / v.z;
+    return exact_div(exact_sqrt(temp), v.z);
 }
 
 /* Beckmann shadowing-masking, rational approximation */
@@ -173,10 +173,10 @@ NORI_HD float microfacet_g1(f3 wv, f3 wh, float alpha) {
     if (dot(wv, wh) / wv.z <= 0.0f) return 0.0f;
     float tanTheta = frame_tan_theta(wv);
     if (tanTheta == 0.0f) return 1.0f;
-    float b = 1.0f / (alpha * tanTheta);
+    float b = exact_rcp(alpha * tanTheta);
     if (b >= 1.6f) return 1.0f;
     float b2 = b * b;
-    return (3.535f * b + 2.181f * b2) / (1.0f + 2.276f * b + 2.577f * b2);
+    return exact_div(3.535f * b + 2.181f * b2, 1.0f + 2.276f * b + 2.577f * b2);
 }
 
 /* BSDF::eval for measure == ESolidAngle */
@@ -206,7 +206,7 @@ NORI_HD float bsdf_pdf(const Bsdf &b, f3 wi, f3 wo) {
         if (wi.z <= 0.0f || wo.z <= 0.0f) return 0.0f;
         f3 wh = normalized(wi + wo);
         float D = square_to_beckmann_pdf(wh, b.alpha);
-        float Jh = 1.0f / (4.0f * dot(wh, wo));
+        float Jh = exact_rcp(4.0f * dot(wh, wo));
         return b.ks * D * Jh + (1.0f - b.ks) * wo.z * kInvPi;
     }
     return 0.0f;
@@ -237,26 +237,26 @@ NORI_HD f3 bsdf_sample(const Bsdf &b, f3 wi, f2 s, f3 &wo, float &eta, int &meas
         bool entering = cosThetaI > 0.0f;
         float etaI = entering ? b.ext_ior : b.int_ior;
         float etaT = entering ? b.int_ior : b.ext_ior;
-        float e = etaI / etaT;
+        float e = exact_div(etaI, etaT);
         float sinThetaTSqr = e * e * (1.0f - cosThetaI * cosThetaI);
-        float cosThetaT = sqrtf(fmaxf(0.0f, 1.0f - sinThetaTSqr));
+        float cosThetaT = exact_sqrt(fmaxf(0.0f, 1.0f - sinThetaTSqr));
         wo = mk3(-e * wi.x, -e * wi.y, entering ? -cosThetaT : cosThetaT);
-        eta = etaT / etaI;
+        eta = exact_div(etaT, etaI);
         return mk3(1.0f);
     }
     default: {
         if (wi.z <= 0.0f) return mk3(0.0f);
         measure = 1;
         if (s.x < b.ks) {
-            f3 n = square_to_beckmann(mk2(s.x / b.ks, s.y), b.alpha);
+            f3 n = square_to_beckmann(mk2(exact_div(s.x, b.ks), s.y), b.alpha);
             wo = 2.0f * dot(wi, n) * n - wi;
         } else {
-            wo = square_to_cosine_hemisphere(mk2((s.x - b.ks) / (1.0f - b.ks), s.y));
+            wo = square_to_cosine_hemisphere(mk2(exact_div(s.x - b.ks, 1.0f - b.ks), s.y));
         }
         if (wo.z <= 0.0f) return mk3(0.0f);
         float p = bsdf_pdf(b, wi, wo);
         if (!(p > 0.0f)) return mk3(0.0f);
-        return bsdf_eval(b, wi, wo) * wo.z / p;
+        return div_ieee(bsdf_eval(b, wi, wo) * wo.z, p);      /* plain division: with kd = 0 the numerator reaches the denormals */
     }
     }
 }

@@ -23,21 +23,9 @@ struct RayIn {
     float mint, maxt;
 };
 
-/* 1.0f / x, correctly rounded, in 3 instructions instead of the compiler's ~11 (v_div_scale x2, v_rcp, 4 fma, v_div_fmas,
- * v_div_fixup): r0 = v_rcp_f32(x) (1 ulp), then one Newton step r0 + r0 (1 - x r0) with two fused multiply-adds.  Verified
- * EXHAUSTIVELY on gfx950 against the IEEE quotient over all 2^32 floats (tools/ubench_recip.hip, result in
- * profiles/r2_exact_rcp.txt): identical for every x whose reciprocal is a normal number; the exceptions are the denormal x
- * and |x| > 2^126.  No fallback branch (it costs the traversal kernel its last free registers): a determinant beyond
- * 8.5e37 needs scene coordinates beyond 1e12, and a denormal one is rejected by |det| < 1e-8 before its reciprocal is used
- * (src/mesh.cpp:52).  The CPU twins use the plain division. */
-NORI_HD float exact_rcp(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const float r0 = __builtin_amdgcn_rcpf(x);
-    return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
-#else
-    return 1.0f / x;
-#endif
-}
+/* exact_rcp (rt_types.h): no fallback branch for the operands outside its domain (it costs the traversal kernel its last
+ * free registers): a determinant beyond 8.5e37 needs scene coordinates beyond 1e12, and a denormal one is rejected by
+ * |det| < 1e-8 before its reciprocal is used (src/mesh.cpp:52). */
 
 /* Reciprocal direction for the slab tests.  A zero (or denormal) component maps to +-2^60: huge, so that (plane - o) * rcp
  * is astronomically far off the plane and exactly 0 on it -- the containment rule of bbox.h:331-333 (boundary inclusive)
@@ -382,7 +370,7 @@ NORI_HD f3 mat_point(const float *m, f3 p) {
     float r[4];
     for (int i = 0; i < 4; ++i)
         r[i] = ((m[4 * i] * p.x + m[4 * i + 1] * p.y) + m[4 * i + 2] * p.z) + m[4 * i + 3] * 1.0f;
-    return mk3(r[0] / r[3], r[1] / r[3], r[2] / r[3]);
+    return mk3(r[0], r[1], r[2]) / r[3];
 }
 NORI_HD f3 mat_vector(const float *m, f3 v) {
     return mk3(m[0] * v.x + (m[1] * v.y + m[2] * v.z),
@@ -392,7 +380,7 @@ NORI_HD f3 mat_vector(const float *m, f3 v) {
 NORI_HD void camera_sample_ray(const CameraRec &cam, f2 samplePosition, RayIn &ray) {
     f3 nearP = mat_point(cam.sample_to_camera, mk3(samplePosition.x * cam.inv_w, samplePosition.y * cam.inv_h, 0.0f));
     f3 d = normalized(nearP);
-    float invZ = 1.0f / d.z;
+    float invZ = exact_rcp(d.z);
     ray.o = mat_point(cam.camera_to_world, mk3(0.0f, 0.0f, 0.0f));
     ray.d = mat_vector(cam.camera_to_world, d);
     ray.mint = cam.near_clip * invZ;

@@ -40,6 +40,59 @@ struct alignas(16) f4 { float x, y, z, w; };
 NORI_HD uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
 NORI_HD float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 
+/* ---- IEEE-correct reciprocal, quotient and square root in fewer instructions than the compiler's expansions.
+ *
+ * hipcc expands a / b into v_div_scale x2, v_rcp, 5 fma, v_div_fmas, v_div_fixup plus VCC hazard nops (~13 issue slots,
+ * ~47 cycles per wave64) and sqrtf(x) into 16 instructions + 4 nops: both carry scaling for operands near the ends of the
+ * exponent range and fix-ups for inf / NaN / 0.  A path vertex of the render loop divides ~22 times and takes ~6 square
+ * roots: a third of wf_shade's instructions.  The forms below give the SAME bits as the IEEE operations on the domain
+ * stated with each (checked on gfx950: tools/ubench_recip.hip exhaustively, tools/ubench_divsqrt.hip exhaustively for the
+ * square root and on 2^36 pairs -- exponents of both operands within +-60, hard mantissa patterns included -- for the
+ * quotient; results in profiles/r2_exact_rcp.txt and profiles/r2_exact_div_sqrt.txt), and the render path's operands
+ * -- lengths, cosines, pdfs, areas of scenes whose unit is not 1e-15 of their size -- lie well inside it.  The CPU twins
+ * (emulation harness, host code) use the plain operators.
+ *
+ *   exact_rcp(x)    = 1.0f / x   for 2^-126 <= |x| < 2^126: r0 = v_rcp_f32(x) (1 ulp), one Newton step with two fma.
+ *   exact_div(a, b) = a / b      y = exact_rcp(b) is the correctly rounded reciprocal, q = a y is within 2 ulp, the
+ *                                residual r = a - b q is exact (fma), and RN(q + r y) is the correctly rounded quotient
+ *                                (Markstein 1990).  Domain: b as for exact_rcp; a = 0, or a and a / b normal numbers with
+ *                                |a| >= 2^-100 (so that r does not underflow).  Three numerators over one denominator
+ *                                (a vector / its length) share y: 12 instructions instead of 39.
+ *   exact_sqrt(x)   = sqrtf(x)   s = v_sqrt_f32(x) (1 ulp); the residuals x - (s -+ 1 ulp) s, exact in one fma each,
+ *                                say whether a neighbour is the correctly rounded root (the compiler's own correction
+ *                                step without its scaling).  Domain: x = 0, +inf, or x >= 2^-104 (below that the residuals
+ *                                underflow; the exhaustive run finds its first mismatch at 2^-105). */
+NORI_HD float exact_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r0, 1.0f), r0, r0);
+#else
+    return 1.0f / x;
+#endif
+}
+NORI_HD float exact_div_by(float a, float b, float rcp_b) {      /* rcp_b = exact_rcp(b) */
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float q = a * rcp_b;
+    return __builtin_fmaf(__builtin_fmaf(-b, q, a), rcp_b, q);
+#else
+    (void) rcp_b;
+    return a / b;
+#endif
+}
+NORI_HD float exact_div(float a, float b) { return exact_div_by(a, b, exact_rcp(b)); }
+NORI_HD float exact_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = u2f(f2u(s) - 1u), hi = u2f(f2u(s) + 1u);
+    const float r_lo = __builtin_fmaf(-lo, s, x), r_hi = __builtin_fmaf(-hi, s, x);
+    float r = r_lo <= 0.0f ? lo : s;
+    r = r_hi > 0.0f ? hi : r;
+    return r;
+#else
+    return sqrtf(x);
+#endif
+}
+
 NORI_HD f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
 NORI_HD f3 mk3(float v) { return mk3(v, v, v); }
 NORI_HD f2 mk2(float x, float y) { f2 r; r.x = x; r.y = y; return r; }
@@ -49,14 +102,15 @@ NORI_HD f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
 NORI_HD f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
 NORI_HD f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
 NORI_HD f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
-NORI_HD f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+NORI_HD f3 operator/(f3 a, float s) { const float y = exact_rcp(s); return mk3(exact_div_by(a.x, s, y), exact_div_by(a.y, s, y), exact_div_by(a.z, s, y)); }
+NORI_HD f3 div_ieee(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }      /* the compiler's full-range division */
 NORI_HD float dot(f3 a, f3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
 NORI_HD f3 cross(f3 a, f3 b) {
     return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 NORI_HD f3 normalized(f3 a) {
     float z = dot(a, a);
-    if (z > 0.0f) return a / sqrtf(z);
+    if (z > 0.0f) return a / exact_sqrt(z);
     return a;
 }
 NORI_HD float max3(f3 a) { return fmaxf(a.x, fmaxf(a.y, a.z)); }
@@ -72,10 +126,10 @@ NORI_HD bool color_valid(f3 c) {
 /* src/common.cpp:248-257 */
 NORI_HD void coordinate_system(f3 a, f3 &b, f3 &c) {
     if (fabsf(a.x) > fabsf(a.y)) {
-        float invLen = 1.0f / sqrtf(a.x * a.x + a.z * a.z);
+        float invLen = exact_rcp(exact_sqrt(a.x * a.x + a.z * a.z));
         c = mk3(a.z * invLen, 0.0f, -a.x * invLen);
     } else {
-        float invLen = 1.0f / sqrtf(a.y * a.y + a.z * a.z);
+        float invLen = exact_rcp(exact_sqrt(a.y * a.y + a.z * a.z));
         c = mk3(0.0f, a.z * invLen, -a.y * invLen);
     }
     b = cross(c, a);
