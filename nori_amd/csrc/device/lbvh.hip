@@ -46,7 +46,7 @@
 #include <string>
 
 #include "lbvh.h"
-#include "rt_wide.h"
+#include "lbvh_steps.h"
 
 using namespace nrt;
 
@@ -61,11 +61,7 @@ __host__ __device__ __forceinline__ float key_float(unsigned int k) {
     return __builtin_bit_cast(float, u);
 }
 
-__device__ __forceinline__ void tri_box(const f4 *pos, const uint32_t *idx, uint32_t t, f3 &mn, f3 &mx) {
-    const f3 a = xyz(pos[idx[3 * (size_t) t]]), b = xyz(pos[idx[3 * (size_t) t + 1]]), c = xyz(pos[idx[3 * (size_t) t + 2]]);
-    mn = mk3(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
-    mx = mk3(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
-}
+/* The kernels are one thread per element over the steps of lbvh_steps.h (which the CPU harness runs as loops). */
 
 __global__ void k_scene_bounds(const f4 *pos, const uint32_t *idx, uint32_t n, unsigned int *bounds) {
     __shared__ unsigned int s[6];
@@ -81,177 +77,83 @@ __global__ void k_scene_bounds(const f4 *pos, const uint32_t *idx, uint32_t n, u
     else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s[threadIdx.x]);
 }
 
-/* spread the low 21 bits of v to every third bit */
-__device__ __forceinline__ unsigned long long expand21(unsigned long long v) {
-    v &= 0x1fffffull;
-    v = (v | (v << 32)) & 0x001f00000000ffffull;
-    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
-    v = (v | (v << 8)) & 0x100f00f00f00f00full;
-    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
-    v = (v | (v << 2)) & 0x1249249249249249ull;
-    return v;
-}
-
-/* 63-bit Morton code of the triangle's box centre (21 bits per axis: a 2M^3 grid keeps the
-   triangles of multi-million-triangle meshes in distinct cells; with 10 bits per axis whole
-   clusters shared a code and were split in index order) */
 __global__ void k_morton(const f4 *pos, const uint32_t *idx, uint32_t n, f3 smin, f3 sinv, unsigned long long *keys, uint32_t *vals) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    f3 mn, mx; tri_box(pos, idx, t, mn, mx);
-    {   /* numerically collinear triangles (rt_types.h, tri_box_pad) sort behind everything else: bit 63 makes
-           the root split them from the spatial hierarchy */
-        const f3 p0 = xyz(pos[idx[3 * (size_t) t]]), p1 = xyz(pos[idx[3 * (size_t) t + 1]]), p2 = xyz(pos[idx[3 * (size_t) t + 2]]);
-        bool unbounded;
-        (void) tri_box_pad(p1 - p0, p2 - p0, 0.0f, unbounded);
-        if (unbounded) { keys[t] = 0x8000000000000000ull; vals[t] = t; return; }
-    }
-    const float cx = (0.5f * (mn.x + mx.x) - smin.x) * sinv.x, cy = (0.5f * (mn.y + mx.y) - smin.y) * sinv.y,
-                cz = (0.5f * (mn.z + mx.z) - smin.z) * sinv.z;
-    const float S = 2097152.0f, M = 2097151.0f;
-    const unsigned long long ix = (unsigned long long) fminf(fmaxf(cx * S, 0.0f), M);
-    const unsigned long long iy = (unsigned long long) fminf(fmaxf(cy * S, 0.0f), M);
-    const unsigned long long iz = (unsigned long long) fminf(fmaxf(cz * S, 0.0f), M);
-    keys[t] = (expand21(ix) << 2) | (expand21(iy) << 1) | expand21(iz);
     vals[t] = t;
-}
-
-/* internal node i: children (bit 31 set = leaf primitive position), key range, parent links */
-struct RadixNode { uint32_t left, right, lo, hi; };
-constexpr uint32_t kLeafBit = 0x80000000u;
-
-/* common-prefix length of the (key, position) pairs i and j: equal codes are told apart by their
-   position in the sorted order, so every pair has a distinct prefix length */
-__device__ __forceinline__ int delta(const unsigned long long *keys, int n, int i, int j) {
-    if (j < 0 || j >= n) return -1;
-    const unsigned long long x = keys[i] ^ keys[j];
-    return x ? __clzll((long long) x) : 64 + __clz(i ^ j);
+    /* numerically collinear triangles (rt_types.h, tri_box_pad) sort behind everything else: bit 63 makes
+       the root split them from the spatial hierarchy */
+    if (tri_unbounded(pos, idx, t)) { keys[t] = 0x8000000000000000ull; return; }
+    f3 mn, mx; tri_box(pos, idx, t, mn, mx);
+    keys[t] = morton63(mn, mx, smin, sinv);
 }
 
 __global__ void k_hierarchy(const unsigned long long *keys, int n, RadixNode *nodes, uint32_t *parent_inner, uint32_t *parent_leaf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
-    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
-    const int dmin = delta(keys, n, i, i - d);
-    int lmax = 2;
-    while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
-    int l = 0;
-    for (int t = lmax >> 1; t >= 1; t >>= 1)
-        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
-    const int j = i + l * d;
-    const int dnode = delta(keys, n, i, j);
-    int s = 0;
-    for (int t = (l + 1) >> 1; ; t = (t + 1) >> 1) {
-        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
-        if (t <= 1) break;
-    }
-    const int gamma = i + s * d + min(d, 0);
-    const int lo = min(i, j), hi = max(i, j);
-    RadixNode nd;
-    nd.lo = (uint32_t) lo; nd.hi = (uint32_t) hi;
-    if (lo == gamma) { nd.left = kLeafBit | (uint32_t) gamma; parent_leaf[gamma] = (uint32_t) i; }
-    else { nd.left = (uint32_t) gamma; parent_inner[gamma] = (uint32_t) i; }
-    if (hi == gamma + 1) { nd.right = kLeafBit | (uint32_t) (gamma + 1); parent_leaf[gamma + 1] = (uint32_t) i; }
-    else { nd.right = (uint32_t) (gamma + 1); parent_inner[gamma + 1] = (uint32_t) i; }
-    nodes[i] = nd;
-    if (i == 0) parent_inner[0] = 0xffffffffu;
+    nodes[i] = radix_node(keys, n, i, parent_inner, parent_leaf);
 }
 
-/* segment tree over the sorted, padded triangle boxes: entries [N + k] */
-__global__ void k_leaf_boxes(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, uint32_t N, float pad0,
-                             f3 smin, f3 smax, f4 *tmin, f4 *tmax) {
+/* ---- PLOC ---- */
+__global__ void k_ploc_init(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, float pad0, PlocClusters c) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    f4 mn, mx; tri_leaf_box(pos, idx, order[k], pad0, mn, mx);
+    mn.w = __uint_as_float(kLeafBit | k); mx.w = __uint_as_float(1u);
+    c.mn[k] = mn; c.mx[k] = mx;
+}
+__global__ void k_ploc_nearest(PlocClusters c, uint32_t m, uint32_t radius, uint32_t *nearest) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) nearest[i] = ploc_nearest(c, m, i, radius);
+}
+/* flags for ONE scan: stays in the low word, lead in the high word */
+__global__ void k_ploc_decide(const uint32_t *nearest, uint32_t m, unsigned long long *flags) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    uint32_t lead, stays; ploc_decide(nearest, i, lead, stays);
+    flags[i] = (unsigned long long) stays | ((unsigned long long) lead << 32);
+}
+__global__ void k_ploc_apply(PlocClusters in, PlocClusters out, PlocNodes nodes, const uint32_t *nearest, uint32_t m,
+                             const unsigned long long *flags, const unsigned long long *incl, uint32_t node_base) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const unsigned long long f = flags[i], r = incl[i] - f;      /* exclusive ranks */
+    ploc_apply(in, out, nodes, nearest, i, (uint32_t) (f >> 32), (uint32_t) f & 1u, (uint32_t) (r >> 32), (uint32_t) r, node_base);
+}
+__global__ void k_ploc_leaf_positions(PlocNodes nodes, uint32_t n, const uint32_t *order, uint32_t *leaf_pos, uint32_t *order_out) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t p = ploc_first_position(nodes, n - 1u, kLeafBit | k);
+    leaf_pos[k] = p; order_out[p] = order[k];
+}
+__global__ void k_ploc_finish(PlocNodes nodes, uint32_t n_nodes, const uint32_t *leaf_pos, RadixNode *out, uint32_t *parent_inner, uint32_t *parent_leaf) {
+    const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_nodes) return;
+    out[n_nodes - 1u - id] = ploc_finish(nodes, n_nodes, id, leaf_pos, parent_inner, parent_leaf);
+}
+
+/* segment tree over the padded triangle boxes in the builder's order: entries [N + k] */
+__global__ void k_leaf_boxes(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, uint32_t N, float pad0, f4 *tmin, f4 *tmax) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     f4 mn4, mx4;
-    if (k < n) {
-        const uint32_t g = order[k];
-        f3 mn, mx; tri_box(pos, idx, g, mn, mx);
-        const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
-        bool unbounded;
-        const float pad = tri_box_pad(p1 - p0, p2 - p0, pad0, unbounded);      /* slivers: rt_types.h */
-        if (unbounded) { mn = mk3(-kBoxInf); mx = mk3(kBoxInf); }
-        mn4.x = mn.x - pad; mn4.y = mn.y - pad; mn4.z = mn.z - pad; mx4.x = mx.x + pad; mx4.y = mx.y + pad; mx4.z = mx.z + pad;
-    } else {
-        mn4.x = mn4.y = mn4.z = kInf; mx4.x = mx4.y = mx4.z = -kInf;
-    }
-    mn4.w = mx4.w = 0.0f;
+    if (k < n) tri_leaf_box(pos, idx, order[k], pad0, mn4, mx4);
+    else { mn4.x = mn4.y = mn4.z = kInf; mx4.x = mx4.y = mx4.z = -kInf; mn4.w = mx4.w = 0.0f; }
     tmin[N + k] = mn4; tmax[N + k] = mx4;
 }
-
 __global__ void k_tree_level(uint32_t first, uint32_t count, f4 *tmin, f4 *tmax) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= count) return;
-    const uint32_t i = first + k;
-    const f4 a = tmin[2 * i], b = tmin[2 * i + 1], c = tmax[2 * i], d = tmax[2 * i + 1];
-    f4 mn, mx;
-    mn.x = fminf(a.x, b.x); mn.y = fminf(a.y, b.y); mn.z = fminf(a.z, b.z); mn.w = 0.0f;
-    mx.x = fmaxf(c.x, d.x); mx.y = fmaxf(c.y, d.y); mx.z = fmaxf(c.z, d.z); mx.w = 0.0f;
-    tmin[i] = mn; tmax[i] = mx;
-}
-
-__device__ __forceinline__ void range_box(const f4 *tmin, const f4 *tmax, uint32_t N, uint32_t lo, uint32_t hi, f3 &mn, f3 &mx) {
-    mn = mk3(kInf); mx = mk3(-kInf);
-    uint32_t l = lo + N, r = hi + N + 1;
-    while (l < r) {
-        if (l & 1u) { const f4 a = tmin[l], b = tmax[l]; ++l;
-            mn = mk3(fminf(mn.x, a.x), fminf(mn.y, a.y), fminf(mn.z, a.z)); mx = mk3(fmaxf(mx.x, b.x), fmaxf(mx.y, b.y), fmaxf(mx.z, b.z)); }
-        if (r & 1u) { --r; const f4 a = tmin[r], b = tmax[r];
-            mn = mk3(fminf(mn.x, a.x), fminf(mn.y, a.y), fminf(mn.z, a.z)); mx = mk3(fmaxf(mx.x, b.x), fmaxf(mx.y, b.y), fmaxf(mx.z, b.z)); }
-        l >>= 1; r >>= 1;
-    }
-}
-
-/* A subtree of <= 4 triangles (contiguous in sorted order) can become ONE leaf (its triangles stored as
-   pairs, rt_types.h) or stay split.  k_collapse decides per radix node with the surface-area heuristic:
-       leaf : A(node) * pairs * Cpair          split : A(node) * Cnode + best(left) + best(right)
-   (a leaf step tests a pair of triangles, 1.5 - 2.5x the work of a node step).  collapse[i] = 1: node i is a
-   leaf wherever it is reached.  Nodes above 4 triangles are always inner nodes. */
-struct CollapseParams { float c_pair, c_node; };
-
-__device__ __forceinline__ float box_area(f3 mn, f3 mx) {
-    const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
-    return 2.0f * (dx * dy + dy * dz + dz * dx);
-}
-
-__device__ float best_cost(const RadixNode *nodes, const f4 *tmin, const f4 *tmax, uint32_t N, uint32_t child, CollapseParams cp, bool *collapse_out) {
-    f3 mn, mx;
-    if (child & kLeafBit) {
-        const uint32_t k = child & ~kLeafBit;
-        range_box(tmin, tmax, N, k, k, mn, mx);
-        return box_area(mn, mx) * cp.c_pair;
-    }
-    const RadixNode nd = nodes[child];
-    range_box(tmin, tmax, N, nd.lo, nd.hi, mn, mx);
-    const float area = box_area(mn, mx);
-    const float leaf = area * (float) ((nd.hi - nd.lo + 2u) / 2u) * cp.c_pair;
-    const float split = area * cp.c_node + best_cost(nodes, tmin, tmax, N, nd.left, cp, nullptr) + best_cost(nodes, tmin, tmax, N, nd.right, cp, nullptr);
-    if (collapse_out) *collapse_out = leaf <= split;
-    return fminf(leaf, split);
+    if (k < count) seg_tree_combine(first + k, tmin, tmax);
 }
 
 __global__ void k_collapse(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N, CollapseParams cp, uint32_t *collapse) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_inner) return;
-    const RadixNode nd = nodes[i];
-    bool c = false;
-    if (nd.hi - nd.lo + 1 <= 4u) (void) best_cost(nodes, tmin, tmax, N, i, cp, &c);      /* subtree of <= 3 inner nodes */
-    collapse[i] = c ? 1u : 0u;
+    if (i < n_inner) collapse[i] = collapse_decide(nodes, i, tmin, tmax, N, cp);
 }
-
-/* is `child` a leaf (primitive or collapsed subtree)?  [lo, hi] = its sorted range */
-__device__ __forceinline__ bool child_range(const RadixNode *nodes, const uint32_t *collapse, uint32_t child, uint32_t &lo, uint32_t &hi) {
-    if (child & kLeafBit) { lo = hi = child & ~kLeafBit; return true; }
-    lo = nodes[child].lo; hi = nodes[child].hi;
-    return collapse[child] != 0u;
-}
-
-/* the first pair of the leaf starting at sorted position lo is pair_start[lo] (exclusive scan of the
-   per-leaf pair counts) */
-__device__ __forceinline__ int32_t child_link(const RadixNode *nodes, const uint32_t *collapse, const uint32_t *pair_start, const uint32_t *node_index,
-                                              uint32_t child, uint32_t &lo, uint32_t &hi, uint32_t pair_base = 0u) {
-    if (!child_range(nodes, collapse, child, lo, hi)) return (int32_t) node_index[child];
-    const uint32_t cnt = hi - lo + 1;
-    return (int32_t) ~(((pair_start[lo] + pair_base) << 3) | ((cnt + 1u) / 2u - 1u));
+__global__ void k_mark_leaves(const RadixNode *nodes, uint32_t n_inner, const uint32_t *collapse, const uint32_t *parent_inner,
+                              uint32_t *leaf_cnt, uint32_t *leaf_pairs, uint32_t *keep) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_inner) keep[i] = mark_leaves(nodes, i, collapse, parent_inner, leaf_cnt, leaf_pairs);
 }
 
 /* ---- WIDE emission ---- */
@@ -262,23 +164,8 @@ __global__ void k_wide_expand(const RadixNode *nodes, const uint32_t *collapse, 
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= count) return;
     const uint32_t i = frontier[t];
-    const RadixNode nd = nodes[i];
-    uint32_t kid[4] = {nd.left, nd.right, 0u, 0u};
-    int n = 2;
-    while (n < 4) {
-        int best = -1; float bestArea = -1.0f;
-        for (int k = 0; k < n; ++k) {
-            uint32_t lo, hi;
-            if (child_range(nodes, collapse, kid[k], lo, hi)) continue;      /* a leaf stays */
-            f3 mn, mx; range_box(tmin, tmax, N, lo, hi, mn, mx);
-            float a = box_area(mn, mx);
-            if (!(a < kInf)) a = kInf;                                        /* unbounded subtree first */
-            if (a > bestArea) { bestArea = a; best = k; }
-        }
-        if (best < 0) break;
-        const RadixNode c = nodes[kid[best]];
-        kid[best] = c.left; kid[n++] = c.right;
-    }
+    uint32_t kid[4];
+    const int n = wide_children(nodes, collapse, tmin, tmax, N, i, kid);
     n_kids[i] = (uint32_t) n;
     for (int k = 0; k < n; ++k) {
         kids[4 * (size_t) i + k] = kid[k];
@@ -286,60 +173,24 @@ __global__ void k_wide_expand(const RadixNode *nodes, const uint32_t *collapse, 
         if (!child_range(nodes, collapse, kid[k], lo, hi)) { is_wide[kid[k]] = 1u; next[atomicAdd(next_count, 1u)] = kid[k]; }
     }
 }
-
 __global__ void k_emit_wide(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N, const uint32_t *collapse,
                             const uint32_t *pair_start, const uint32_t *is_wide, const uint32_t *wide_index, const uint32_t *kids,
                             const uint32_t *n_kids, f4 *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_inner || !is_wide[i]) return;
-    float mn[4][3], mx[4][3]; int32_t link[4];
-    const int n = (int) n_kids[i];
-    for (int k = 0; k < n; ++k) {
-        uint32_t lo, hi;
-        link[k] = child_link(nodes, collapse, pair_start, wide_index, kids[4 * (size_t) i + k], lo, hi, 1u);      /* pair 0 = the null pair */
-        f3 a, b; range_box(tmin, tmax, N, lo, hi, a, b);
-        mn[k][0] = a.x; mn[k][1] = a.y; mn[k][2] = a.z; mx[k][0] = b.x; mx[k][1] = b.y; mx[k][2] = b.z;
-    }
     f4 q[4];
-    wide_pack(n, mn, mx, link, q);
+    emit_wide_node(nodes, tmin, tmax, N, collapse, pair_start, wide_index, kids + 4 * (size_t) i, (int) n_kids[i], q);
     f4 *dst = out + (size_t) wide_index[i] * kNodeQuads;
     dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
-}
-
-/* leaf_cnt[lo] = triangles of the leaf that starts at sorted position lo, leaf_pairs[lo] = its pairs;
-   keep[i] = 1 for the radix nodes that survive as BVH nodes: not collapsed and not below a collapsed node */
-__global__ void k_mark_leaves(const RadixNode *nodes, uint32_t n_inner, const uint32_t *collapse, const uint32_t *parent_inner,
-                              uint32_t *leaf_cnt, uint32_t *leaf_pairs, uint32_t *keep) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_inner) return;
-    const RadixNode nd = nodes[i];
-    bool reachable = collapse[i] == 0u;
-    for (uint32_t p = i; reachable && p != 0u && nodes[p].hi - nodes[p].lo + 1 <= 4u; ) {      /* ancestors that might have collapsed */
-        p = parent_inner[p];
-        if (p == 0xffffffffu) break;
-        if (collapse[p]) reachable = false;
-    }
-    keep[i] = reachable ? 1u : 0u;
-    if (!reachable) return;
-    uint32_t lo, hi;
-    if (child_range(nodes, collapse, nd.left, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
-    if (child_range(nodes, collapse, nd.right, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
 }
 
 __global__ void k_emit_nodes(const RadixNode *nodes, uint32_t n_inner, const f4 *tmin, const f4 *tmax, uint32_t N,
                              const uint32_t *collapse, const uint32_t *pair_start, const uint32_t *keep, const uint32_t *node_index, f4 *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_inner || !keep[i]) return;
-    const RadixNode nd = nodes[i];
-    uint32_t llo, lhi, rlo, rhi;
-    const int32_t cl = child_link(nodes, collapse, pair_start, node_index, nd.left, llo, lhi), cr = child_link(nodes, collapse, pair_start, node_index, nd.right, rlo, rhi);
-    f3 lmn, lmx, rmn, rmx;
-    range_box(tmin, tmax, N, llo, lhi, lmn, lmx);
-    range_box(tmin, tmax, N, rlo, rhi, rmn, rmx);
-    const float a0[3] = {lmn.x, lmn.y, lmn.z}, a1[3] = {lmx.x, lmx.y, lmx.z}, b0[3] = {rmn.x, rmn.y, rmn.z}, b1[3] = {rmx.x, rmx.y, rmx.z};
     f4 q[4];
-    node_pack(a0, a1, b0, b1, cl, cr, q);
-    f4 *dst = out + (size_t) node_index[i] * kNodeQuads;      /* dense: only the surviving nodes, in radix-tree order */
+    emit_node(nodes, i, tmin, tmax, N, collapse, pair_start, node_index, q);
+    f4 *dst = out + (size_t) node_index[i] * kNodeQuads;      /* dense: only the surviving nodes, in tree-array order */
     dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2]; dst[3] = q[3];
 }
 
@@ -349,33 +200,12 @@ __global__ void k_emit_pairs(const f4 *pos, const uint32_t *idx, const uint32_t 
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t cnt = leaf_cnt[k];
-    if (cnt == 0u) return;
-    for (uint32_t t = 0; t < ((cnt + 1u) / 2u) * 2u; ++t) {
-        f4 q[kPairQuads];
-        f4 *dst = out + (size_t) (pair_start[k] + pair_base + t / 2u) * kPairQuads;
-        if ((t & 1u) == 0u) for (int j = 0; j < kPairQuads; ++j) q[j].x = q[j].y = q[j].z = q[j].w = 0.0f;
-        else for (int j = 0; j < kPairQuads; ++j) q[j] = dst[j];
-        if (t < cnt) {
-            const uint32_t g = order[k + t];
-            const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
-            const f3 e1 = p1 - p0, e2 = p2 - p0;      /* the subtraction mesh.cpp:43 performs per ray */
-            const float a0[3] = {p0.x, p0.y, p0.z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
-            pair_pack(q, (int) (t & 1u), a0, a1, a2, g, tri_mesh[g]);
-        } else {
-            const float z[3] = {0.0f, 0.0f, 0.0f};
-            pair_pack(q, (int) (t & 1u), z, z, z, kNoTriangle, kNoTriangle);
-        }
-        for (int j = 0; j < kPairQuads; ++j) dst[j] = q[j];
-    }
+    if (cnt) emit_leaf_pairs(pos, idx, tri_mesh, order, k, cnt, out + (size_t) (pair_start[k] + pair_base) * kPairQuads);
 }
 
 __global__ void k_depth(const uint32_t *parent_inner, const uint32_t *parent_leaf, uint32_t n, unsigned int *max_depth) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    unsigned int depth = 1;
-    uint32_t p = parent_leaf[k];
-    while (p != 0u && p != 0xffffffffu && depth < 4096u) { p = parent_inner[p]; ++depth; }
-    atomicMax(max_depth, depth);
+    if (k < n) atomicMax(max_depth, leaf_depth(parent_inner, parent_leaf, k));
 }
 
 struct Buf {
@@ -392,7 +222,7 @@ struct Buf {
 
 namespace nrt {
 
-std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mesh, LbvhDeviceResult &out, bool wide) {
+std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mesh, LbvhDeviceResult &out, bool wide, uint32_t ploc_radius) {
     out = LbvhDeviceResult();
     if (dev.n_triangles <= 4) wide = false;                  /* a single leaf: no nodes at all */
     const uint32_t pair_base = wide ? 1u : 0u;               /* wide trees reserve pair 0 as the all-zero pair of unused slots */
@@ -429,7 +259,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     LB_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(),
                                               vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), (int) n, 0, 64));
     const unsigned long long *keys = keys_b.as<unsigned long long>();
-    const uint32_t *order = vals_b.as<uint32_t>();      /* sorted position -> global triangle */
+    const uint32_t *order = vals_b.as<uint32_t>();      /* position in the builder's order -> global triangle */
 
     /* leaves: start positions, triangle counts, pair counts -> first pair of every leaf */
     Buf leaf_cnt, leaf_pairs, pair_start, rnodes, pin, plf, keep, node_index, collapse, tmin, tmax;
@@ -441,14 +271,53 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         LB_TRY(hipMemcpy(leaf_cnt.p, &one[0], 4, hipMemcpyHostToDevice));
         LB_TRY(hipMemcpy(leaf_pairs.p, &one[1], 4, hipMemcpyHostToDevice));
     } else {
-        /* 4. radix tree */
         LB_TRY(rnodes.alloc((size_t) (n - 1) * sizeof(RadixNode)));
         LB_TRY(pin.alloc((size_t) n * 4)); LB_TRY(plf.alloc((size_t) n * 4));
-        hipLaunchKernelGGL(k_hierarchy, dim3(gridN), dim3(B), 0, 0, keys, (int) n, rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());
+        if (ploc_radius == 0u) {
+            /* 4. radix tree */
+            hipLaunchKernelGGL(k_hierarchy, dim3(gridN), dim3(B), 0, 0, keys, (int) n, rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());
+        } else {
+            /* 4'. PLOC (lbvh_steps.h): clusters in Morton order merge with their nearest neighbour until one is left */
+            Buf ca_mn, ca_mx, cb_mn, cb_mx, nearest, flags, incl, scan_tmp, nl, nr, nc, npn, npp, leaf_pos;
+            LB_TRY(ca_mn.alloc((size_t) n * 16)); LB_TRY(ca_mx.alloc((size_t) n * 16)); LB_TRY(cb_mn.alloc((size_t) n * 16)); LB_TRY(cb_mx.alloc((size_t) n * 16));
+            LB_TRY(nearest.alloc((size_t) n * 4)); LB_TRY(flags.alloc((size_t) n * 8)); LB_TRY(incl.alloc((size_t) n * 8));
+            LB_TRY(nl.alloc((size_t) n * 4)); LB_TRY(nr.alloc((size_t) n * 4)); LB_TRY(nc.alloc((size_t) n * 4));
+            LB_TRY(npn.alloc((size_t) n * 4)); LB_TRY(npp.alloc((size_t) n * 4)); LB_TRY(leaf_pos.alloc((size_t) n * 4));
+            size_t scan_bytes = 0;
+            LB_TRY(hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, flags.as<unsigned long long>(), incl.as<unsigned long long>(), (int) n));
+            LB_TRY(scan_tmp.alloc(scan_bytes));
+            PlocClusters ca{ca_mn.as<f4>(), ca_mx.as<f4>()}, cb{cb_mn.as<f4>(), cb_mx.as<f4>()};
+            PlocNodes pn{nl.as<uint32_t>(), nr.as<uint32_t>(), nc.as<uint32_t>(), npn.as<uint32_t>(), npp.as<uint32_t>()};
+            hipLaunchKernelGGL(k_ploc_init, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, order, n, pad, ca);
+            uint32_t m = n, node_base = 0u, iterations = 0u;
+            while (m > 1u) {
+                const dim3 g((m + B - 1) / B);
+                hipLaunchKernelGGL(k_ploc_nearest, g, dim3(B), 0, 0, ca, m, ploc_radius, nearest.as<uint32_t>());
+                hipLaunchKernelGGL(k_ploc_decide, g, dim3(B), 0, 0, nearest.as<uint32_t>(), m, flags.as<unsigned long long>());
+                size_t sb = scan_bytes;
+                LB_TRY(hipcub::DeviceScan::InclusiveSum(scan_tmp.p, sb, flags.as<unsigned long long>(), incl.as<unsigned long long>(), (int) m));
+                hipLaunchKernelGGL(k_ploc_apply, g, dim3(B), 0, 0, ca, cb, pn, nearest.as<uint32_t>(), m, flags.as<unsigned long long>(),
+                                   incl.as<unsigned long long>(), node_base);
+                unsigned long long total = 0ull;
+                LB_TRY(hipMemcpy(&total, incl.as<unsigned long long>() + (m - 1), 8, hipMemcpyDeviceToHost));
+                const uint32_t merged = (uint32_t) (total >> 32), left = (uint32_t) total;
+                if (merged == 0u || left + merged != m) return "lbvh: a PLOC iteration merged nothing";
+                node_base += merged; m = left;
+                std::swap(ca, cb);
+                if (++iterations > 100000u) return "lbvh: PLOC did not terminate";
+            }
+            if (node_base != n - 1u) return "lbvh: PLOC node count";
+            out.ploc_iterations = iterations;
+            /* the order of the tree's leaves, left to right: every node covers a contiguous range of it */
+            hipLaunchKernelGGL(k_ploc_leaf_positions, dim3(gridN), dim3(B), 0, 0, pn, n, order, leaf_pos.as<uint32_t>(), vals_a.as<uint32_t>());
+            hipLaunchKernelGGL(k_ploc_finish, dim3(gridN), dim3(B), 0, 0, pn, n - 1u, leaf_pos.as<uint32_t>(), rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());
+            LB_TRY(hipDeviceSynchronize());
+            order = vals_a.as<uint32_t>();
+        }
         /* 5. segment tree of boxes */
         N = 1; while (N < n) N <<= 1;
         LB_TRY(tmin.alloc((size_t) 2 * N * sizeof(f4))); LB_TRY(tmax.alloc((size_t) 2 * N * sizeof(f4)));
-        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, order, n, N, pad, smin, smax, tmin.as<f4>(), tmax.as<f4>());
+        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, order, n, N, pad, tmin.as<f4>(), tmax.as<f4>());
         for (uint32_t first = N >> 1; first >= 1; first >>= 1) {
             hipLaunchKernelGGL(k_tree_level, dim3((first + B - 1) / B), dim3(B), 0, 0, first, first, tmin.as<f4>(), tmax.as<f4>());
             if (first == 1) break;

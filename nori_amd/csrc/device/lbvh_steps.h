@@ -1,0 +1,378 @@
+/*
+ * lbvh_steps.h -- the per-element steps of the device BVH builders (lbvh.hip), written as plain functions of an
+ * index so that the kernels are one-line wrappers and the CPU test harness (tests/emu) can run the same steps as
+ * loops: Morton keys, the radix tree of Karras 2012, and PLOC (parallel locally-ordered clustering, Meister &
+ * Bittner 2018) -- the builder for scenes where the tree's quality decides the render time.
+ *
+ * PLOC, per iteration over the m clusters that are left (initially the triangles in Morton order):
+ *   ploc_nearest   every cluster looks R places to the left and right for the neighbour whose union with it has the
+ *                  smallest surface area (ties: the position with the longest common prefix)
+ *   ploc_decide    two clusters that chose EACH OTHER merge; the lower position leads.  Exclusive scans of the
+ *                  `lead` and `stays` flags give the new node's id and the cluster's place in the next iteration
+ *   ploc_apply     the leader writes the new node (children, triangle count, parent links) and the merged cluster
+ * Node ids grow in creation order, so the last node is the root; ploc_finish renumbers them root = 0.
+ * Every merge is local in Morton order, but the union is chosen by AREA, not by the next Morton bit: where the radix
+ * tree must split a cell along the axis whose bit comes next -- e.g. by HEIGHT across a patch of terrain -- PLOC pairs
+ * what is actually close.
+ *
+ * The rest of the pipeline (segment tree of boxes, leaf collapse, pair / node emission) needs every node to cover a
+ * CONTIGUOUS range of an ordering of the triangles.  Any binary tree has one: the order of its leaves, left to right.
+ * ploc_first_position computes it by walking up the parent links (offset = triangles in the left siblings passed on
+ * the way), ploc_finish writes the nodes with their ranges, and the builder permutes the triangles into that order.
+ *
+ * Numerically collinear triangles (rt_types.h, tri_box_pad: unbounded boxes) only cluster with each other, and with the
+ * rest at the very end: cost 0 among themselves, kPlocMixed with a bounded cluster.
+ */
+#pragma once
+#include "rt_types.h"
+#include "rt_wide.h"
+
+namespace nrt {
+
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kNoParent = 0xffffffffu;
+constexpr float kPlocMixed = 1e38f;
+
+/* internal node: children (bit 31 set = leaf, position of its triangle in the builder's order), covered range */
+struct RadixNode { uint32_t left, right, lo, hi; };
+
+/* ---- Morton keys ---- */
+/* spread the low 21 bits of v to every third bit */
+NORI_HD unsigned long long expand21(unsigned long long v) {
+    v &= 0x1fffffull;
+    v = (v | (v << 32)) & 0x001f00000000ffffull;
+    v = (v | (v << 16)) & 0x001f0000ff0000ffull;
+    v = (v | (v << 8)) & 0x100f00f00f00f00full;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ull;
+    v = (v | (v << 2)) & 0x1249249249249249ull;
+    return v;
+}
+/* 63-bit Morton code of a box centre (21 bits per axis: a 2M^3 grid keeps the triangles of multi-million-triangle
+   meshes in distinct cells) */
+NORI_HD unsigned long long morton63(f3 mn, f3 mx, f3 smin, f3 sinv) {
+    const float cx = (0.5f * (mn.x + mx.x) - smin.x) * sinv.x, cy = (0.5f * (mn.y + mx.y) - smin.y) * sinv.y,
+                cz = (0.5f * (mn.z + mx.z) - smin.z) * sinv.z;
+    const float S = 2097152.0f, M = 2097151.0f;
+    const unsigned long long ix = (unsigned long long) fminf(fmaxf(cx * S, 0.0f), M);
+    const unsigned long long iy = (unsigned long long) fminf(fmaxf(cy * S, 0.0f), M);
+    const unsigned long long iz = (unsigned long long) fminf(fmaxf(cz * S, 0.0f), M);
+    return (expand21(ix) << 2) | (expand21(iy) << 1) | expand21(iz);
+}
+
+/* ---- radix tree (Karras 2012) ---- */
+NORI_HD int clz64(unsigned long long x) { return __builtin_clzll(x); }
+NORI_HD int clz32(uint32_t x) { return __builtin_clz(x); }
+/* common-prefix length of the (key, position) pairs i and j: equal codes are told apart by their
+   position in the sorted order, so every pair has a distinct prefix length */
+NORI_HD int radix_delta(const unsigned long long *keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long x = keys[i] ^ keys[j];
+    return x ? clz64(x) : 64 + clz32((uint32_t) (i ^ j));
+}
+/* internal node i of the radix tree over n sorted keys; writes the parent links of its children */
+NORI_HD RadixNode radix_node(const unsigned long long *keys, int n, int i, uint32_t *parent_inner, uint32_t *parent_leaf) {
+    const int d = (radix_delta(keys, n, i, i + 1) - radix_delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = radix_delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (radix_delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+    int l = 0;
+    for (int t = lmax >> 1; t >= 1; t >>= 1)
+        if (radix_delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = radix_delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) >> 1; ; t = (t + 1) >> 1) {
+        if (radix_delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t <= 1) break;
+    }
+    const int gamma = i + s * d + (d < 0 ? d : 0);
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    RadixNode nd;
+    nd.lo = (uint32_t) lo; nd.hi = (uint32_t) hi;
+    if (lo == gamma) { nd.left = kLeafBit | (uint32_t) gamma; parent_leaf[gamma] = (uint32_t) i; }
+    else { nd.left = (uint32_t) gamma; parent_inner[gamma] = (uint32_t) i; }
+    if (hi == gamma + 1) { nd.right = kLeafBit | (uint32_t) (gamma + 1); parent_leaf[gamma + 1] = (uint32_t) i; }
+    else { nd.right = (uint32_t) (gamma + 1); parent_inner[gamma + 1] = (uint32_t) i; }
+    if (i == 0) parent_inner[0] = kNoParent;
+    return nd;
+}
+
+/* ---- PLOC ---- */
+/* a cluster: box, id (leaf: kLeafBit | sorted position; else node id in creation order), triangle count; the box of
+   an unbounded cluster is (-kBoxInf, kBoxInf)^3 */
+struct PlocClusters {
+    f4 *mn;      /* xyz = lower corner, w = id bits */
+    f4 *mx;      /* xyz = upper corner, w = count bits */
+};
+/* a node in creation order */
+struct PlocNodes {
+    uint32_t *left, *right, *count;       /* children ids (as cluster ids), triangles below */
+    uint32_t *parent_node, *parent_prim;  /* by node id / by sorted position */
+};
+
+NORI_HD float half_area(f3 mn, f3 mx) {
+    const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+    return dx * dy + (dy * dz + dz * dx);
+}
+NORI_HD bool ploc_unbounded(f4 mx) { return !(mx.x < kBoxInf); }
+NORI_HD float ploc_cost(f4 amn, f4 amx, f4 bmn, f4 bmx) {
+    const bool ua = ploc_unbounded(amx), ub = ploc_unbounded(bmx);
+    if (ua || ub) return (ua && ub) ? 0.0f : kPlocMixed;
+    return half_area(mk3(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z)),
+                     mk3(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z)));
+}
+/* position of cluster i's nearest neighbour among the m clusters, searching `radius` places each way */
+NORI_HD uint32_t ploc_nearest(const PlocClusters &c, uint32_t m, uint32_t i, uint32_t radius) {
+    const f4 amn = c.mn[i], amx = c.mx[i];
+    const uint32_t j0 = i > radius ? i - radius : 0u, j1 = (i + radius < m - 1u) ? i + radius : m - 1u;
+    float best = kInf; uint32_t arg = i;
+    for (uint32_t j = j0; j <= j1; ++j) {
+        if (j == i) continue;
+        const float cost = ploc_cost(amn, amx, c.mn[j], c.mx[j]);
+        /* equal costs (duplicated triangles, sheets of equal boxes): the position sharing the longest prefix with i, so that
+           whole runs pair up (2k, 2k + 1) at once instead of one pair per iteration at the run's end; the key (cost, i ^ j) is
+           symmetric in i and j, so the best pair overall is always mutual and every iteration merges something */
+        if (cost < best || (cost == best && (i ^ j) < (i ^ arg))) { best = cost; arg = j; }
+    }
+    return arg;
+}
+/* flags of cluster i for the scans: lead = it creates a node (mutual choice, lower position), stays = it has a place in
+   the next iteration (everything but the partner that is merged away) */
+NORI_HD void ploc_decide(const uint32_t *nearest, uint32_t i, uint32_t &lead, uint32_t &stays) {
+    const uint32_t j = nearest[i];
+    const bool mutual = j != i && nearest[j] == i;
+    lead = (mutual && i < j) ? 1u : 0u;
+    stays = (!mutual || i < j) ? 1u : 0u;
+}
+NORI_HD uint32_t ploc_count_of(f4 mx) { return f2u(mx.w); }
+/* cluster i moves to (or, leading a merge, creates node node_base + lead_rank and moves as that node to) place
+   stays_rank of the next iteration */
+NORI_HD void ploc_apply(const PlocClusters &in, const PlocClusters &out, const PlocNodes &nodes, const uint32_t *nearest, uint32_t i,
+                        uint32_t lead, uint32_t stays, uint32_t lead_rank, uint32_t stays_rank, uint32_t node_base) {
+    if (!stays) return;
+    f4 mn = in.mn[i], mx = in.mx[i];
+    if (lead) {
+        const uint32_t j = nearest[i];
+        const f4 bmn = in.mn[j], bmx = in.mx[j];
+        const uint32_t id = node_base + lead_rank, a = f2u(mn.w), b = f2u(bmn.w);
+        const uint32_t cnt = ploc_count_of(mx) + ploc_count_of(bmx);
+        nodes.left[id] = a; nodes.right[id] = b; nodes.count[id] = cnt;
+        if (a & kLeafBit) nodes.parent_prim[a & ~kLeafBit] = id; else nodes.parent_node[a] = id;
+        if (b & kLeafBit) nodes.parent_prim[b & ~kLeafBit] = id; else nodes.parent_node[b] = id;
+        mn.x = fminf(mn.x, bmn.x); mn.y = fminf(mn.y, bmn.y); mn.z = fminf(mn.z, bmn.z); mn.w = u2f(id);
+        mx.x = fmaxf(mx.x, bmx.x); mx.y = fmaxf(mx.y, bmx.y); mx.z = fmaxf(mx.z, bmx.z); mx.w = u2f(cnt);
+    }
+    out.mn[stays_rank] = mn; out.mx[stays_rank] = mx;
+}
+
+/* triangles below a child id */
+NORI_HD uint32_t ploc_child_count(const PlocNodes &nodes, uint32_t child) { return (child & kLeafBit) ? 1u : nodes.count[child]; }
+/* first position, in left-to-right leaf order, of the subtree `id` (a node id, or kLeafBit | sorted position):
+   the triangles of the left siblings passed on the way up to the root (node n_nodes - 1) */
+NORI_HD uint32_t ploc_first_position(const PlocNodes &nodes, uint32_t n_nodes, uint32_t id) {
+    uint32_t pos = 0u, c = id;
+    while (c != n_nodes - 1u) {
+        const uint32_t p = (c & kLeafBit) ? nodes.parent_prim[c & ~kLeafBit] : nodes.parent_node[c];
+        if (nodes.right[p] == c) pos += ploc_child_count(nodes, nodes.left[p]);
+        c = p;
+    }
+    return pos;
+}
+/* node `id` (creation order) as the radix-tree record the emission kernels read; its index there is n_nodes - 1 - id (root = 0).
+   leaf_pos[k] = ploc_first_position of the triangle at sorted position k. */
+NORI_HD RadixNode ploc_finish(const PlocNodes &nodes, uint32_t n_nodes, uint32_t id, const uint32_t *leaf_pos,
+                              uint32_t *parent_inner, uint32_t *parent_leaf) {
+    const uint32_t self = n_nodes - 1u - id;
+    RadixNode nd;
+    nd.lo = ploc_first_position(nodes, n_nodes, id);
+    nd.hi = nd.lo + nodes.count[id] - 1u;
+    const uint32_t a = nodes.left[id], b = nodes.right[id];
+    if (a & kLeafBit) { nd.left = kLeafBit | leaf_pos[a & ~kLeafBit]; parent_leaf[leaf_pos[a & ~kLeafBit]] = self; }
+    else { nd.left = n_nodes - 1u - a; parent_inner[n_nodes - 1u - a] = self; }
+    if (b & kLeafBit) { nd.right = kLeafBit | leaf_pos[b & ~kLeafBit]; parent_leaf[leaf_pos[b & ~kLeafBit]] = self; }
+    else { nd.right = n_nodes - 1u - b; parent_inner[n_nodes - 1u - b] = self; }
+    if (self == 0u) parent_inner[0] = kNoParent;
+    return nd;
+}
+
+/* ---- boxes ---- */
+NORI_HD void tri_box(const f4 *pos, const uint32_t *idx, uint32_t t, f3 &mn, f3 &mx) {
+    const f3 a = xyz(pos[idx[3 * (size_t) t]]), b = xyz(pos[idx[3 * (size_t) t + 1]]), c = xyz(pos[idx[3 * (size_t) t + 2]]);
+    mn = mk3(fminf(a.x, fminf(b.x, c.x)), fminf(a.y, fminf(b.y, c.y)), fminf(a.z, fminf(b.z, c.z)));
+    mx = mk3(fmaxf(a.x, fmaxf(b.x, c.x)), fmaxf(a.y, fmaxf(b.y, c.y)), fmaxf(a.z, fmaxf(b.z, c.z)));
+}
+NORI_HD bool tri_unbounded(const f4 *pos, const uint32_t *idx, uint32_t t) {
+    const f3 p0 = xyz(pos[idx[3 * (size_t) t]]), p1 = xyz(pos[idx[3 * (size_t) t + 1]]), p2 = xyz(pos[idx[3 * (size_t) t + 2]]);
+    bool unbounded;
+    (void) tri_box_pad(p1 - p0, p2 - p0, 0.0f, unbounded);
+    return unbounded;
+}
+/* the box a triangle enters the tree with: padded (slivers wider: rt_types.h), unbounded = (-kBoxInf, kBoxInf)^3 */
+NORI_HD void tri_leaf_box(const f4 *pos, const uint32_t *idx, uint32_t g, float pad0, f4 &mn4, f4 &mx4) {
+    f3 mn, mx; tri_box(pos, idx, g, mn, mx);
+    const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
+    bool unbounded;
+    const float pad = tri_box_pad(p1 - p0, p2 - p0, pad0, unbounded);
+    if (unbounded) { mn = mk3(-kBoxInf); mx = mk3(kBoxInf); }
+    mn4.x = mn.x - pad; mn4.y = mn.y - pad; mn4.z = mn.z - pad; mx4.x = mx.x + pad; mx4.y = mx.y + pad; mx4.z = mx.z + pad;
+    mn4.w = mx4.w = 0.0f;
+}
+/* min / max segment tree over the boxes in the builder's order: leaves at [N + k], node i = union of 2 i, 2 i + 1 */
+NORI_HD void seg_tree_combine(uint32_t i, f4 *tmin, f4 *tmax) {
+    const f4 a = tmin[2 * i], b = tmin[2 * i + 1], c = tmax[2 * i], d = tmax[2 * i + 1];
+    f4 mn, mx;
+    mn.x = fminf(a.x, b.x); mn.y = fminf(a.y, b.y); mn.z = fminf(a.z, b.z); mn.w = 0.0f;
+    mx.x = fmaxf(c.x, d.x); mx.y = fmaxf(c.y, d.y); mx.z = fmaxf(c.z, d.z); mx.w = 0.0f;
+    tmin[i] = mn; tmax[i] = mx;
+}
+NORI_HD void range_box(const f4 *tmin, const f4 *tmax, uint32_t N, uint32_t lo, uint32_t hi, f3 &mn, f3 &mx) {
+    mn = mk3(kInf); mx = mk3(-kInf);
+    uint32_t l = lo + N, r = hi + N + 1;
+    while (l < r) {
+        if (l & 1u) { const f4 a = tmin[l], b = tmax[l]; ++l;
+            mn = mk3(fminf(mn.x, a.x), fminf(mn.y, a.y), fminf(mn.z, a.z)); mx = mk3(fmaxf(mx.x, b.x), fmaxf(mx.y, b.y), fmaxf(mx.z, b.z)); }
+        if (r & 1u) { --r; const f4 a = tmin[r], b = tmax[r];
+            mn = mk3(fminf(mn.x, a.x), fminf(mn.y, a.y), fminf(mn.z, a.z)); mx = mk3(fmaxf(mx.x, b.x), fmaxf(mx.y, b.y), fmaxf(mx.z, b.z)); }
+        l >>= 1; r >>= 1;
+    }
+}
+NORI_HD float box_area(f3 mn, f3 mx) {
+    const float dx = mx.x - mn.x, dy = mx.y - mn.y, dz = mx.z - mn.z;
+    return 2.0f * (dx * dy + dy * dz + dz * dx);
+}
+
+/* ---- leaves ---- */
+/* A subtree of <= 4 triangles (contiguous in the builder's order) can become ONE leaf (its triangles stored as
+   pairs, rt_types.h) or stay split.  collapse_decide chooses per node with the surface-area heuristic:
+       leaf : A(node) * pairs * Cpair          split : A(node) * Cnode + best(left) + best(right)
+   (a leaf step tests a pair of triangles, 1.5 - 2.5x the work of a node step).  collapse[i] = 1: node i is a
+   leaf wherever it is reached.  Nodes above 4 triangles are always inner nodes. */
+struct CollapseParams { float c_pair, c_node; };
+
+NORI_HD float best_cost(const RadixNode *nodes, const f4 *tmin, const f4 *tmax, uint32_t N, uint32_t child, CollapseParams cp, bool *collapse_out) {
+    f3 mn, mx;
+    if (child & kLeafBit) {
+        const uint32_t k = child & ~kLeafBit;
+        range_box(tmin, tmax, N, k, k, mn, mx);
+        return box_area(mn, mx) * cp.c_pair;
+    }
+    const RadixNode nd = nodes[child];
+    range_box(tmin, tmax, N, nd.lo, nd.hi, mn, mx);
+    const float area = box_area(mn, mx);
+    const float leaf = area * (float) ((nd.hi - nd.lo + 2u) / 2u) * cp.c_pair;
+    const float split = area * cp.c_node + best_cost(nodes, tmin, tmax, N, nd.left, cp, nullptr) + best_cost(nodes, tmin, tmax, N, nd.right, cp, nullptr);
+    if (collapse_out) *collapse_out = leaf <= split;
+    return fminf(leaf, split);
+}
+NORI_HD uint32_t collapse_decide(const RadixNode *nodes, uint32_t i, const f4 *tmin, const f4 *tmax, uint32_t N, CollapseParams cp) {
+    const RadixNode nd = nodes[i];
+    bool c = false;
+    if (nd.hi - nd.lo + 1 <= 4u) (void) best_cost(nodes, tmin, tmax, N, i, cp, &c);      /* subtree of <= 3 inner nodes */
+    return c ? 1u : 0u;
+}
+/* is `child` a leaf (primitive or collapsed subtree)?  [lo, hi] = its range */
+NORI_HD bool child_range(const RadixNode *nodes, const uint32_t *collapse, uint32_t child, uint32_t &lo, uint32_t &hi) {
+    if (child & kLeafBit) { lo = hi = child & ~kLeafBit; return true; }
+    lo = nodes[child].lo; hi = nodes[child].hi;
+    return collapse[child] != 0u;
+}
+/* the first pair of the leaf starting at position lo is pair_start[lo] (exclusive scan of the per-leaf pair counts) */
+NORI_HD int32_t child_link(const RadixNode *nodes, const uint32_t *collapse, const uint32_t *pair_start, const uint32_t *node_index,
+                           uint32_t child, uint32_t &lo, uint32_t &hi, uint32_t pair_base = 0u) {
+    if (!child_range(nodes, collapse, child, lo, hi)) return (int32_t) node_index[child];
+    const uint32_t cnt = hi - lo + 1;
+    return (int32_t) ~(((pair_start[lo] + pair_base) << 3) | ((cnt + 1u) / 2u - 1u));
+}
+/* leaf_cnt[lo] = triangles of the leaf that starts at position lo, leaf_pairs[lo] = its pairs; returns keep = 1 for the
+   nodes that survive as BVH nodes: not collapsed and not below a collapsed node */
+NORI_HD uint32_t mark_leaves(const RadixNode *nodes, uint32_t i, const uint32_t *collapse, const uint32_t *parent_inner,
+                             uint32_t *leaf_cnt, uint32_t *leaf_pairs) {
+    const RadixNode nd = nodes[i];
+    bool reachable = collapse[i] == 0u;
+    for (uint32_t p = i; reachable && p != 0u && nodes[p].hi - nodes[p].lo + 1 <= 4u; ) {      /* ancestors that might have collapsed */
+        p = parent_inner[p];
+        if (p == kNoParent) break;
+        if (collapse[p]) reachable = false;
+    }
+    if (!reachable) return 0u;
+    uint32_t lo, hi;
+    if (child_range(nodes, collapse, nd.left, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
+    if (child_range(nodes, collapse, nd.right, lo, hi)) { leaf_cnt[lo] = hi - lo + 1; leaf_pairs[lo] = (hi - lo + 2) / 2; }
+    return 1u;
+}
+
+/* ---- emission ---- */
+/* node i as a 64-B two-child-box record (rt_types.h) */
+NORI_HD void emit_node(const RadixNode *nodes, uint32_t i, const f4 *tmin, const f4 *tmax, uint32_t N, const uint32_t *collapse,
+                       const uint32_t *pair_start, const uint32_t *node_index, f4 q[4]) {
+    const RadixNode nd = nodes[i];
+    uint32_t llo, lhi, rlo, rhi;
+    const int32_t cl = child_link(nodes, collapse, pair_start, node_index, nd.left, llo, lhi), cr = child_link(nodes, collapse, pair_start, node_index, nd.right, rlo, rhi);
+    f3 lmn, lmx, rmn, rmx;
+    range_box(tmin, tmax, N, llo, lhi, lmn, lmx);
+    range_box(tmin, tmax, N, rlo, rhi, rmn, rmx);
+    const float a0[3] = {lmn.x, lmn.y, lmn.z}, a1[3] = {lmx.x, lmx.y, lmx.z}, b0[3] = {rmn.x, rmn.y, rmn.z}, b1[3] = {rmx.x, rmx.y, rmx.z};
+    node_pack(a0, a1, b0, b1, cl, cr, q);
+}
+/* the leaf that starts at position k (cnt triangles): its triangles, de-indexed, as pair records */
+NORI_HD void emit_leaf_pairs(const f4 *pos, const uint32_t *idx, const uint32_t *tri_mesh, const uint32_t *order, uint32_t k, uint32_t cnt,
+                             f4 *dst_pairs) {
+    for (uint32_t t = 0; t < ((cnt + 1u) / 2u) * 2u; ++t) {
+        f4 q[kPairQuads];
+        f4 *dst = dst_pairs + (size_t) (t / 2u) * kPairQuads;
+        if ((t & 1u) == 0u) for (int j = 0; j < kPairQuads; ++j) q[j].x = q[j].y = q[j].z = q[j].w = 0.0f;
+        else for (int j = 0; j < kPairQuads; ++j) q[j] = dst[j];
+        if (t < cnt) {
+            const uint32_t g = order[k + t];
+            const f3 p0 = xyz(pos[idx[3 * (size_t) g]]), p1 = xyz(pos[idx[3 * (size_t) g + 1]]), p2 = xyz(pos[idx[3 * (size_t) g + 2]]);
+            const f3 e1 = p1 - p0, e2 = p2 - p0;      /* the subtraction mesh.cpp:43 performs per ray */
+            const float a0[3] = {p0.x, p0.y, p0.z}, a1[3] = {e1.x, e1.y, e1.z}, a2[3] = {e2.x, e2.y, e2.z};
+            pair_pack(q, (int) (t & 1u), a0, a1, a2, g, tri_mesh[g]);
+        } else {
+            const float z[3] = {0.0f, 0.0f, 0.0f};
+            pair_pack(q, (int) (t & 1u), z, z, z, kNoTriangle, kNoTriangle);
+        }
+        for (int j = 0; j < kPairQuads; ++j) dst[j] = q[j];
+    }
+}
+/* WIDE emission, one wide node: take node i's two children and twice replace the inner child of largest surface area by
+   that child's children.  Returns the number of children in kid[]; the inner ones are the wide nodes of the next level. */
+NORI_HD int wide_children(const RadixNode *nodes, const uint32_t *collapse, const f4 *tmin, const f4 *tmax, uint32_t N, uint32_t i, uint32_t kid[4]) {
+    const RadixNode nd = nodes[i];
+    kid[0] = nd.left; kid[1] = nd.right; kid[2] = kid[3] = 0u;
+    int n = 2;
+    while (n < 4) {
+        int best = -1; float bestArea = -1.0f;
+        for (int k = 0; k < n; ++k) {
+            uint32_t lo, hi;
+            if (child_range(nodes, collapse, kid[k], lo, hi)) continue;      /* a leaf stays */
+            f3 mn, mx; range_box(tmin, tmax, N, lo, hi, mn, mx);
+            float a = box_area(mn, mx);
+            if (!(a < kInf)) a = kInf;                                        /* unbounded subtree first */
+            if (a > bestArea) { bestArea = a; best = k; }
+        }
+        if (best < 0) break;
+        const RadixNode c = nodes[kid[best]];
+        kid[best] = c.left; kid[n++] = c.right;
+    }
+    return n;
+}
+NORI_HD void emit_wide_node(const RadixNode *nodes, const f4 *tmin, const f4 *tmax, uint32_t N, const uint32_t *collapse, const uint32_t *pair_start,
+                            const uint32_t *wide_index, const uint32_t *kids, int n, f4 q[4]) {
+    float mn[4][3], mx[4][3]; int32_t link[4];
+    for (int k = 0; k < n; ++k) {
+        uint32_t lo, hi;
+        link[k] = child_link(nodes, collapse, pair_start, wide_index, kids[k], lo, hi, 1u);      /* pair 0 = the null pair */
+        f3 a, b; range_box(tmin, tmax, N, lo, hi, a, b);
+        mn[k][0] = a.x; mn[k][1] = a.y; mn[k][2] = a.z; mx[k][0] = b.x; mx[k][1] = b.y; mx[k][2] = b.z;
+    }
+    wide_pack(n, mn, mx, link, q);
+}
+/* nodes on the way from the triangle at position k to the root */
+NORI_HD uint32_t leaf_depth(const uint32_t *parent_inner, const uint32_t *parent_leaf, uint32_t k) {
+    uint32_t depth = 1u, p = parent_leaf[k];
+    while (p != 0u && p != kNoParent && depth < 4096u) { p = parent_inner[p]; ++depth; }
+    return depth;
+}
+
+} // namespace nrt

@@ -526,21 +526,33 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
 int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     if (!ctx) return NORI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) { ctx->error = "build_accel: no scene uploaded"; return NORI_ERR_NOT_READY; }
-    if (builder == NORI_ACCEL_AUTO) builder = ctx->dev.n_triangles > (1u << 22) ? NORI_ACCEL_GPU_LBVH : NORI_ACCEL_HOST_SAH;
-    if (builder != NORI_ACCEL_HOST_SAH && builder != NORI_ACCEL_GPU_LBVH) { ctx->error = "build_accel: unknown builder"; return NORI_ERR_INVALID_ARGUMENT; }
+    if (builder == NORI_ACCEL_AUTO) builder = ctx->dev.n_triangles > (1u << 22) ? NORI_ACCEL_GPU_PLOC : NORI_ACCEL_HOST_SAH;
+    if (builder != NORI_ACCEL_HOST_SAH && builder != NORI_ACCEL_GPU_LBVH && builder != NORI_ACCEL_GPU_PLOC) { ctx->error = "build_accel: unknown builder"; return NORI_ERR_INVALID_ARGUMENT; }
     DeviceGuard g(ctx->device);
     free_pool(ctx->allocs_accel);
     ctx->have_accel = false;
     int layout = ctx->accel_layout;
     if (const char *e = getenv("NORI_HIP_ACCEL_LAYOUT")) layout = std::string(e) == "bvh4q" ? 1 : (std::string(e) == "bvh2" ? 0 : -1);
     const bool want_wide = layout == 1 || (layout < 0 && ctx->dev.n_triangles >= (1u << 20));
-    if (builder == NORI_ACCEL_GPU_LBVH && ctx->dev.n_triangles > 0) {
+    if (builder != NORI_ACCEL_HOST_SAH && ctx->dev.n_triangles > 0) {
         LbvhDeviceResult res;
-        std::string err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res, want_wide);
+        uint32_t ploc_radius = builder == NORI_ACCEL_GPU_PLOC ? 8u : 0u;      /* 8, 16, 32 give the same trees within 1 % (tools/builder_probe.py); 8 builds fastest */
+        if (const char *e = getenv("NORI_HIP_PLOC_RADIUS")) if (ploc_radius) ploc_radius = (uint32_t) std::min(256, std::max(1, atoi(e)));
+        std::string err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res, want_wide, ploc_radius);
         if (err.empty() && res.wide && res.max_depth + 1 > 64) {      /* wide tree needs more stack than the kernels have: BVH2 nodes */
             if (res.d_nodes) (void) hipFree(res.d_nodes);
             if (res.d_tris) (void) hipFree(res.d_tris);
-            err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res, false);
+            err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res, false, ploc_radius);
+        }
+        if (err.empty() && ploc_radius && res.max_depth + 1 > 64) {   /* a clustering of near-identical boxes can degenerate into a chain: the radix tree instead */
+            if (res.d_nodes) (void) hipFree(res.d_nodes);
+            if (res.d_tris) (void) hipFree(res.d_tris);
+            err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res, want_wide, 0u);
+            if (err.empty() && res.wide && res.max_depth + 1 > 64) {
+                if (res.d_nodes) (void) hipFree(res.d_nodes);
+                if (res.d_tris) (void) hipFree(res.d_tris);
+                err = build_bvh_lbvh_device(ctx->dev, ctx->d_tri_mesh, res, false, 0u);
+            }
         }
         if (res.d_nodes) ctx->allocs_accel.push_back(res.d_nodes);
         if (res.d_tris) ctx->allocs_accel.push_back(res.d_tris);

@@ -742,7 +742,10 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     /* persistent extend grid: fill the CUs, but with two pipes leave half of the wave slots to
        the other pipe's kernels */
     /* traversal stack: what the tree needs, at most `lds_stack` entries of it in LDS */
-    int lds_stack = (L.stack_depth <= 16 || sc.wide) ? 16 : 24;      /* wide trees: 16 measured best on the 10 M-triangle terrain (6 workgroups per CU) */
+    /* 16 entries in LDS, deeper walks spill to HBM: a stack of 24 entries costs three of the eight workgroups per CU, and walks
+       rarely hold more than 16 deferred subtrees however deep the tree (measured, trace ms at 16 / 24 entries: table scene,
+       depth 19: 77.5 / 83.0; Cornell box with the device builders' deeper trees: 61.6 / 74.8 and 73.3 / 82.1) */
+    int lds_stack = 16;
     if (const char *e = getenv("NORI_HIP_WF_STACK")) lds_stack = atoi(e) <= 16 ? 16 : atoi(e) <= 24 ? 24 : 32;
     const bool spill = L.stack_depth > lds_stack || sc.wide != 0;
     int finish_paths = 524288;           /* fewer live paths than this: wf_finish ends the batch */

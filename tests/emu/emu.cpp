@@ -20,6 +20,7 @@
 
 #include "../../include/nori_hip.h"
 #include "emu_film.h"
+#include "emu_builder.h"
 #include "../../nori_amd/csrc/device/wf_records.h"
 #include "../../nori_amd/csrc/device/rt_path.h"
 #include "../../nori_amd/csrc/device/scene_prep.h"
@@ -140,8 +141,24 @@ int emu_create(const nori_scene_desc *scene, emu_ctx **out) {
     /* node layout as the library picks it (nori_hip_build_accel): NORI_HIP_ACCEL_LAYOUT=bvh4q forces wide nodes */
     const char *lay = std::getenv("NORI_HIP_ACCEL_LAYOUT");
     const bool wide = lay ? std::string(lay) == "bvh4q" : c->host.tri_mesh.size() >= ((size_t) 1 << 20);
-    if (err.empty()) err = build_bvh_sah(c->host, 64, c->bvh, wide);
-    if (!err.empty() && wide) err = build_bvh_sah(c->host, 64, c->bvh, false);
+    /* NORI_EMU_BUILDER=lbvh | ploc: the DEVICE builders' steps run on the CPU (emu_builder.h) instead of the host SAH builder */
+    const char *bld = std::getenv("NORI_EMU_BUILDER");
+    const std::string builder = bld ? bld : "sah";
+    if (err.empty() && builder != "sah") {
+        uint32_t radius = builder == "ploc" ? 8u : 0u;
+        if (const char *e = std::getenv("NORI_HIP_PLOC_RADIUS")) if (radius) radius = (uint32_t) std::max(1, atoi(e));
+        EmuBuilderStats st;
+        err = build_bvh_steps_host(c->host, wide, radius, c->bvh, &st);
+        if (err.empty() && c->bvh.max_depth + 1 > 64 && wide) err = build_bvh_steps_host(c->host, false, radius, c->bvh, &st);
+        if (err.empty() && c->bvh.max_depth + 1 > 64 && radius) {      /* as nori_hip_build_accel: the radix tree instead */
+            err = build_bvh_steps_host(c->host, wide, 0u, c->bvh, &st);
+            if (err.empty() && c->bvh.max_depth + 1 > 64 && wide) err = build_bvh_steps_host(c->host, false, 0u, c->bvh, &st);
+        }
+        if (err.empty() && c->bvh.max_depth + 1 > 64) err = "tree deeper than the traversal stack";
+    } else {
+        if (err.empty()) err = build_bvh_sah(c->host, 64, c->bvh, wide);
+        if (!err.empty() && wide) err = build_bvh_sah(c->host, 64, c->bvh, false);
+    }
     if (!err.empty()) { fprintf(stderr, "emu_create: %s\n", err.c_str()); delete c; return NORI_ERR_INVALID_ARGUMENT; }
     bind(c);
     *out = c;

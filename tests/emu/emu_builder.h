@@ -1,0 +1,184 @@
+/*
+ * emu_builder.h -- TEST-ONLY: the device BVH builders (nori_amd/csrc/device/lbvh.hip) run on the CPU.
+ *
+ * lbvh.hip's kernels are one thread per element over the functions of lbvh_steps.h; here the same functions run in
+ * loops, in the order of build_bvh_lbvh_device, with std::sort / serial prefix sums where the device uses hipcub.
+ * The result is a HostBvh the emulation harness traverses like any other, so `pytest -m "not gpu"` checks the
+ * builders' LOGIC (radix tree, PLOC, leaf collapse, pair / node / wide-node emission) against the oracle's
+ * brute force and reports what the trees cost per ray before GPU minutes are spent.
+ */
+#pragma once
+#include <algorithm>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../nori_amd/csrc/device/lbvh_steps.h"
+#include "../../nori_amd/csrc/device/scene_prep.h"
+
+namespace nrt {
+
+struct EmuBuilderStats { uint32_t ploc_iterations = 0; float sah_cost = 0.0f; };
+
+inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint32_t ploc_radius, HostBvh &out, EmuBuilderStats *stats = nullptr) {
+    out = HostBvh();
+    const uint32_t n = (uint32_t) scene.tri_mesh.size();
+    if (n == 0) return "empty scene";
+    if (n <= 4) wide = false;
+    const uint32_t pair_base = wide ? 1u : 0u;
+    const f4 *pos = scene.positions.data();
+    const uint32_t *idx = scene.indices.data();
+
+    /* 1. scene bounds */
+    f3 smin = mk3(kInf), smax = mk3(-kInf);
+    for (uint32_t t = 0; t < n; ++t) {
+        f3 mn, mx; tri_box(pos, idx, t, mn, mx);
+        smin = mk3(fminf(smin.x, mn.x), fminf(smin.y, mn.y), fminf(smin.z, mn.z));
+        smax = mk3(fmaxf(smax.x, mx.x), fmaxf(smax.y, mx.y), fmaxf(smax.z, mx.z));
+    }
+    const float ex = smax.x - smin.x, ey = smax.y - smin.y, ez = smax.z - smin.z;
+    const float pad = box_pad_rel() * sqrtf(ex * ex + ey * ey + ez * ez) + 1e-30f;
+    const f3 sinv = mk3(ex > 0 ? 1.0f / ex : 0.0f, ey > 0 ? 1.0f / ey : 0.0f, ez > 0 ? 1.0f / ez : 0.0f);
+
+    /* 2, 3. Morton keys, sorted (stable in the triangle index, like the radix sort) */
+    std::vector<unsigned long long> key(n), keys(n);
+    std::vector<uint32_t> order(n);
+    for (uint32_t t = 0; t < n; ++t) {
+        if (tri_unbounded(pos, idx, t)) { key[t] = 0x8000000000000000ull; continue; }
+        f3 mn, mx; tri_box(pos, idx, t, mn, mx);
+        key[t] = morton63(mn, mx, smin, sinv);
+    }
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    for (uint32_t k = 0; k < n; ++k) keys[k] = key[order[k]];
+
+    std::vector<uint32_t> leaf_cnt(n, 0u), leaf_pairs(n, 0u), pair_start(n, 0u);
+    std::vector<RadixNode> rnodes;
+    std::vector<uint32_t> pin(n, 0u), plf(n, 0u), keep(n, 0u), node_index(n, 0u), collapse(n, 0u);
+    std::vector<f4> tmin, tmax;
+    uint32_t N = 1;
+    if (n <= 4) {
+        leaf_cnt[0] = n; leaf_pairs[0] = (n + 1) / 2;
+    } else {
+        rnodes.resize(n - 1);
+        if (ploc_radius == 0u) {
+            for (uint32_t i = 0; i + 1 < n; ++i) rnodes[i] = radix_node(keys.data(), (int) n, (int) i, pin.data(), plf.data());
+        } else {
+            std::vector<f4> amn(n), amx(n), bmn(n), bmx(n);
+            std::vector<uint32_t> nearest(n), nl(n), nr(n), nc(n), npn(n), npp(n), leaf_pos(n), order2(n);
+            PlocClusters ca{amn.data(), amx.data()}, cb{bmn.data(), bmx.data()};
+            PlocNodes pn{nl.data(), nr.data(), nc.data(), npn.data(), npp.data()};
+            for (uint32_t k = 0; k < n; ++k) {
+                f4 mn, mx; tri_leaf_box(pos, idx, order[k], pad, mn, mx);
+                mn.w = u2f(kLeafBit | k); mx.w = u2f(1u);
+                ca.mn[k] = mn; ca.mx[k] = mx;
+            }
+            uint32_t m = n, node_base = 0u, iterations = 0u;
+            std::vector<uint32_t> lead(n), stays(n), lead_rank(n), stays_rank(n);
+            while (m > 1u) {
+                for (uint32_t i = 0; i < m; ++i) nearest[i] = ploc_nearest(ca, m, i, ploc_radius);
+                uint32_t nl_ = 0u, ns_ = 0u;
+                for (uint32_t i = 0; i < m; ++i) {
+                    ploc_decide(nearest.data(), i, lead[i], stays[i]);
+                    lead_rank[i] = nl_; stays_rank[i] = ns_; nl_ += lead[i]; ns_ += stays[i];
+                }
+                for (uint32_t i = 0; i < m; ++i) ploc_apply(ca, cb, pn, nearest.data(), i, lead[i], stays[i], lead_rank[i], stays_rank[i], node_base);
+                if (nl_ == 0u || ns_ + nl_ != m) return "a PLOC iteration merged nothing";
+                node_base += nl_; m = ns_;
+                std::swap(ca, cb);
+                ++iterations;
+            }
+            if (node_base != n - 1u) return "PLOC node count";
+            if (stats) stats->ploc_iterations = iterations;
+            for (uint32_t k = 0; k < n; ++k) { leaf_pos[k] = ploc_first_position(pn, n - 1u, kLeafBit | k); order2[leaf_pos[k]] = order[k]; }
+            for (uint32_t id = 0; id + 1 < n; ++id) rnodes[n - 2u - id] = ploc_finish(pn, n - 1u, id, leaf_pos.data(), pin.data(), plf.data());
+            order.swap(order2);
+        }
+        /* 5. segment tree of boxes */
+        while (N < n) N <<= 1;
+        tmin.resize((size_t) 2 * N); tmax.resize((size_t) 2 * N);
+        for (uint32_t k = 0; k < N; ++k) {
+            f4 mn4, mx4;
+            if (k < n) tri_leaf_box(pos, idx, order[k], pad, mn4, mx4);
+            else { mn4.x = mn4.y = mn4.z = kInf; mx4.x = mx4.y = mx4.z = -kInf; mn4.w = mx4.w = 0.0f; }
+            tmin[N + k] = mn4; tmax[N + k] = mx4;
+        }
+        for (uint32_t i = N - 1; i >= 1; --i) seg_tree_combine(i, tmin.data(), tmax.data());
+        /* 6. leaves */
+        CollapseParams cp; cp.c_pair = 1.5f; cp.c_node = 1.0f;
+        for (uint32_t i = 0; i + 1 < n; ++i) collapse[i] = collapse_decide(rnodes.data(), i, tmin.data(), tmax.data(), N, cp);
+        for (uint32_t i = 0; i + 1 < n; ++i) keep[i] = mark_leaves(rnodes.data(), i, collapse.data(), pin.data(), leaf_cnt.data(), leaf_pairs.data());
+        if (stats) {      /* cost of the tree as built: node areas + leaf areas x pairs, relative to the root's area */
+            f3 a, b; range_box(tmin.data(), tmax.data(), N, 0, n - 1, a, b);
+            double root_area = 0.0, cost = 0.0;
+            /* unbounded triangles (infinite boxes) would make every number infinite: measure the bounded part */
+            for (uint32_t i = 0; i + 1 < n; ++i) {
+                if (!keep[i]) continue;
+                range_box(tmin.data(), tmax.data(), N, rnodes[i].lo, rnodes[i].hi, a, b);
+                const double area = box_area(a, b);
+                if (!(area < 1e30)) continue;
+                if (area > root_area) root_area = area;
+                cost += area * cp.c_node;
+                for (uint32_t child : {rnodes[i].left, rnodes[i].right}) {
+                    uint32_t lo, hi;
+                    if (!child_range(rnodes.data(), collapse.data(), child, lo, hi)) continue;
+                    range_box(tmin.data(), tmax.data(), N, lo, hi, a, b);
+                    cost += (double) box_area(a, b) * ((hi - lo + 2) / 2) * cp.c_pair;
+                }
+            }
+            stats->sah_cost = root_area > 0.0 ? (float) (cost / root_area) : 0.0f;
+        }
+    }
+    for (uint32_t k = 1; k < n; ++k) pair_start[k] = pair_start[k - 1] + leaf_pairs[k - 1];
+    const uint32_t n_pairs = pair_start[n - 1] + leaf_pairs[n - 1] + pair_base;
+    out.n_pairs = n_pairs;
+    out.tris.assign((size_t) std::max<uint32_t>(n_pairs, 1) * kPairQuads, f4{0.0f, 0.0f, 0.0f, 0.0f});
+    for (uint32_t k = 0; k < n; ++k)
+        if (leaf_cnt[k]) emit_leaf_pairs(pos, idx, scene.tri_mesh.data(), order.data(), k, leaf_cnt[k], out.tris.data() + (size_t) (pair_start[k] + pair_base) * kPairQuads);
+
+    if (n <= 4) {
+        out.nodes.assign(kNodeQuads, f4{0.0f, 0.0f, 0.0f, 0.0f});
+        out.root = (int32_t) ~((0u << 3) | ((n + 1u) / 2u - 1u));
+        out.n_nodes = 0; out.n_leaves = 1; out.max_depth = 0;
+    } else if (wide) {
+        std::vector<uint32_t> kids((size_t) n * 4, 0u), n_kids(n, 0u), is_wide(n, 0u), wide_index(n, 0u), frontier{0u}, next;
+        is_wide[0] = 1u;
+        uint32_t levels = 0;
+        while (!frontier.empty()) {
+            next.clear();
+            for (uint32_t i : frontier) {
+                uint32_t kid[4];
+                const int nk = wide_children(rnodes.data(), collapse.data(), tmin.data(), tmax.data(), N, i, kid);
+                n_kids[i] = (uint32_t) nk;
+                for (int k = 0; k < nk; ++k) {
+                    kids[4 * (size_t) i + k] = kid[k];
+                    uint32_t lo, hi;
+                    if (!child_range(rnodes.data(), collapse.data(), kid[k], lo, hi)) { is_wide[kid[k]] = 1u; next.push_back(kid[k]); }
+                }
+            }
+            frontier.swap(next);
+            if (++levels > 4096) return "wide levels did not terminate";
+        }
+        uint32_t n_wide = 0;
+        for (uint32_t i = 0; i + 1 < n; ++i) { wide_index[i] = n_wide; n_wide += is_wide[i]; }
+        out.nodes.assign((size_t) std::max<uint32_t>(n_wide, 1) * kNodeQuads, f4{0.0f, 0.0f, 0.0f, 0.0f});
+        for (uint32_t i = 0; i + 1 < n; ++i)
+            if (is_wide[i]) emit_wide_node(rnodes.data(), tmin.data(), tmax.data(), N, collapse.data(), pair_start.data(), wide_index.data(),
+                                           kids.data() + 4 * (size_t) i, (int) n_kids[i], out.nodes.data() + (size_t) wide_index[i] * kNodeQuads);
+        out.root = 0; out.n_nodes = n_wide; out.n_leaves = 0; out.max_depth = 3 * levels; out.wide = true;
+    } else {
+        uint32_t n_nodes = 0;
+        for (uint32_t i = 0; i + 1 < n; ++i) { node_index[i] = n_nodes; n_nodes += keep[i]; }
+        out.nodes.assign((size_t) std::max<uint32_t>(n_nodes, 1) * kNodeQuads, f4{0.0f, 0.0f, 0.0f, 0.0f});
+        for (uint32_t i = 0; i + 1 < n; ++i)
+            if (keep[i]) emit_node(rnodes.data(), i, tmin.data(), tmax.data(), N, collapse.data(), pair_start.data(), node_index.data(),
+                                   out.nodes.data() + (size_t) node_index[i] * kNodeQuads);
+        uint32_t depth = 0;
+        for (uint32_t k = 0; k < n; ++k) depth = std::max(depth, leaf_depth(pin.data(), plf.data(), k));
+        out.root = 0; out.n_nodes = n_nodes; out.n_leaves = 0; out.max_depth = depth;
+    }
+    if (stats) out.sah_cost = stats->sah_cost;
+    return std::string();
+}
+
+} // namespace nrt

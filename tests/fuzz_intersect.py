@@ -1,5 +1,5 @@
 """Randomised bit-exactness sweep of Accel::rayIntersect on the device against the oracle's linear scan
-(the reference's algorithm, src/accel.cpp:23-99): many seeds x scene shapes x both BVH builders.
+(the reference's algorithm, src/accel.cpp:23-99): many seeds x scene shapes x all BVH builders.
 
     python tests/fuzz_intersect.py [--seconds 60] [--seed 0]
 
@@ -27,6 +27,7 @@ from tests.scenes import lookat  # noqa: E402
 
 FIELDS = ("p", "t", "uv", "sh_s", "sh_t", "sh_n", "geo_s", "geo_t", "geo_n", "mesh", "tri")
 TOLERATED = [0]      # rays whose mismatch was ill-posed in the reference (see ill_posed)
+BUILDERS = (0, 1, 3)          # host SAH, device radix tree, device PLOC
 
 
 def make_meshes(rng, kind, n, scale):
@@ -120,7 +121,7 @@ def one_round(seed, renderer_cls, n_rays=20000, verbose=False):
     tris = [m.positions[m.indices.astype(np.int64)] for m in meshes]       # [mesh][tri] -> 3x3
     o = Oracle(sc)
     a, sa = o.intersect(rays), o.intersect(rays, True)
-    for builder in (0, 1):
+    for builder in BUILDERS:
         r = renderer_cls(0).upload(sc, builder=builder)
         b, sb = r.intersect(rays), r.intersect(rays, True)
         r.close()

@@ -291,7 +291,11 @@ def test_wide_nodes_fuzz_and_render():
             self.e.close()
 
     fuzz_intersect.TOLERATED[0] = 0
-    hits = sum(fuzz_intersect.one_round(seed, R, n_rays=3000) for seed in range(7000, 7040))
+    saved, fuzz_intersect.BUILDERS = fuzz_intersect.BUILDERS, (0, 1)      # the harness builds one tree whatever the id
+    try:
+        hits = sum(fuzz_intersect.one_round(seed, R, n_rays=3000) for seed in range(7000, 7040))
+    finally:
+        fuzz_intersect.BUILDERS = saved
     assert hits > 20000 and fuzz_intersect.TOLERATED[0] == 0
     sc = scenes.cornell_box(40, 24, 4, "path_mis", sphere_bsdfs=[Bsdf("mirror"), Bsdf("dielectric")])
     a, sa = _with_layout("bvh2", lambda: Emu(sc)).render_host(count_traversal=True)
@@ -301,3 +305,81 @@ def test_wide_nodes_fuzz_and_render():
     assert np.array_equal(a, b)
     assert (sa["n_closest_rays"], sa["n_shadow_rays"]) == (sb["n_closest_rays"], sb["n_shadow_rays"])
     assert sb["n_node_tests"] < 0.75 * sa["n_node_tests"]          # four boxes per node record: far fewer node visits
+
+
+def _with_env(env, fn):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+@pytest.mark.parametrize("layout", ["bvh2", "bvh4q"])
+@pytest.mark.parametrize("n_tris,seed", [(1, 3), (4, 9), (5, 5), (6, 2), (37, 8), (300, 6), (20000, 7)])
+def test_device_builders_same_hits_as_brute_force(builder, layout, n_tris, seed):
+    """The steps of the DEVICE builders (lbvh_steps.h: Morton keys, radix tree / PLOC clustering, left-to-right leaf order,
+    leaf collapse, pair / node / wide-node emission) run as loops on the CPU (tests/emu/emu_builder.h): the trees they emit
+    give hit records bit-identical to the oracle's linear scan (src/accel.cpp:30-40)."""
+    sc = scenes.soup_scene(n_tris, seed)
+    rays = scenes.random_rays(20000, seed=seed + 10)
+    rays["d"][:300, 0] = 0.0
+    e = _with_env({"NORI_EMU_BUILDER": builder, "NORI_HIP_ACCEL_LAYOUT": layout, "NORI_HIP_PLOC_RADIUS": "3" if n_tris < 100 else "16"}, lambda: Emu(sc))
+    o = Oracle(sc)
+    a, b = o.intersect(rays), e.intersect(rays)
+    for k in a.dtype.names:
+        assert np.array_equal(a[k], b[k], equal_nan=a[k].dtype.kind == "f"), k
+    assert np.array_equal(o.intersect(rays, True)["mesh"], e.intersect(rays, True)["mesh"])
+
+
+@pytest.mark.parametrize("builder", ["lbvh", "ploc"])
+def test_device_builders_fuzz(builder):
+    """The fuzzer's scene shapes (degenerate and numerically collinear triangles -> unbounded boxes, which PLOC must keep out of
+    the spatial clusters; duplicates, sheets, scales 1e-3 .. 1e3) through the device builders' steps, both node layouts."""
+    from tests import fuzz_intersect
+
+    for layout in ("bvh2", "bvh4q"):
+        class R:
+            def __init__(self, dev):
+                pass
+
+            def upload(self, sc, builder_id=0, **kw):
+                self.e = _with_env({"NORI_EMU_BUILDER": builder, "NORI_HIP_ACCEL_LAYOUT": layout}, lambda: Emu(sc))
+                return self
+
+            def intersect(self, rays, shadow=False):
+                return self.e.intersect(rays, shadow)
+
+            def close(self):
+                self.e.close()
+
+        fuzz_intersect.TOLERATED[0] = 0
+        saved, fuzz_intersect.BUILDERS = fuzz_intersect.BUILDERS, (0,)      # the harness builds the tree NORI_EMU_BUILDER names
+        try:
+            hits = sum(fuzz_intersect.one_round(seed, R, n_rays=2000) for seed in range(8000, 8030))
+        finally:
+            fuzz_intersect.BUILDERS = saved
+        assert hits > 2500 and fuzz_intersect.TOLERATED[0] == 0
+
+
+def test_ploc_trees_cost_less_than_radix_trees():
+    """What PLOC is for: on the Cornell box and on a patch of terrain its trees need fewer node and triangle tests per ray than
+    the radix tree over the same Morton order (and stay within 10 % of the host SAH builder's)."""
+    from nori_amd import workloads
+    for name, kw in (("pa4-cbox-path_mis", {}), ("c5-terrain-10m", {"triangles": 20000})):
+        sc = workloads.load(name, width=32, height=32, spp=2, **kw).scene
+        cost = {}
+        for b in ("sah", "lbvh", "ploc"):
+            e = _with_env({"NORI_EMU_BUILDER": b, "NORI_HIP_ACCEL_LAYOUT": "bvh4q"}, lambda: Emu(sc))
+            _, st = e.render_host(count_traversal=True)
+            cost[b] = (st["n_node_tests"] + 2.0 * st["n_tri_tests"]) / (st["n_closest_rays"] + st["n_shadow_rays"])
+            e.close()
+        assert cost["ploc"] < cost["lbvh"], (name, cost)
+        assert cost["ploc"] < 1.10 * cost["sah"], (name, cost)

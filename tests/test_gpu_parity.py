@@ -224,12 +224,14 @@ def test_error_behaviour():
     r.close()
 
 
-@pytest.mark.parametrize("n_tris,seed", [(1, 3), (3, 4), (5, 5), (300, 6), (20000, 7)])
-def test_gpu_lbvh_builder_same_hits_as_brute_force(renderer_factory, n_tris, seed):
-    """Accel::build on the device (Morton / radix-tree LBVH): any valid BVH must give the scan's answers."""
+@pytest.mark.parametrize("builder", [1, 3])
+@pytest.mark.parametrize("n_tris,seed", [(1, 3), (3, 4), (5, 5), (6, 2), (300, 6), (20000, 7)])
+def test_gpu_lbvh_builder_same_hits_as_brute_force(renderer_factory, n_tris, seed, builder):
+    """Accel::build on the device (1: Morton order + radix tree, 3: Morton order + PLOC clustering): any valid BVH must give the
+    scan's answers."""
     sc = scenes.soup_scene(n_tris, seed)
     rays = scenes.random_rays(50000, seed=seed + 20)
-    r, o = renderer_factory(sc, builder=1), Oracle(sc)
+    r, o = renderer_factory(sc, builder=builder), Oracle(sc)
     info = r.accel_info()
     assert info["n_triangles"] == n_tris and info["max_depth"] < 64
     a, b = o.intersect(rays), r.intersect(rays)
@@ -244,11 +246,16 @@ def test_gpu_lbvh_render_equals_sah_render(renderer_factory):
     import os
     sc = Scene.load_npz(os.path.join(os.path.dirname(__file__), "golden", "pa5-cbox_mis.npz"))
     sc.camera.width, sc.camera.height, sc.sample_count = 160, 120, 8
-    a, sa = renderer_factory(sc, builder=0).render_host()
-    b, sb = renderer_factory(sc, builder=1).render_host()
-    # same hits -> same paths: images differ by float summation order only
-    np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-5)
-    assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
+    a, sa = renderer_factory(sc, builder=0).render_host(count_traversal=True)
+    cost = {0: sa["n_node_tests"] + 2 * sa["n_tri_tests"]}
+    for builder in (1, 3):
+        b, sb = renderer_factory(sc, builder=builder).render_host(count_traversal=True)
+        # same hits -> same paths: images differ by float summation order only
+        np.testing.assert_allclose(b, a, rtol=1e-4, atol=1e-5)
+        assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
+        cost[builder] = sb["n_node_tests"] + 2 * sb["n_tri_tests"]
+    print(f"[builders] node + 2 x triangle tests per frame: host SAH {cost[0]}, radix tree {cost[1]}, PLOC {cost[3]}")
+    assert cost[3] < cost[1]              # what the clustering is for
 
 
 def test_gpu_lbvh_large_scene_build(renderer_factory):
@@ -262,13 +269,16 @@ def test_gpu_lbvh_large_scene_build(renderer_factory):
     sc = scenes.soup_scene(1)
     sc.meshes = [Mesh(tri, np.arange(3 * nt, dtype=np.uint32).reshape(nt, 3))]
     rays = scenes.random_rays(20000, seed=4)
-    r1 = renderer_factory(sc, builder=1)
-    info = r1.accel_info()
-    assert info["build_ms"] < 2000 and info["max_depth"] < 64
     r0 = renderer_factory(sc, builder=0)
-    a, b = r0.intersect(rays), r1.intersect(rays)
-    for k in ITS_FIELDS:
-        assert np.array_equal(a[k], b[k]), k
+    a = r0.intersect(rays)
+    for builder in (1, 3):
+        r1 = renderer_factory(sc, builder=builder)
+        info = r1.accel_info()
+        print(f"[builders] 1 M triangles, builder {builder}: {info['build_ms']:.1f} ms, {info['n_nodes']} nodes, depth {info['max_depth']}")
+        assert info["build_ms"] < 2000 and info["max_depth"] < 64
+        b = r1.intersect(rays)
+        for k in ITS_FIELDS:
+            assert np.array_equal(a[k], b[k]), k
 
 
 @pytest.mark.parametrize("radius,engine", [(0.5, "megakernel"), (3.4, "megakernel"), (4.6, "wavefront"), (8.4, "megakernel"), (8.4, "wavefront")])
@@ -293,7 +303,7 @@ def test_film_radius_beyond_limit_fails_loudly(renderer_factory):
 
 
 def test_fuzz_intersect_short():
-    """A few rounds of tests/fuzz_intersect.py (randomised scene shapes, both BVH builders, bit-exact hits).
+    """A few rounds of tests/fuzz_intersect.py (randomised scene shapes, all three BVH builders, bit-exact hits).
     The fuzzer exempts a mismatching ray only when the reference's own answer is ill-posed (ray within
     2e-3 rad of the triangle's plane); the exemptions are counted, logged, and on these seeds there are none."""
     from nori_amd.render import Renderer
@@ -302,7 +312,7 @@ def test_fuzz_intersect_short():
     hits = 0
     for seed in range(1000, 1015):
         hits += fuzz_intersect.one_round(seed, Renderer, n_rays=8000)
-    print(f"[fuzz] {hits} hits bit-identical on both builders, {fuzz_intersect.TOLERATED[0]} ill-posed rays exempted")
+    print(f"[fuzz] {hits} hits bit-identical on all builders, {fuzz_intersect.TOLERATED[0]} ill-posed rays exempted")
     assert hits > 10000
     assert fuzz_intersect.TOLERATED[0] == 0, f"{fuzz_intersect.TOLERATED[0]} rays needed the ill-posed exemption"
 
@@ -362,7 +372,7 @@ def test_wide_nodes_on_device(renderer_factory):
     class WideRenderer(Renderer):
         def upload(self, sc, build=True, builder=0):
             self.set_option("accel_layout", "bvh4q")
-            return super().upload(sc, build, builder)      # the fuzzer passes both builders: host SAH and device LBVH
+            return super().upload(sc, build, builder)      # the fuzzer passes every builder: host SAH, device radix tree, device PLOC
 
     fuzz_intersect.TOLERATED[0] = 0
     hits = sum(fuzz_intersect.one_round(seed, WideRenderer, n_rays=8000) for seed in range(3000, 3012))
