@@ -533,7 +533,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     ctx->have_accel = false;
     int layout = ctx->accel_layout;
     if (const char *e = getenv("NORI_HIP_ACCEL_LAYOUT")) layout = std::string(e) == "bvh4q" ? 1 : (std::string(e) == "bvh2" ? 0 : -1);
-    const bool want_wide = layout == 1 || (layout < 0 && ctx->dev.n_triangles >= (1u << 20));
+    const bool want_wide = layout == 1 || (layout < 0 && ctx->dev.n_triangles >= (1u << 18));      /* measured: 22 k triangles BVH2 +3 %, 328 k wide +10 %, 10 M wide +50 % */
     if (builder != NORI_ACCEL_HOST_SAH && ctx->dev.n_triangles > 0) {
         LbvhDeviceResult res;
         uint32_t ploc_radius = builder == NORI_ACCEL_GPU_PLOC ? 8u : 0u;      /* 8, 16, 32 give the same trees within 1 % (tools/builder_probe.py); 8 builds fastest */

@@ -140,7 +140,7 @@ int emu_create(const nori_scene_desc *scene, emu_ctx **out) {
     std::string err = prepare_scene(*scene, c->host);
     /* node layout as the library picks it (nori_hip_build_accel): NORI_HIP_ACCEL_LAYOUT=bvh4q forces wide nodes */
     const char *lay = std::getenv("NORI_HIP_ACCEL_LAYOUT");
-    const bool wide = lay ? std::string(lay) == "bvh4q" : c->host.tri_mesh.size() >= ((size_t) 1 << 20);
+    const bool wide = lay ? std::string(lay) == "bvh4q" : c->host.tri_mesh.size() >= ((size_t) 1 << 18);
     /* NORI_EMU_BUILDER=lbvh | ploc: the DEVICE builders' steps run on the CPU (emu_builder.h) instead of the host SAH builder */
     const char *bld = std::getenv("NORI_EMU_BUILDER");
     const std::string builder = bld ? bld : "sah";
