@@ -390,12 +390,14 @@ def test_wide_nodes_on_device(renderer_factory):
         assert sa[k] == sb[k], k
     assert sb["n_node_tests"] < 0.6 * sa["n_node_tests"]
     assert_image_parity(Oracle(sc, use_bvh=True).render_host()[0], B, b.border, "pa5-table_mis wide nodes")
-    c = Renderer(0); c.set_option("accel_layout", "bvh4q"); c.upload(sc, builder=1)      # wide nodes emitted on the device (lbvh.hip)
-    assert c.accel_info()["node_children"] == 4
-    C_, sc_ = c.render_host()
-    np.testing.assert_allclose(C_, A, rtol=1e-4, atol=1e-5)                                # same hits -> same paths; film summation order only
-    assert sc_["n_closest_rays"] == sa["n_closest_rays"] and sc_["n_shadow_rays"] == sa["n_shadow_rays"]
-    a.close(); b.close(); c.close()
+    for builder in (1, 3):                                                                 # wide nodes emitted on the device (lbvh.hip): radix tree, PLOC
+        c = Renderer(0); c.set_option("accel_layout", "bvh4q"); c.upload(sc, builder=builder)
+        assert c.accel_info()["node_children"] == 4
+        C_, sc_ = c.render_host()
+        np.testing.assert_allclose(C_, A, rtol=1e-4, atol=1e-5)                            # same hits -> same paths; film summation order only
+        assert sc_["n_closest_rays"] == sa["n_closest_rays"] and sc_["n_shadow_rays"] == sa["n_shadow_rays"]
+        c.close()
+    a.close(); b.close()
 
 
 
