@@ -35,6 +35,7 @@ import glob
 import hashlib
 import json
 import os
+import re
 import subprocess
 import sys
 import time
@@ -119,6 +120,8 @@ def device_source_sha() -> str:
         if f.endswith((".hip", ".h", ".cpp")):
             h.update(os.path.basename(f).encode())
             h.update(open(f, "rb").read())
+    m = re.search(r"^HIP_FLAGS = (.*)$", open(os.path.join(ROOT, "__graft_entry__.py")).read(), re.M)      # the build flags are part of the build
+    h.update((m.group(1) if m else "").encode())
     return h.hexdigest()[:16]
 
 

@@ -26,6 +26,8 @@ def source_sha():
     for f in sorted(glob.glob(os.path.join(ROOT, "nori_amd", "csrc", "device", "*"))):
         if f.endswith((".hip", ".h", ".cpp")):
             h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    m = re.search(r"^HIP_FLAGS = (.*)$", open(os.path.join(ROOT, "__graft_entry__.py")).read(), re.M)      # as bench.py device_source_sha
+    h.update((m.group(1) if m else "").encode())
     return h.hexdigest()[:16]
 
 
