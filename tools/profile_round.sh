@@ -1,10 +1,10 @@
 # One round's profile set for bench.py's roofline (run on the GPU box):
 #   bash tools/profile_round.sh <tag> [workload]      -> gpurun_out/prof_<tag>/, then copy the summaries into profiles/
-#   1. the bench line itself                                   <tag>_bench.json
 #   2. rocprofv3 --kernel-trace --stats of the same command    <tag>_kernel_stats.csv
 #   3. counter passes (each its own rocprofv3 run, --kernel-trace only), ONE render pass each (tools/wf_probe.py, REPS=1):
 #      SQ issue / SQ mix / TCC hit-miss / FETCH_SIZE / WRITE_SIZE   <tag>_<pass>_counter_collection.csv
 #   4. tools/summarize_profile.py -> <tag>_counters.json  (what bench.py's `traffic` / `valu_busy_frac` read)
+#   5. the bench line itself, with those counters in place      <tag>_bench.json
 set -u
 TAG=${1:-r2}
 WL=${2:-pa4-cbox-path_mis}
@@ -12,7 +12,6 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 B="python bench.py --steps 3 --warmup 1 --workload $WL"
-timeout 600 $B 2>$OUT/bench.err | tail -1 > $OUT/${TAG}_bench.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o s -- $B --no-cpu-baseline > $OUT/stats.log 2>&1
 find /tmp/prof_stats -name '*kernel_stats.csv' -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 rm -rf /tmp/prof_stats
@@ -29,4 +28,7 @@ run_pass tcc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE
 run_pass fetch FETCH_SIZE
 run_pass write WRITE_SIZE
 python tools/summarize_profile.py $OUT $TAG $WL > $OUT/${TAG}_summary.txt 2>&1
+# the bench line last, with the counters of THIS build in place (bench.py reads profiles/*_counters.json matched by build hash)
+cp $OUT/${TAG}_counters.json profiles/
+timeout 600 $B 2>$OUT/bench.err | tail -1 > $OUT/${TAG}_bench.json
 cat $OUT/${TAG}_summary.txt; cat $OUT/${TAG}_bench.json
