@@ -227,8 +227,12 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     if (dev.n_triangles <= 4) wide = false;                  /* a single leaf: no nodes at all */
     const uint32_t pair_base = wide ? 1u : 0u;               /* wide trees reserve pair 0 as the all-zero pair of unused slots */
     const uint32_t n = dev.n_triangles;
-    hipEvent_t e0, e1;
-    LB_TRY(hipEventCreate(&e0)); LB_TRY(hipEventCreate(&e1));
+    struct Events {      /* released on every return path */
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void) hipEventDestroy(a); if (b) (void) hipEventDestroy(b); }
+    } ev;
+    LB_TRY(hipEventCreate(&ev.a)); LB_TRY(hipEventCreate(&ev.b));
+    const hipEvent_t e0 = ev.a, e1 = ev.b;
     LB_TRY(hipEventRecord(e0, 0));
 
     if (n == 0) return "lbvh: empty scene";
@@ -424,7 +428,6 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     LB_TRY(hipEventRecord(e1, 0));
     LB_TRY(hipEventSynchronize(e1));
     LB_TRY(hipEventElapsedTime(&out.build_ms, e0, e1));
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     return std::string();
 }
 
