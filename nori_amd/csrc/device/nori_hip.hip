@@ -440,6 +440,12 @@ static int upload(nori_hip_ctx *ctx, std::vector<void *> &pool, const std::vecto
     return NORI_OK;
 }
 
+/* rt_top.h: one thread walks the first levels of the finished tree (any builder, either layout) and writes the image of
+   its hottest records -- a few dozen dependent loads, once per acceleration structure */
+__global__ void top_image_kernel(DevScene sc, f4 *image) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) top_image_build(sc.nodes, sc.tris, sc.root, sc.wide != 0u, sc.n_triangles, image);
+}
+
 static void free_pool(std::vector<void *> &pool) {
     for (void *p : pool) (void) hipFree(p);
     pool.clear();
@@ -576,6 +582,16 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     }
     ctx->dev.root = ctx->bvh.root;
     ctx->dev.wide = ctx->bvh.wide ? 1u : 0u;
+    ctx->dev.top_image = nullptr;
+    if (ctx->dev.n_triangles > 0 && getenv("NORI_HIP_NO_TOP_IMAGE") == nullptr) {      /* what wf_extend keeps in LDS (rt_top.h) */
+        void *img = nullptr;
+        HIP_TRY(ctx, hipMalloc(&img, kTopImageQuads * sizeof(f4)));
+        ctx->allocs_accel.push_back(img);
+        hipLaunchKernelGGL(top_image_kernel, dim3(1), dim3(64), 0, 0, ctx->dev, reinterpret_cast<f4 *>(img));
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        ctx->dev.top_image = reinterpret_cast<const f4 *>(img);
+    }
     ctx->stack_depth = ctx->bvh.max_depth + 1 <= 32 ? 32 : 64;
     nori_accel_info &in = ctx->info;
     in.n_triangles = ctx->dev.n_triangles; in.n_nodes = ctx->bvh.n_nodes; in.n_leaves = ctx->bvh.n_leaves;

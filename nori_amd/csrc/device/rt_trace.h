@@ -15,6 +15,15 @@
  */
 #pragma once
 #include "rt_types.h"
+#include "rt_top.h"
+
+#if defined(NORI_TRAV_HISTOGRAM) && !defined(__HIP_DEVICE_COMPILE__)
+/* CPU harness only (tools/trav_histogram.py): visits per node and per leaf pair record */
+extern "C" void nori_trav_hist(int kind, uint32_t index);
+#define NORI_HIST(kind, index) nori_trav_hist(kind, index)
+#else
+#define NORI_HIST(kind, index) ((void) 0)
+#endif
 
 namespace nrt {
 
@@ -126,21 +135,27 @@ NORI_HD void trav_pop(Stack &stack, Trav &tv) {
     tv.node = stack.pop_or(kTravDone);
 }
 
-/* The top of the tree in LDS.  Every ray starts at the root, so the few nodes of the first levels are fetched by every lane
- * of every wave -- and a per-lane 64-B node fetch is four 16-B accesses of the CU's vector L1, which serves ONE access per
- * clock: counters show wf_extend at 1.04 L1 accesses per clock per CU (profiles/r2_02_*tcp*), i.e. bound by the L1's tag
- * rate, not by VALU or HBM.  A kernel that keeps the first kTopNodes nodes (breadth first from the root) in LDS takes the
- * first ~5 of a ray's ~9 node steps out of the L1.  Links to cached nodes carry kTopBit and the LDS slot; cached records
- * are kTopStrideQuads * 16 B apart (80 B: consecutive slots start in different banks). */
-constexpr int kTopNodes = 32;
-constexpr int kTopStrideQuads = 5;
-constexpr int kTopBit = 0x40000000;          /* node indices stay below 2^30 */
+/* The hot part of the tree in LDS: rt_top.h (which records, the image layout, the link codes). */
+/* the four quads of node `node`: from the LDS cache (`top` non-null and the link carries kTopBit) or from memory.
+   On the device the cache is reached through an LDS-address-space pointer: two exec-masked paths, ds_read_b128 for the
+   cached nodes and global_load_dwordx4 for the others.  (With a generic pointer the compiler merges the two paths into one
+   flat_load through a selected address -- and a flat load that resolves to LDS still occupies the vector-memory address
+   path the cache was meant to relieve.) */
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float v4f_lds __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) v4f_lds *TopNodesP;
+NORI_HD f4 top_quad(TopNodesP p) { const v4f_lds v = *p; f4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r; }
+NORI_HD TopNodesP top_nodes_pointer(const f4 *generic) { return (TopNodesP) generic; }
+#else
+typedef const f4 *TopNodesP;
+NORI_HD f4 top_quad(TopNodesP p) { return *p; }
+NORI_HD TopNodesP top_nodes_pointer(const f4 *generic) { return generic; }
+#endif
 
-/* the four quads of node `node`: from the LDS cache (`top` non-null and the link carries kTopBit) or from memory */
-NORI_HD void node_fetch(const DevScene &sc, const f4 *top, int node, f4 &q0, f4 &q1, f4 &q2, f4 &q3) {
+NORI_HD void node_fetch(const DevScene &sc, TopNodesP top, int node, f4 &q0, f4 &q1, f4 &q2, f4 &q3) {
     if (top != nullptr && (node & kTopBit)) {
-        const f4 *nq = top + (node & (kTopNodes - 1)) * kTopStrideQuads;
-        q0 = nq[0]; q1 = nq[1]; q2 = nq[2]; q3 = nq[3];
+        const TopNodesP nq = top + 1 + (node & 31) * kTopStrideQuads;      /* kTopNodes <= 32 slots behind the header quad */
+        q0 = top_quad(nq); q1 = top_quad(nq + 1); q2 = top_quad(nq + 2); q3 = top_quad(nq + 3);
     } else {
         const f4 *nq = sc.nodes + (size_t) node * kNodeQuads;
         q0 = nq[0]; q1 = nq[1]; q2 = nq[2]; q3 = nq[3];
@@ -149,10 +164,11 @@ NORI_HD void node_fetch(const DevScene &sc, const f4 *top, int node, f4 &q0, f4 
 
 /* one inner-node step: both child boxes from one 64-B record */
 template <bool COUNT, class Stack>
-NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, const f4 *top = nullptr) {
+NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, TopNodesP top = nullptr) {
     f4 q0, q1, q2, q3;
     node_fetch(sc, top, tv.node, q0, q1, q2, q3);
     if (COUNT) cnt.nodes++;
+    NORI_HIST(0, (uint32_t) tv.node);
     float nl, fl, nr, fr;
     slab_two(q0, q1, q2, tv.o, tv.rcp, nl, fl, nr, fr);
     /* conservative: m carries 2.5 ulp/2 of relative error, the fma one rounding -- a far side widened by 10 u covers a ray
@@ -202,7 +218,7 @@ NORI_HD Wide4 wide_planes(uint32_t w, float A, float B) {
 }
 
 template <bool COUNT, class Stack>
-NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, const f4 *top = nullptr) {
+NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, TopNodesP top = nullptr) {
     f4 q0, q1, q2, q3;
     node_fetch(sc, top, tv.node, q0, q1, q2, q3);
     if (COUNT) cnt.nodes++;
@@ -284,17 +300,23 @@ NORI_HD void tri_pair_test(const f4 &q0, const f4 &q1, const f4 &q2, const f4 &q
     }
 }
 
-/* one leaf step: ONE PAIR of triangles, then advance within the leaf */
+/* one leaf step: ONE PAIR of triangles, then advance within the leaf.  `top`: the LDS image (rt_top.h) -- a cursor
+   with kTopBit names a pair record cached there */
 template <bool COUNT, class Stack>
-NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt) {
+NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, TopNodesP top = nullptr) {
     const uint32_t cursor = ~(uint32_t) tv.node;
+    f4 q0, q1, q2, q3, q4;
+    const bool cached = top != nullptr && (cursor & (uint32_t) kTopBit) != 0u;
+    const TopNodesP lq = top + 1 + kTopNodes * kTopStrideQuads + ((cursor >> 3) & 15u) * kPairQuads;      /* kTopPairs <= 16 */
     const f4 *tq = sc.tris + (size_t) (cursor >> 3) * kPairQuads;
-    const f4 q0 = tq[0], q1 = tq[1], q2 = tq[2], q3 = tq[3], q4 = tq[4];
+    if (cached) { q0 = top_quad(lq); q1 = top_quad(lq + 1); q2 = top_quad(lq + 2); q3 = top_quad(lq + 3); q4 = top_quad(lq + 4); }
+    else { q0 = tq[0]; q1 = tq[1]; q2 = tq[2]; q3 = tq[3]; q4 = tq[4]; }
     if (COUNT) cnt.tris += 2;
+    NORI_HIST(1, cursor >> 3);
     TriPairHit r;
     tri_pair_test(q0, q1, q2, q3, q4, tv.o, tv.d, tv.mint, tv.hit.t, r);
     if (r.ok[0] || r.ok[1]) {
-        const f4 q5 = tq[5];
+        const f4 q5 = cached ? top_quad(lq + 5) : tq[5];
         if (tv.any) {
             const int k = r.ok[0] ? 0 : 1;
             tv.hit.tri = f2u(k == 0 ? q4.z : q4.w); tv.hit.t = r.t[k]; tv.node = kTravDone;
@@ -315,16 +337,25 @@ NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
 }
 
 /* Run a traversal to completion (batch kernels, tests).
- * Returns true if something was hit; for closest-hit `hit` holds t,u,v,tri,mesh. */
+ * Returns true if something was hit; for closest-hit `hit` holds t,u,v,tri,mesh.
+ * In the CPU harness the walk goes through the image of the hot records (rt_top.h) when the scene has one -- the links
+ * and records wf_extend reads from LDS, checked there against the brute-force scan; on the device this function serves
+ * the batch twins and wf_finish, which keep nothing in LDS. */
 template <bool COUNT, class Stack>
 NORI_HD bool traverse(const DevScene &sc, const RayIn &ray, bool any, Stack &stack, Hit &hit, TraversalCounters &cnt) {
     Trav tv;
     trav_begin<kLayoutAny>(sc, ray, any, stack, tv);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const TopNodesP top = nullptr;
+#else
+    const TopNodesP top = sc.top_image;
+    if (top != nullptr && trav_active(tv)) tv.node = (int) f2u(top[0].x);
+#endif
     while (trav_active(tv)) {
         if (trav_at_inner(tv)) {
-            if (sc.wide) trav_wide_step<COUNT>(sc, stack, tv, cnt);
-            else trav_inner_step<COUNT>(sc, stack, tv, cnt);
-        } else trav_leaf_step<COUNT>(sc, stack, tv, cnt);
+            if (sc.wide) trav_wide_step<COUNT>(sc, stack, tv, cnt, top);
+            else trav_inner_step<COUNT>(sc, stack, tv, cnt, top);
+        } else trav_leaf_step<COUNT>(sc, stack, tv, cnt, top);
     }
     hit = tv.hit;
     return hit.tri != kNoHit;

@@ -309,6 +309,7 @@ struct DevScene {
     const uint32_t *emitters;   /* mesh ids of emitters */
     const uint32_t *tri_mesh;   /* mesh id per global triangle */
     const f4 *shade_tris;       /* kShadeQuads per global triangle: the shading data pre-gathered */
+    const f4 *top_image;        /* the hot records of the tree as wf_extend keeps them in LDS (rt_top.h), or null */
     uint32_t n_emitters;
     uint32_t n_meshes;
     uint32_t n_triangles;

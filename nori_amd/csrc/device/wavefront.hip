@@ -135,40 +135,41 @@ struct LdsStackW<DEPTH, false> {
 
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
 
-/* Copies the first kTopNodes nodes of the tree, breadth first from the root, into the workgroup's LDS cache (rt_trace.h,
-   node_fetch) and rewrites the links between cached nodes to kTopBit | slot.  Works on any node order (host SAH: depth
-   first; device LBVH: radix order) and both layouts (links are q3.x, q3.y [, q3.z, q3.w]; inner = non-negative).
-   Returns the link a walk starts with.  s_q / s_cnt: 32 + 2 ints of LDS scratch. */
-__device__ int top_nodes_to_lds(const DevScene &sc, f4 *top, int *s_q, int *s_cnt) {
-    if (sc.n_triangles == 0u || sc.root < 0) return sc.root;            /* empty scene, or the root is a leaf */
-    const int tid = (int) threadIdx.x, n_links = sc.wide ? 4 : 2;
-    if (tid == 0) { s_q[0] = sc.root; s_cnt[0] = 1; }
-    __syncthreads();
-    int head = 0;
-    while (true) {
-        const int end = min(s_cnt[0], kTopNodes);                        /* this level: slots [head, end) */
-        __syncthreads();
-        if (head >= end) break;
-        if (head + tid < end) {
-            const int slot = head + tid;
-            const f4 *nq = sc.nodes + (size_t) s_q[slot] * kNodeQuads;
-            const f4 q0 = nq[0], q1 = nq[1], q2 = nq[2];
-            f4 q3 = nq[3];
-            auto adopt = [&](float &link_bits) {                          /* an inner child gets a slot while there is room */
-                const int child = (int) __float_as_uint(link_bits);
-                if (child < 0) return;                                   /* leaf (or unused wide slot) */
-                const int s = atomicAdd(&s_cnt[0], 1);
-                if (s < kTopNodes) { s_q[s] = child; link_bits = __uint_as_float((uint32_t) (kTopBit | s)); }
-            };
-            adopt(q3.x); adopt(q3.y);
-            if (n_links == 4) { adopt(q3.z); adopt(q3.w); }
-            f4 *dst = top + slot * kTopStrideQuads;
-            dst[0] = q0; dst[1] = q1; dst[2] = q2; dst[3] = q3;
-        }
-        head = end;
-        __syncthreads();
+/* Streaming accesses to the path state: every record is written once and read once per pass, tens of GB -- nothing of
+   it is worth a line of L2 next to the tree.  Nontemporal where it measured faster (A/B on one box, ms per pass):
+   level 1 = wf_extend's hit / sample-position stores and wf_shade's read of the hit record (wf_extend 47.9 -> 47.2),
+   level 2 = wf_shade's state loads and stores (wf_shade 27.9 -> 27.1).  wf_extend's own state LOADS stay plain: nontemporal
+   they cost it 2 ms (the 32 B a path re-reads after its shadow ray then miss). */
+#ifndef NORI_EXP_NT
+#define NORI_EXP_NT 2
+#endif
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef float v2f_t __attribute__((ext_vector_type(2)));
+template <int LEVEL> __device__ __forceinline__ void st_f4(f4 *p, const f4 &v) {
+    if (NORI_EXP_NT >= LEVEL) { v4f_t t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p)); }
+    else *p = v;
+}
+template <int LEVEL> __device__ __forceinline__ void st_f2(f2 *p, const f2 &v) {
+    if (NORI_EXP_NT >= LEVEL) { v2f_t t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f_t *>(p)); }
+    else *p = v;
+}
+template <int LEVEL> __device__ __forceinline__ f4 ld_f4(const f4 *p) {
+    if (NORI_EXP_NT >= LEVEL) { const v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p)); f4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r; }
+    return *p;
+}
+template <int LEVEL, class T> __device__ __forceinline__ void st_w(T *p, T v) { if (NORI_EXP_NT >= LEVEL) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int LEVEL, class T> __device__ __forceinline__ T ld_w(const T *p) { if (NORI_EXP_NT >= LEVEL) return __builtin_nontemporal_load(p); return *p; }
+
+/* The hot records of the tree (rt_top.h: the image is built once per acceleration structure) into the workgroup's LDS.
+   Returns the link a walk starts with. */
+__device__ int top_image_to_lds(const DevScene &sc, f4 *top) {
+    if (sc.top_image == nullptr) {      /* no image: nothing cached, every link is a memory link */
+        if (threadIdx.x == 0) { f4 h; h.x = __uint_as_float((uint32_t) sc.root); h.y = h.z = h.w = 0.0f; top[0] = h; }
+    } else {
+        for (int q = (int) threadIdx.x; q < kTopImageQuads; q += kB) top[q] = sc.top_image[q];
     }
-    return kTopBit | 0;
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane((int) __float_as_uint(top[0].x));
 }
 
 /* The first vertex of the batch's path p is never stored: its camera sample (renderBlock,
@@ -201,8 +202,8 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
     stack.init(smem, b.stack_spill, gridDim.x * kB);
     /* the first levels of the tree in LDS (rt_trace.h, node_fetch): behind the stacks */
     f4 *top = reinterpret_cast<f4 *>(smem + (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int));
-    int *top_scratch = reinterpret_cast<int *>(top + kTopNodes * kTopStrideQuads);
-    const int root_link = top_nodes_to_lds(sc, top, top_scratch, top_scratch + kTopNodes);
+    const int root_link = top_image_to_lds(sc, top);
+    const TopNodesP top_lds = top_nodes_pointer(top);
     const WfState S = b.st[cur];
     const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
     /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
@@ -219,13 +220,14 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
        waves busy; in the long tail of a batch the static chunks cover everything and no wave
        touches the counter (a single hot word sustains only ~90 atomics/us --
        MI355X_MICROARCH.md, row "dequeue" -- which used to cost 0.2 ms per tail iteration). */
-    const uint32_t n_waves = gridDim.x * (kB / 64u), wave_id = blockIdx.x * (kB / 64u) + (threadIdx.x >> 6);
+    /* wave_id is the same in all lanes of a wave: readfirstlane tells the compiler, so the chunk cursor lives in SGPRs */
+    const uint32_t n_waves = gridDim.x * (kB / 64u), wave_id = (uint32_t) __builtin_amdgcn_readfirstlane((int) (blockIdx.x * (kB / 64u) + (threadIdx.x >> 6)));
     const uint32_t static_limit = (uint32_t) ((thresholds >> 16) & 0xfff) * n_waves;
     const uint32_t kChunk = n <= static_limit ? (((n + n_waves - 1u) / n_waves + 63u) & ~63u)      /* all static */
                                               : min(1024u, max(64u, (n / (n_waves * (uint32_t) ((thresholds >> 28) & 0xf))) & ~63u));
     const uint32_t dyn0 = n_waves * kChunk;        /* first dynamically claimed path */
     uint32_t chunk_pos = min(wave_id * kChunk, n), chunk_end = min(chunk_pos + kChunk, n);       /* wave-uniform */
-    uint32_t nClosest = 0, nShadow = 0, nCam = 0;
+    uint32_t nClosest = 0, nShadow = 0, nCam = 0;      /* wave-uniform: counted from ballots at the refill */
     uint32_t zc[Z_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};      /* wave-uniform census */
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
     while (true) {
@@ -250,27 +252,26 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                idle and write together.  An idle lane keeps its answer in tv.hit until then. */
             if (unsaved && !trav_active(tv)) {
                 if (pend) rid |= tv.hit.tri != kNoHit ? 1u : 0u;      /* the shadow ray is answered; the continuation ray of the same vertex is next */
-                else b.hit[rid >> 2] = tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u);
+                else st_f4<1>(&b.hit[rid >> 2], tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u));
                 unsaved = false;
             }
             const unsigned long long fresh = idle & ~pending;
             if (COUNT) { zc[Z_REFILLS]++; zc[Z_REFILL_LANES] += (uint32_t) nIdle; }
             const uint32_t avail = chunk_end - chunk_pos;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (fresh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) fresh, 0u));   /* set bits below this lane */
+            bool startedA = false, startedB = false;      /* this lane starts a closest-hit / a shadow query in this refill */
             if (FIRST) {
                 if (!trav_active(tv) && rank < avail) {      /* path i = camera sample i of the batch */
                     const uint32_t i = chunk_pos + rank;
                     f2 ps; RayIn ray; Rng rng;
                     if (first_vertex(sc, bt, i, ps, ray, rng)) {
-                        b.samp_pos[i] = ps;
+                        st_f2<1>(&b.samp_pos[i], ps);
                         rid = i << 2;
                         trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, false, stack, tv);
-                        ++nClosest; ++nCam;
+                        startedA = true;
                         unsaved = trav_active(tv);
                         if (unsaved) tv.node = root_link;
-                        if (!trav_active(tv)) {
-                            b.hit[i] = hit_pack(nullptr, false);
-                        }
+                        if (!trav_active(tv)) st_f4<1>(&b.hit[i], hit_pack(nullptr, false));
                     }
                 }
             } else if (pend || (!trav_active(tv) && rank < avail)) {
@@ -291,16 +292,18 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                     ray.mint = any ? kEpsilon : o.w; ray.maxt = d.w;
                     rid = pend ? (rid & ~2u) : ((i << 2) | ((any && (fl & F_HAS_A)) ? 2u : 0u));
                     trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, any, stack, tv);
-                    if (any) ++nShadow; else ++nClosest;
+                    startedA = !any; startedB = any;
                     unsaved = trav_active(tv);
                     if (unsaved) tv.node = root_link;
                     if (!trav_active(tv)) {            /* empty scene: nothing occludes, nothing is hit */
-                        if (rid & 2u) { ++nClosest; rid &= ~2u; }
-                        b.hit[i] = hit_pack(nullptr, false);
+                        if (rid & 2u) { startedA = true; rid &= ~2u; }      /* the continuation ray counts as traced, too */
+                        st_f4<1>(&b.hit[i], hit_pack(nullptr, false));
                     }
                 }
             }
             chunk_pos += min(avail, (uint32_t) __popcll(fresh));
+            { const uint32_t na = (uint32_t) __popcll(__ballot(startedA)); nClosest += na; if (FIRST) nCam += na; }
+            if (!FIRST) nShadow += (uint32_t) __popcll(__ballot(startedB));
         }
         if (__ballot(trav_active(tv)) == 0ull) {
             if (exhausted && __ballot((rid & 2u) != 0u) == 0ull) break;
@@ -313,27 +316,22 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
         do {
             if (COUNT) { const int ni = __popcll(__ballot(trav_at_inner(tv))); if (ni) { zc[Z_INNER_TRIPS]++; zc[Z_INNER_LANES] += (uint32_t) ni; } }
             if (trav_at_inner(tv)) {
-                if (WIDE) trav_wide_step<COUNT>(sc, stack, tv, tc, top);      /* BVH4, quantised boxes: scenes beyond the caches */
-                else trav_inner_step<COUNT>(sc, stack, tv, tc, top);
+                if (WIDE) trav_wide_step<COUNT>(sc, stack, tv, tc, top_lds);      /* BVH4, quantised boxes: scenes beyond the caches */
+                else trav_inner_step<COUNT>(sc, stack, tv, tc, top_lds);
             }
         } while (__popcll(__ballot(trav_at_inner(tv))) >= bt.inner_repeat);
         const bool atLeaf = trav_at_leaf(tv);
         const int nLeaf = __popcll(__ballot(atLeaf));
         const bool innerLeft = __ballot(trav_at_inner(tv)) != 0ull;
         if (COUNT && nLeaf && (nLeaf >= leaf_threshold || !innerLeft)) { zc[Z_LEAF_TRIPS]++; zc[Z_LEAF_LANES] += (uint32_t) nLeaf; }
-        if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT>(sc, stack, tv, tc);
+        if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT>(sc, stack, tv, tc, top_lds);
     }
     /* the answers still held in registers when the wave ran out of paths (no lane is pending here: the loop ends only
        when no continuation ray is left): a path with a shadow ray only ends on it (tv.any); otherwise the closest hit
        + the shadow answer */
-    if (unsaved) b.hit[rid >> 2] = tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u);
+    if (unsaved) st_f4<1>(&b.hit[rid >> 2], tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u));
     /* counters: one atomic per wave */
-    for (int off = 32; off > 0; off >>= 1) {
-        nClosest += (uint32_t) __shfl_down((int) nClosest, off);
-        nShadow += (uint32_t) __shfl_down((int) nShadow, off);
-        if (FIRST) nCam += (uint32_t) __shfl_down((int) nCam, off);
-        if (COUNT) { tc.nodes += (uint32_t) __shfl_down((int) tc.nodes, off); tc.tris += (uint32_t) __shfl_down((int) tc.tris, off); }
-    }
+    if (COUNT) for (int off = 32; off > 0; off >>= 1) { tc.nodes += (uint32_t) __shfl_down((int) tc.nodes, off); tc.tris += (uint32_t) __shfl_down((int) tc.tris, off); }
     if (lane == 0) {
         if (nClosest) atomicAdd(&b.stats[S_CLOSEST], (unsigned long long) nClosest);
         if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
@@ -381,16 +379,16 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
                 t4.x = t4.y = t4.z = t4.w = 1.0f;                  /* T = 1, eta = 1 */
                 d4.x = cam.d.x; d4.y = cam.d.y; d4.z = cam.d.z; d4.w = cam.maxt;
             } else {
-                fl = S.flags[i];
+                fl = ld_w<2>(&S.flags[i]);
             }
             if (fl & (F_HAS_A | F_HAS_B)) {
-                if (!FIRST) { sidx = S.sidx[i]; L4 = S.L_pdf[i]; }
-                const f4 h = b.hit[i];
+                if (!FIRST) { sidx = ld_w<2>(&S.sidx[i]); L4 = ld_f4<2>(&S.L_pdf[i]); }
+                const f4 h = ld_f4<1>(&b.hit[i]);
                 const uint32_t hw = __float_as_uint(h.w);
                 bool done = false;
                 if (fl & F_HAS_B) {                       /* path_on_shadow: add the emitter sample if unoccluded */
                     if (!(hw & kOccludedB)) {
-                        const f4 ld = S.Ld[i];
+                        const f4 ld = ld_f4<2>(&S.Ld[i]);
                         L4.x = L4.x + ld.x; L4.y = L4.y + ld.y; L4.z = L4.z + ld.z;
                     }
                     if (fl & F_END_AFTER_B) done = true;
@@ -398,12 +396,12 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
                 PathState st;
                 st.L = mk3(L4.x, L4.y, L4.z);
                 if (!done) {
-                    if (!FIRST) { d4 = S.dA[i]; t4 = S.T_eta[i]; }
+                    if (!FIRST) { d4 = ld_f4<2>(&S.dA[i]); t4 = ld_f4<2>(&S.T_eta[i]); }
                     Hit hit; bool found;
                     hit_unpack(sc, h, hit, found);
                     /* pcg32 stream of this camera sample: inc from the sample index, state from HBM */
                     const uint32_t sl = (sidx % per_tile) >> 8;
-                    vertex_unpack(st, fl, L4, t4, FIRST ? rng0.state : S.rng[i], ((uint64_t) (s_first + sl) << 1u) | 1u);
+                    vertex_unpack(st, fl, L4, t4, FIRST ? rng0.state : ld_w<2>(&S.rng[i]), ((uint64_t) (s_first + sl) << 1u) | 1u);
                     done = path_on_closest<INTEG>(sc, st, hit, found, mk3(d4.x, d4.y, d4.z));
                     if (!done) {
                         survive = true;
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
                 }
                 if (done) {
                     f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 0.0f;
-                    b.samp_L[sidx] = out;
+                    st_f4<2>(&b.samp_L[sidx], out);
                 }
             }
         }
@@ -438,9 +436,10 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
         }
         if (survive && !overflow) {
             const uint32_t j = off < room ? out_base + out_used + off : new_base + (off - room);
-            D.o[j] = n_o; D.T_eta[j] = n_T; D.L_pdf[j] = n_L; D.flags[j] = n_fl; D.rng[j] = n_rng; D.sidx[j] = sidx;
-            if (n_fl & F_HAS_A) D.dA[j] = n_dA;
-            if (n_fl & F_HAS_B) { D.dB[j] = n_dB; D.Ld[j] = n_Ld; }
+            st_f4<2>(&D.o[j], n_o); st_f4<2>(&D.T_eta[j], n_T); st_f4<2>(&D.L_pdf[j], n_L);
+            st_w<2>(&D.flags[j], n_fl); st_w<2>(&D.rng[j], n_rng); st_w<2>(&D.sidx[j], sidx);
+            if (n_fl & F_HAS_A) st_f4<2>(&D.dA[j], n_dA);
+            if (n_fl & F_HAS_B) { st_f4<2>(&D.dB[j], n_dB); st_f4<2>(&D.Ld[j], n_Ld); }
         }
         if (c > room) { out_base = new_base; out_used = c - room; out_len = want; }
         else out_used += c;
@@ -568,7 +567,7 @@ std::string ensure_pool(Pool &pool, size_t records) {
 
 template <int STACK, bool SPILL, bool COUNT, bool FIRST>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, const WfBatch &bt, hipStream_t s) {
-    const size_t lds = (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int) + kTopNodes * kTopStrideQuads * sizeof(f4) + (kTopNodes + 2) * sizeof(int);
+    const size_t lds = (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int) + kTopImageQuads * sizeof(f4);
     if (sc.wide) {
         /* wide trees push up to three children per step: always the spilling stack */
         if (SPILL) hipLaunchKernelGGL((wf_extend<STACK, true, COUNT, FIRST, true>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill, bt);
@@ -757,7 +756,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     if (const char *e = getenv("NORI_HIP_WF_FINISH_PATHS")) finish_paths = std::max(256, atoi(e)) & ~255;
     const int finish_grid = finish_paths / kB;
     /* LDS per workgroup: stack entries (+1: the "done" marker of the non-spilling stack) + the top-node cache */
-    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + kTopNodes * kTopStrideQuads * sizeof(f4) + (kTopNodes + 2) * sizeof(int)))));
+    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + kTopImageQuads * sizeof(f4)))));
     /* every workgroup of the persistent grid must be resident from the start (a workgroup that starts late owns a
        static share of the paths and works it off alone): the wide-node kernels are built for 6 waves per SIMD
        (their first-pass variant for 5: measured 3.47 vs 3.29 Grays/s on the terrain against 5 everywhere) */

@@ -42,6 +42,7 @@ struct emu_ctx {
     HostScene host;
     HostBvh bvh;
     DevScene dev;
+    std::vector<f4> top_image;      /* rt_top.h: the records wf_extend keeps in LDS; the harness walks through them too */
     std::string error;
 };
 
@@ -59,6 +60,12 @@ static void bind(emu_ctx *c) {
     d.n_cdf = (uint32_t) h.emitter_cdf.size();
     d.root = c->bvh.root;
     d.wide = c->bvh.wide ? 1u : 0u;
+    const char *ti = std::getenv("NORI_EMU_TOP_IMAGE");
+    if (d.n_triangles > 0 && !(ti && atoi(ti) == 0)) {
+        c->top_image.assign(kTopImageQuads, f4());
+        top_image_build(d.nodes, d.tris, d.root, d.wide != 0u, d.n_triangles, c->top_image.data());
+        d.top_image = c->top_image.data();
+    }
     d.camera = h.camera; d.filter = h.filter; d.integrator = h.integrator;
 }
 
