@@ -245,6 +245,9 @@ typedef struct nori_render_stats {
        also shades), the Li kernels (wf_shade, wf_finish) and the film kernels */
     float trace_ms, shade_ms, film_ms;
     uint32_t n_trace_launches;
+    uint32_t engine;         /* what rendered this call: 0 = megakernel (render_kernel), 1 = wavefront (wf_extend / wf_shade),
+                                2 = the block-serial kernel of NORI_SEED_NORI_BLOCK.  The option "engine" is a request: "auto"
+                                picks by job size, and trees with wide nodes are walked by the wavefront engine only */
 } nori_render_stats;
 
 typedef struct nori_accel_info {
@@ -282,6 +285,13 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene);
 /* Accel::build (src/accel.cpp:19-21 -- a no-op in the reference, a BVH here) */
 int nori_hip_build_accel(nori_hip_ctx *ctx, int builder /* nori_accel_builder */);
 int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out);
+
+/* Diagnostics of the arithmetic the device substitutes for the reference's `/`, `1 / x` and std::sqrt (Eigen's
+ * operator/ and normalized() in src/common.cpp:248-257, include/nori/frame.h, the BSDFs): out[0..2] = operands that left
+ * the domain on which the short reciprocal / quotient / square-root sequences are verified bit-identical to the IEEE
+ * operations, out[3] = results that came out NaN or infinite (rt_types.h), since the last reset.  Only the
+ * build with -DNORI_COUNT_EXCURSIONS (libnori_hip_count.so) counts; the product build returns NORI_ERR_UNSUPPORTED. */
+int nori_hip_debug_excursions(nori_hip_ctx *ctx, unsigned long long out[4], int reset);
 
 /* Tuning / engine selection (no reference counterpart).  Keys:
  *   "engine"          "auto" (default: wavefront for >= 2^24 camera samples per call,

@@ -80,7 +80,7 @@ class RenderStats(C.Structure):
                 ("n_shadow_rays", C.c_uint64), ("n_node_tests", C.c_uint64),
                 ("n_tri_tests", C.c_uint64), ("n_invalid", C.c_uint64),
                 ("kernel_ms", C.c_float), ("n_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("trace_ms", C.c_float), ("shade_ms", C.c_float), ("film_ms", C.c_float), ("n_trace_launches", C.c_uint32)]
+                ("trace_ms", C.c_float), ("shade_ms", C.c_float), ("film_ms", C.c_float), ("n_trace_launches", C.c_uint32), ("engine", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -118,6 +118,7 @@ HIP_PROTOTYPES = {
     "nori_hip_upload_scene": (C.c_int, [_P, C.POINTER(SceneDesc)]),
     "nori_hip_build_accel": (C.c_int, [_P, C.c_int]),
     "nori_hip_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
+    "nori_hip_debug_excursions": (C.c_int, [_P, _P, C.c_int]),
     "nori_hip_set_option": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
     "nori_hip_border_size": (C.c_int, [_P]),
     "nori_hip_intersect": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),

@@ -408,7 +408,7 @@ struct nori_hip_ctx {
     int stack_depth = 32;
     uint64_t lbvh_bytes = 0;
     int engine = -1;                /* -1 auto, 0 megakernel, 1 wavefront */
-    int accel_layout = -1;          /* -1 auto (wide from 2^20 triangles), 0 bvh2, 1 bvh4q (wide nodes) */
+    int accel_layout = -1;          /* -1 auto (wide from 2^18 triangles), 0 bvh2, 1 bvh4q (wide nodes) */
     bool film_reference = false;    /* film_order = reference: samples added in the reference's own order (film.h) */
     size_t wavefront_paths = (size_t) 1 << 28;     /* 240 B of state each (two copies) + film: ~80 GB of the 288 GB */
     /* render-time resources of THIS context (never shared, freed in nori_hip_destroy): the wavefront
@@ -601,6 +601,25 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     in.node_children = ctx->bvh.wide ? 4u : 2u; in.reserved = 0u;
     ctx->have_accel = true;
     return NORI_OK;
+}
+
+int nori_hip_debug_excursions(nori_hip_ctx *ctx, unsigned long long out[4], int reset) {
+    if (!ctx || !out) return NORI_ERR_INVALID_ARGUMENT;
+    out[0] = out[1] = out[2] = out[3] = 0ull;
+#if defined(NORI_COUNT_EXCURSIONS)
+    DeviceGuard g(ctx->device);
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIP_TRY(ctx, hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nori_excursions), sizeof(h)));      /* this translation unit's kernels */
+    for (int k = 0; k < 4; ++k) out[k] += h[k];
+    if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_nori_excursions), z, sizeof(z))); }
+    if (!wavefront_excursions(out, reset != 0)) { ctx->error = "debug_excursions: reading the wavefront engine's counters failed"; return NORI_ERR_INTERNAL; }
+    return NORI_OK;
+#else
+    (void) reset;
+    ctx->error = "debug_excursions: this library was built without -DNORI_COUNT_EXCURSIONS (use libnori_hip_count.so)";
+    return NORI_ERR_UNSUPPORTED;
+#endif
 }
 
 int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value) {
@@ -982,7 +1001,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         timer.end(s);
         HIP_TRY(ctx, hipGetLastError());
         if (stats) n_invalid = film_invalid_count(film, s);
-        engine = 0;      /* stats come from ctx->d_stats like the megakernel's */
+        engine = 2;      /* stats come from ctx->d_stats like the megakernel's */
     } else
     if (engine == 1 && a.n_sel_tiles > 0 && a.spp_count > 0) {
         WfLaunch wl;
@@ -1061,6 +1080,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         stats->n_camera_samples = h[0]; stats->n_closest_rays = h[1]; stats->n_shadow_rays = h[2];
         stats->n_node_tests = h[3]; stats->n_tri_tests = h[4]; stats->n_invalid = n_invalid;
         stats->kernel_ms = ms;
+        stats->engine = (uint32_t) engine;
         if (getenv("NORI_HIP_CENSUS") && h[8])
             fprintf(stderr, "[census] shade runs %llu lanes %.1f | inner runs %llu lanes %.1f | leaf runs %llu lanes %.1f\n", h[8], (double) h[9] / h[8], h[10], (double) h[11] / std::max(1ull, h[10]), h[12], (double) h[13] / std::max(1ull, h[12]));
         stats->n_workgroups = n_workgroups;

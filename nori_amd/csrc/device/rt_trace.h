@@ -32,7 +32,7 @@ struct RayIn {
     float mint, maxt;
 };
 
-/* exact_rcp (rt_types.h): no fallback branch for the operands outside its domain (it costs the traversal kernel its last
+/* exact_rcp_raw (rt_types.h): no fallback branch for the operands outside its domain (it costs the traversal kernel its last
  * free registers): a determinant beyond 8.5e37 needs scene coordinates beyond 1e12, and a denormal one is rejected by
  * |det| < 1e-8 before its reciprocal is used (src/mesh.cpp:52). */
 
@@ -41,7 +41,7 @@ struct RayIn {
  * -- yet a power of two small enough that every product the node tests form with it (centre and half-extent form of
  * the BVH2 node, quantised-plane form of the wide node) stays finite: no inf - inf, no 0 * inf. */
 NORI_HD float slab_rcp(float d) {
-    float r = exact_rcp(d);
+    float r = exact_rcp_raw(d);
     if (!(fabsf(r) <= 1.152921504606846976e18f)) r = (f2u(d) >> 31) ? -1.152921504606846976e18f : 1.152921504606846976e18f;
     return r;
 }
@@ -55,7 +55,7 @@ NORI_HD bool tri_test(f3 p0, f3 edge1, f3 edge2, f3 o, f3 d, float &u, float &v,
     f3 pvec = cross(d, edge2);
     float det = dot(edge1, pvec);
     if (det > -1e-8f && det < 1e-8f) return false;
-    float inv_det = exact_rcp(det);
+    float inv_det = exact_rcp_raw(det);
     f3 tvec = o - p0;
     u = dot(tvec, pvec) * inv_det;
     if (u < 0.0f || u > 1.0f) return false;
@@ -285,7 +285,7 @@ NORI_HD void tri_pair_test(const f4 &q0, const f4 &q1, const f4 &q2, const f4 &q
     const v2f pvx = dy * e2z - dz * e2y, pvy = dz * e2x - dx * e2z, pvz = dx * e2y - dy * e2x;
     const v2f det = e1x * pvx + (e1y * pvy + e1z * pvz);
     v2f inv;
-    inv[0] = exact_rcp(det[0]); inv[1] = exact_rcp(det[1]);      /* = 1.0f / det, bit for bit */
+    inv[0] = exact_rcp_raw(det[0]); inv[1] = exact_rcp_raw(det[1]);      /* = 1.0f / det, bit for bit */
     /* tvec = o - p0; u = dot(tvec, pvec) * inv_det */
     const v2f tx = splat2(o.x) - p0x, ty = splat2(o.y) - p0y, tz = splat2(o.z) - p0z;
     r.u = (tx * pvx + (ty * pvy + tz * pvz)) * inv;

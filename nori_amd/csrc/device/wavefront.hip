@@ -640,6 +640,19 @@ void wavefront_destroy(WfEngine *e) {
     delete e;
 }
 
+bool wavefront_excursions(unsigned long long out[4], bool reset) {
+#if defined(NORI_COUNT_EXCURSIONS)
+    unsigned long long h[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_nori_excursions), sizeof(h)) != hipSuccess) return false;
+    for (int k = 0; k < 4; ++k) out[k] += h[k];
+    if (reset) { const unsigned long long z[4] = {0, 0, 0, 0}; (void) hipMemcpyToSymbol(HIP_SYMBOL(g_nori_excursions), z, sizeof(z)); }
+    return true;
+#else
+    (void) out; (void) reset;
+    return false;
+#endif
+}
+
 size_t wavefront_bytes_per_path() { return kStateBytesPerRecord + sizeof(f2) + sizeof(f4); }
 
 size_t wavefront_held_bytes(const WfEngine *e, const FilmStore &film) {

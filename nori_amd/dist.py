@@ -52,12 +52,16 @@ def reduce_frame(frame, dst: int = 0):
 
 def column_strips(rank: int, world: int, tiles_x: int, border: int, frame_cols: int, device=None):
     """Bordered-frame x coordinates rank `rank`'s tile columns touch (tile column c covers
-    [16 c, 16 c + 16 + 2 border)), and which of them lie inside the frame (the last column of an image
-    whose width is not a multiple of 16 is clipped)."""
+    [16 c, 16 c + 16 + 2 border)), and which of them to pack: those inside the frame (the last column of an image
+    whose width is not a multiple of 16 is clipped) at their FIRST occurrence -- a rank's own strips overlap when
+    16 world < 16 + 2 border (always for a group of one rank), and a frame column packed twice would be added twice."""
     import torch
     cols = torch.arange(rank, tiles_x, world, device=device)
     x = (cols[:, None] * TILE + torch.arange(TILE + 2 * border, device=device)[None, :]).reshape(-1)
-    return x.clamp(max=frame_cols - 1), x < frame_cols
+    first = torch.ones_like(x, dtype=torch.bool)
+    if x.numel() > 1:
+        first[1:] = x[1:] > torch.cummax(x, 0).values[:-1]
+    return x.clamp(max=frame_cols - 1), (x < frame_cols) & first
 
 
 def gather_frame(frame, rank: int, world: int, tiles_x: int, border: int, dst: int = 0):
@@ -76,7 +80,7 @@ def gather_frame(frame, rank: int, world: int, tiles_x: int, border: int, dst: i
         frame.zero_()
         for r in range(world):
             xr, _ = column_strips(r, world, tiles_x, border, frame.shape[1], frame.device)
-            frame.index_add_(1, xr, parts[r])      # masked entries are zero: clamped duplicates add nothing
+            frame.index_add_(1, xr, parts[r])      # masked entries are zero: clamped and repeated columns add nothing
     return frame
 
 

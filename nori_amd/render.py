@@ -64,6 +64,12 @@ class Renderer:
             msg = self._lib.nori_hip_last_error(self._h)
             raise NoriError(f"{what}: {capi.STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
 
+    def excursions(self, reset: bool = False):
+        """(rcp, div, sqrt operands outside the verified domain, fallbacks taken) -- libnori_hip_count.so only."""
+        out = (C.c_ulonglong * 4)()
+        self._check(self._lib.nori_hip_debug_excursions(self._h, out, int(reset)), "debug_excursions")
+        return tuple(int(v) for v in out)
+
     # ------------------------------------------------------------ load time
     def upload(self, scene: Scene, build: bool = True, builder: int = 0):
         desc, keep = scene.c_desc()

@@ -140,7 +140,41 @@ static f3 run_path_records(const DevScene &sc, const RayIn &cam, uint64_t rng_st
 }
 
 
+#include "emu_wavesim.h"
+
 extern "C" {
+
+/* tools/wave_sim.py: counts[level][12] for the first `max_levels` passes of a spp-sample frame under `policy` (6 ints) */
+int emu_wave_sim(emu_ctx *c, uint32_t spp, uint32_t max_levels, const int *policy, uint64_t *counts) {
+    const DevScene &sc = c->dev;
+    if (sc.integrator.type != 6) return NORI_ERR_INVALID_ARGUMENT;      /* path_mis only */
+    const int W = sc.camera.width, H = sc.camera.height;
+    const uint32_t tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
+    std::vector<std::vector<SimEntry>> levels;
+    ArrayStack stack;
+    for (uint32_t tile = 0; tile < tiles_x * tiles_y; ++tile)
+        for (uint32_t s = 0; s < spp; ++s)
+            for (int pix = 0; pix < 256; ++pix) {
+                const int px = (int) (tile % tiles_x) * kTile + (((pix >> 6) & 1) << 3) + (pix & 7), py = (int) (tile / tiles_x) * kTile + ((pix >> 7) << 3) + ((pix & 63) >> 3);      /* film.h, film_tile_pixel */
+                if (px >= W || py >= H) continue;
+                Rng rng; rng_seed(rng, (uint64_t) py * (uint64_t) W + (uint64_t) px, (uint64_t) s);
+                const f2 j = rng_next_2d(rng);
+                (void) rng_next_2d(rng);
+                RayIn cam; camera_sample_ray(sc.camera, mk2((float) px + j.x, (float) py + j.y), cam);
+                sim_capture_path<6>(sc, cam, rng.state, rng.inc, stack, levels, max_levels);
+            }
+    SimPolicy P; P.refill_threshold = policy[0]; P.leaf_threshold = policy[1]; P.inner_repeat = policy[2]; P.postpone = policy[3]; P.chunk = policy[4]; P.sort_octant = policy[5];
+    for (size_t k = 0; k < levels.size() && k < max_levels; ++k) {
+        std::vector<SimEntry> &e = levels[k];
+        if (P.sort_octant)
+            for (size_t b = 0; b < e.size(); b += 256)
+                std::stable_sort(e.begin() + b, e.begin() + std::min(e.size(), b + 256), [](const SimEntry &x, const SimEntry &y) { return sim_octant(x) < sim_octant(y); });
+        SimCounts C; std::memset(&C, 0, sizeof(C));
+        for (size_t b = 0; b < e.size(); b += (size_t) P.chunk) sim_wave(sc, e.data() + b, std::min((size_t) P.chunk, e.size() - b), P, C);
+        std::memcpy(counts + k * 12, &C, sizeof(C));
+    }
+    return (int) levels.size();
+}
 
 int emu_create(const nori_scene_desc *scene, emu_ctx **out) {
     emu_ctx *c = new emu_ctx();

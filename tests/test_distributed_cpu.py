@@ -65,10 +65,36 @@ def test_gather_needs_divisible_columns():
     import torch
     x, valid = column_strips(1, 2, 4, 2, 64 + 4)
     assert x.tolist()[:3] == [16, 17, 18] and len(x) == 2 * 20 and bool(valid.all())
-    x, valid = column_strips(0, 1, 3, 2, 40 + 4)       # 40-px-wide image: the third tile column is clipped
-    assert int(valid.sum()) == 20 + 20 + 12
+    x, valid = column_strips(0, 1, 3, 2, 40 + 4)       # 40-px-wide image: the third tile column is clipped; one rank's strips overlap
+    assert int(valid.sum()) == 40 + 4 and sorted(x[valid].tolist()) == list(range(44))      # every frame column packed exactly once
     with pytest.raises(ValueError):
         gather_frame(torch.zeros(8, 52, 4), 0, 2, 3, 2)
+
+
+def test_gather_packs_every_column_once():
+    """A rank's own column strips overlap when 16 world < 16 + 2 border -- always for a process group of ONE rank (what
+    `bench.py --gpus 1` under a launcher creates): the halo columns must not be added twice."""
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    from nori_amd.dist import column_strips, gather_frame
+    for world, tiles_x, border in ((1, 2, 2), (1, 5, 2), (2, 4, 9), (3, 6, 20)):
+        cols = tiles_x * 16 + 2 * border
+        seen = torch.zeros(cols, dtype=torch.int64)
+        for r in range(world):
+            x, valid = column_strips(r, world, tiles_x, border, cols)
+            seen.index_add_(0, x, valid.to(torch.int64))
+        assert int(seen.min()) >= 1                      # every column some rank touched is packed ...
+        x0, v0 = column_strips(0, world, tiles_x, border, cols)
+        assert len(set(x0[v0].tolist())) == int(v0.sum())      # ... and by one rank at most once
+    with tempfile.TemporaryDirectory() as d:
+        dist.init_process_group("gloo", init_method=f"file://{d}/store", rank=0, world_size=1)
+        try:
+            frame = torch.ones(7, 2 * 16 + 4, 4)
+            gather_frame(frame, 0, 1, 2, 2)
+            assert torch.equal(frame, torch.ones(7, 36, 4))
+        finally:
+            dist.destroy_process_group()
 
 
 def test_shard_partitions():
