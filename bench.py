@@ -17,9 +17,11 @@ tile columns + halo, tile split only).  Total work is fixed as N grows -> "scali
 Rank 0 prints ONE JSON line: the contract fields plus
   roofline      dominant kernel (the ray-query kernel, all its launches of one pass), timed live with HIP events on
                 the launch stream.  bound "valu": scenes whose BVH is cache-resident are VALU-issue bound
-                (profiles/*_counters.json: SQ_ACTIVE_INST_VALU vs SQ_BUSY_CYCLES); achieved = algorithmic f32 vector
-                operations (52 per two-box node test, 54 per triangle test, 9 per ray) / time
-                against 78.6 Tops/s (256 CUs x 4 SIMD x 32 lanes x 2.4 GHz, non-FMA).  bound "hbm": trees beyond
+                (profiles/*_counters.json: SQ_INSTS_VALU x the kernel's cycles per instruction vs elapsed cycles);
+                achieved = algorithmic f32 vector operations (52 per two-box node test, 54 per triangle test, 9 per
+                ray, DESIGN.md section 3) / time against 78.6 Tops/s (256 CUs x 4 SIMD x 32 lanes x 2.4 GHz, non-FMA);
+                beside it `flop_frac` (the same operations against the 157.3 TFLOP/s f32 peak) and `issued_frac` (the
+                VALU instructions the shipped code issues per unit against the issue rate).  bound "hbm": trees beyond
                 L2 + Infinity Cache; achieved = algorithmic bytes / time against 8 TB/s.
                 `traffic` = PMC-measured HBM bytes of that kernel per pass, from the committed counter summary
                 whose device-source hash matches this build (else null), stamped with its source.
@@ -47,6 +49,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 VALU_PEAK_TOPS = 78.6          # 256 CUs x 4 SIMD-32 x 2.4 GHz: one non-FMA f32 lane-operation per lane per clock
 OPS_NODE, OPS_TRI, OPS_RAY = 52, 54, 9      # algorithmic f32 vector ops per two-box node test / triangle test / ray setup
 OPS_NODE_WIDE = 103                          # ... per WIDE node test (four quantised boxes: 21 setup + 6 selects + 48 planes + 16 min/max + 12 compares)
+# the same work as the kernel ISSUES it (rt_trace.h): VALU instructions per unit of the shipped code
+ISSUED_NODE, ISSUED_TRI, ISSUED_RAY = 30, 37.5, 9      # slab_two: 6 v_pk + 12 v_fma + 4 min3/max3 + 2 v_mul + 6 v_cmp; tri_pair_test: ~75 per PAIR of triangles
+ISSUED_NODE_WIDE = 85
+VALU_ISSUE_SLOTS = 256 * 4 * 2.4e9 / 2.4 * 64          # lane-instructions per second at the measured best case of 2.4 cycles per wave64 instruction
+FLOP_PEAK_TFLOPS = 157.3                               # MI355X_MICROARCH.md: f32 vector peak (v_pk_fma_f32: 2 lanes x 2 flops)
 CACHE_RESIDENT_BYTES = 256 << 20             # a BVH below this lives in L2 + Infinity Cache: HBM is not its bound
 
 
@@ -187,10 +194,7 @@ def main():
     tiles = tiles_x * tiles_y
     shard = ndist.shard(split, rank, world, spp)
     my_tiles = (tiles - shard["tile_rem"] + shard["tile_mod"] - 1) // shard["tile_mod"]
-    engine = args.engine
-    if engine == "auto":      # the library's rule (nori_hip.h, nori_hip_set_option)
-        engine = "wavefront" if my_tiles * 256 * shard["spp_count"] >= (1 << 24) else "megakernel"
-    r.set_option("engine", engine)
+    r.set_option("engine", args.engine)      # a request: the library reports what actually rendered (nori_render_stats.engine)
     info = r.accel_info()
     frame = torch.zeros(r.frame_shape(), dtype=torch.float32, device=dev)
     stream = None if args.emulate else torch.cuda.current_stream(dev)
@@ -209,6 +213,10 @@ def main():
 
     # one instrumented pass: traversal counters for the roofline (untimed)
     counted = step(want_stats=True, count=True)
+    if "engine" in counted:
+        engine = {0: "megakernel", 1: "wavefront", 2: "block-serial"}[int(counted["engine"])]
+    else:                      # --emulate: the CPU harness walks paths one by one, sized like the library's rule would
+        engine = args.engine if args.engine != "auto" else ("wavefront" if my_tiles * 256 * shard["spp_count"] >= (1 << 24) else "megakernel")
     for _ in range(args.warmup):
         step()
     barrier()
@@ -284,12 +292,20 @@ def main():
                          "note": "algorithmic bytes per SURVEY 8(d): N_node x %d + N_tri x %d + ray / hit records; the BVH (%.0f MB) "
                                  "exceeds L2 + Infinity Cache" % (info["node_bytes"], info["tri_bytes"], info["total_bytes"] / 1e6)})
         roof["valu_frac"], roof["hbm_algorithmic_frac"] = round(fr_valu, 5), round(fr_hbm, 5)
+        # the three ways to price the same traversal work (all <= 1): `valu_frac` = textbook operation count (52 / 54 / 9) against
+        # one lane-operation per lane per clock; `flop_frac` = the same count against the f32 FLOP peak (packed FMA: 4 flops
+        # per lane per clock -- reachable only by v_pk_fma); `issued_frac` = the VALU instructions the shipped code issues
+        # per unit (30 / 37.5 / 9), as lane-instructions, against the issue rate of the fastest instructions
+        issued = counted["n_node_tests"] * (ISSUED_NODE_WIDE if wide else ISSUED_NODE) + counted["n_tri_tests"] * ISSUED_TRI + rays_c * ISSUED_RAY
+        roof["flop_frac"] = round(ops / (t_ms * 1e-3) / 1e12 / FLOP_PEAK_TFLOPS, 5)
+        roof["issued_valu_instr"] = int(issued)
+        roof["issued_frac"] = round(issued / (t_ms * 1e-3) / VALU_ISSUE_SLOTS, 5)
         roof["traffic"] = traffic
         if ctr:
             roof["traffic_source"] = os.path.relpath(ctr[0], ROOT)
             if fr_hbm_measured is not None:
                 roof["hbm_measured_frac"] = round(fr_hbm_measured, 5)
-            for k in ("valu_busy_frac", "valu_lanes_per_instr", "valu_useful_frac", "l2_hit_rate"):
+            for k in ("valu_busy_frac", "valu_cycles_per_instr", "valu_lanes_per_instr", "valu_useful_frac", "l2_hit_rate"):
                 if k in cd:
                     roof[k] = cd[k]
         out = {

@@ -392,6 +392,38 @@ int nori_hip_render_host(nori_hip_ctx *ctx, const nori_render_params *params,
 int nori_hip_develop(nori_hip_ctx *ctx, const void *d_rgbw, void *d_rgb,
                      void *stream);
 
+/* ------------------------------------------------------ all GPUs of one node
+ *
+ * render() of the reference spreads the image blocks over TBB workers (src/main.cpp:85-113) and merges every worker's
+ * block into the frame under a mutex, ImageBlock::put(ImageBlock&) (src/block.cpp:93-102).  A group does the same over
+ * the GPUs of a node: one context and one host thread per device, every device renders its share of the frame into its
+ * own RGBW buffer, ONE merge on the first device (RCCL over xGMI), the merged frame to the caller's host buffer.
+ * Shares: NORI_SPLIT_TILE = 16x16 tiles round-robin over the devices, NORI_SPLIT_SAMPLE = a range of the per-pixel
+ * sample indices each.  Merges: NORI_MERGE_REDUCE = ncclReduce(sum) of the whole frames, NORI_MERGE_GATHER (tile split,
+ * tile columns divisible by the device count) = every device sends only the column strips its tiles touched.
+ * A device list that names a device more than once is served without RCCL (peer copies) -- for tests on one GPU. */
+typedef struct nori_hip_group nori_hip_group;
+typedef enum nori_group_split { NORI_SPLIT_TILE = 0, NORI_SPLIT_SAMPLE = 1 } nori_group_split;
+typedef enum nori_group_merge { NORI_MERGE_REDUCE = 0, NORI_MERGE_GATHER = 1 } nori_group_merge;
+
+/* NORI_ERR_NO_DEVICE when a listed device does not exist ("device 1 not found ...", nori_hip_group_last_error(NULL)) */
+int nori_hip_group_create(const int *devices, int n_devices, nori_hip_group **out);
+void nori_hip_group_destroy(nori_hip_group *group);
+int nori_hip_group_size(const nori_hip_group *group);
+/* context of device i of the list (owned by the group): options, accel_info, the batch operators */
+nori_hip_ctx *nori_hip_group_ctx(nori_hip_group *group, int i);
+const char *nori_hip_group_last_error(const nori_hip_group *group);
+/* "rccl" or "copy" */
+const char *nori_hip_group_transport(const nori_hip_group *group);
+/* nori_hip_upload_scene + nori_hip_build_accel on every device, side by side (Scene::activate per device) */
+int nori_hip_group_upload_scene(nori_hip_group *group, const nori_scene_desc *scene, int builder /* nori_accel_builder */);
+/* The render loop of src/main.cpp:78-119 over the group: samples [spp_begin, spp_begin + spp_count) of every pixel of the
+ * width x height frame (params->tile_mod must be 1: the group shares the tiles out itself), merged into the HOST buffer
+ * `rgbw` (layout of nori_render_params; overwritten).  stats: counters summed over the devices, times = the slowest
+ * device's; merge_ms: HIP-event time of the merge on the first device's stream. */
+int nori_hip_group_render_host(nori_hip_group *group, const nori_render_params *params, int split, int merge,
+                               int width, int height, float *rgbw, nori_render_stats *stats, float *merge_ms);
+
 #ifdef __cplusplus
 }
 #endif

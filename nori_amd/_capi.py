@@ -136,6 +136,14 @@ HIP_PROTOTYPES = {
     "nori_hip_render": (C.c_int, [_P, C.POINTER(RenderParams), _P, C.POINTER(RenderStats)]),
     "nori_hip_render_host": (C.c_int, [_P, C.POINTER(RenderParams), _P, C.POINTER(RenderStats)]),
     "nori_hip_develop": (C.c_int, [_P, _P, _P, _P]),
+    "nori_hip_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "nori_hip_group_destroy": (None, [_P]),
+    "nori_hip_group_size": (C.c_int, [_P]),
+    "nori_hip_group_ctx": (_P, [_P, C.c_int]),
+    "nori_hip_group_last_error": (C.c_char_p, [_P]),
+    "nori_hip_group_transport": (C.c_char_p, [_P]),
+    "nori_hip_group_upload_scene": (C.c_int, [_P, C.POINTER(SceneDesc), C.c_int]),
+    "nori_hip_group_render_host": (C.c_int, [_P, C.POINTER(RenderParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(RenderStats), C.POINTER(C.c_float)]),
 }
 
 

@@ -1,0 +1,331 @@
+/*
+ * group.hip -- all GPUs of one node behind ONE host call: nori_hip_group_* of include/nori_hip.h.
+ *
+ * What the reference does with TBB workers over image blocks (src/main.cpp:85-113) and a mutex around
+ * ImageBlock::put(ImageBlock&) (src/block.cpp:93-102), a node of MI355Xs does with one host thread and one
+ * nori_hip_ctx per GPU (a context is bound to its device and not thread-safe: one thread each) and ONE merge over xGMI:
+ *
+ *   render   thread k renders share k (group_merge.h: tiles k, k + N, ... or a range of the sample indices) into device
+ *            k's own zero-initialised RGBW frame -- no traffic between devices
+ *   merge    reduce: ncclReduce(sum) of the N frames into device 0's (ring over the xGMI links; 17 MB at 1024^2)
+ *            gather: every device packs the column strips its tiles touched (pack_strips_kernel), device 0 receives them
+ *                    (ncclSend / ncclRecv in one group) and adds them (add_strips_kernel): 1/N of a frame per link
+ *   output   device 0's frame -> the caller's host buffer
+ *
+ * RCCL runs single-process here (ncclCommInitAll: one communicator per device, all owned by this process) and is
+ * loaded with dlopen at the first group of more than one distinct device: a one-GPU process never maps librccl.
+ * Transport "copy" (hipMemcpyPeerAsync + the same kernels) serves device lists that name a device twice -- which RCCL
+ * refuses -- i.e. the tests that drive the whole group path, threads and merges included, on a one-GPU box.
+ */
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      /* types and prototypes only: the library is dlopen'ed */
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/nori_hip.h"
+#include "group_merge.h"
+
+using namespace nrt;
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    std::string load() {
+        if (lib) return std::string();
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) return std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+#define SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); if (!field) return std::string("librccl lacks ") + name
+        SYM(CommInitAll, "ncclCommInitAll"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GetErrorString, "ncclGetErrorString");
+        SYM(Reduce, "ncclReduce"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
+#undef SYM
+        return std::string();
+    }
+};
+
+Rccl g_rccl;      /* process-wide: the library handle only; communicators belong to their group */
+
+/* frame: rows x cols x RGBW; x: frame column of each packed column or -1 (group_merge.h) */
+__global__ void pack_strips_kernel(const float4 *frame, int rows, int cols, const int32_t *x, int w, float4 *pack) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (i >= w || y >= rows) return;
+    const int32_t c = x[i];
+    pack[(size_t) y * w + i] = c >= 0 ? frame[(size_t) y * cols + c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+__global__ void add_strips_kernel(float4 *frame, int rows, int cols, const int32_t *x, int w, const float4 *pack) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (i >= w || y >= rows) return;
+    const int32_t c = x[i];
+    if (c < 0) return;                 /* columns of one list are distinct: no two threads add to the same pixel */
+    float4 a = frame[(size_t) y * cols + c];
+    const float4 b = pack[(size_t) y * w + i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    frame[(size_t) y * cols + c] = a;
+}
+__global__ void add_frames_kernel(float4 *dst, const float4 *src, size_t n) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float4 a = dst[i]; const float4 b = src[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    dst[i] = a;
+}
+
+} // namespace
+
+struct nori_hip_group {
+    std::vector<int> devices;
+    std::vector<nori_hip_ctx *> ctx;
+    std::vector<hipStream_t> streams;
+    std::vector<float *> d_frame;          /* per device, sized for the last frame geometry */
+    std::vector<float *> d_pack;           /* per device: its packed strips */
+    std::vector<int32_t *> d_x;            /* per device: its strip column list; on device 0 also every other device's */
+    std::vector<float *> d_recv;           /* on device 0: one receive buffer per other device (strips or a whole frame) */
+    std::vector<int32_t *> d_x_root;       /* on device 0: column list of device k */
+    std::vector<ncclComm_t> comms;
+    size_t frame_floats = 0, pack_floats = 0, x_ints = 0, recv_floats = 0;      /* what the buffers are sized for */
+    bool rccl = false;
+    std::string error;
+    void free_buffers() {
+        for (size_t k = 0; k < devices.size(); ++k) {
+            (void) hipSetDevice(devices[k]);
+            if (k < d_frame.size() && d_frame[k]) (void) hipFree(d_frame[k]);
+            if (k < d_pack.size() && d_pack[k]) (void) hipFree(d_pack[k]);
+            if (k < d_x.size() && d_x[k]) (void) hipFree(d_x[k]);
+        }
+        if (!devices.empty()) (void) hipSetDevice(devices[0]);
+        for (float *p : d_recv) if (p) (void) hipFree(p);
+        for (int32_t *p : d_x_root) if (p) (void) hipFree(p);
+        d_frame.clear(); d_pack.clear(); d_x.clear(); d_recv.clear(); d_x_root.clear();
+        frame_floats = pack_floats = x_ints = recv_floats = 0;
+    }
+};
+
+#define GRP_HIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { g->error = std::string(#expr) + ": " + hipGetErrorString(e__); return NORI_ERR_INTERNAL; } } while (0)
+#define GRP_NCCL(expr) do { ncclResult_t r__ = (expr); if (r__ != ncclSuccess) { g->error = std::string(#expr) + ": " + g_rccl.GetErrorString(r__); return NORI_ERR_INTERNAL; } } while (0)
+
+static std::string g_group_create_error;
+
+extern "C" {
+
+int nori_hip_group_create(const int *devices, int n_devices, nori_hip_group **out) {
+    if (!out) return NORI_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    if (!devices || n_devices < 1 || n_devices > 64) { g_group_create_error = "group_create: 1 .. 64 devices"; return NORI_ERR_INVALID_ARGUMENT; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { g_group_create_error = "no HIP device available"; return NORI_ERR_NO_DEVICE; }
+    for (int k = 0; k < n_devices; ++k)
+        if (devices[k] < 0 || devices[k] >= count) {
+            g_group_create_error = "device " + std::to_string(devices[k]) + " not found (this node has " + std::to_string(count) + ")";
+            return NORI_ERR_NO_DEVICE;
+        }
+    nori_hip_group *g = new nori_hip_group();
+    g->devices.assign(devices, devices + n_devices);
+    bool distinct = true;
+    for (int a = 0; a < n_devices; ++a) for (int b = a + 1; b < n_devices; ++b) distinct &= devices[a] != devices[b];
+    const char *tr = getenv("NORI_GROUP_TRANSPORT");
+    g->rccl = distinct && (n_devices > 1 || (tr && std::string(tr) == "rccl")) && !(tr && std::string(tr) == "copy");
+    for (int k = 0; k < n_devices; ++k) {
+        nori_hip_ctx *c = nullptr;
+        const int rc = nori_hip_create(devices[k], &c);
+        if (rc != NORI_OK) { g_group_create_error = std::string("device ") + std::to_string(devices[k]) + ": " + nori_hip_last_error(nullptr); nori_hip_group_destroy(g); return rc; }
+        g->ctx.push_back(c);
+        hipStream_t s = nullptr;
+        if (hipSetDevice(devices[k]) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { g_group_create_error = "hipStreamCreate failed"; nori_hip_group_destroy(g); return NORI_ERR_INTERNAL; }
+        g->streams.push_back(s);
+    }
+    if (g->rccl) {
+        std::string e = g_rccl.load();
+        if (!e.empty()) { g_group_create_error = e; nori_hip_group_destroy(g); return NORI_ERR_UNSUPPORTED; }
+        g->comms.assign((size_t) n_devices, nullptr);
+        const ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), n_devices, g->devices.data());
+        if (r != ncclSuccess) { g_group_create_error = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r); g->comms.clear(); nori_hip_group_destroy(g); return NORI_ERR_INTERNAL; }
+    }
+    (void) hipSetDevice(devices[0]);
+    *out = g;
+    return NORI_OK;
+}
+
+void nori_hip_group_destroy(nori_hip_group *g) {
+    if (!g) return;
+    g->free_buffers();
+    for (ncclComm_t c : g->comms) if (c) (void) g_rccl.CommDestroy(c);
+    for (size_t k = 0; k < g->streams.size(); ++k) { (void) hipSetDevice(g->devices[k]); if (g->streams[k]) (void) hipStreamDestroy(g->streams[k]); }
+    for (nori_hip_ctx *c : g->ctx) nori_hip_destroy(c);
+    delete g;
+}
+
+int nori_hip_group_size(const nori_hip_group *g) { return g ? (int) g->ctx.size() : 0; }
+nori_hip_ctx *nori_hip_group_ctx(nori_hip_group *g, int i) { return (g && i >= 0 && i < (int) g->ctx.size()) ? g->ctx[(size_t) i] : nullptr; }
+const char *nori_hip_group_last_error(const nori_hip_group *g) { return g ? g->error.c_str() : g_group_create_error.c_str(); }
+const char *nori_hip_group_transport(const nori_hip_group *g) { return !g ? "" : g->rccl ? "rccl" : "copy"; }
+
+int nori_hip_group_upload_scene(nori_hip_group *g, const nori_scene_desc *scene, int builder) {
+    if (!g || !scene) return NORI_ERR_INVALID_ARGUMENT;
+    const size_t n = g->ctx.size();
+    std::vector<int> rc(n, NORI_OK);
+    std::vector<std::thread> th;
+    for (size_t k = 0; k < n; ++k) th.emplace_back([&, k] {
+        rc[k] = nori_hip_upload_scene(g->ctx[k], scene);
+        if (rc[k] == NORI_OK) rc[k] = nori_hip_build_accel(g->ctx[k], builder);
+    });
+    for (auto &t : th) t.join();
+    for (size_t k = 0; k < n; ++k)
+        if (rc[k] != NORI_OK) { g->error = "device " + std::to_string(g->devices[k]) + ": " + nori_hip_last_error(g->ctx[k]); return rc[k]; }
+    return NORI_OK;
+}
+
+int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *params, int split, int merge, int width, int height,
+                               float *rgbw, nori_render_stats *stats, float *merge_ms) {
+    if (!g || !params || !rgbw) return NORI_ERR_INVALID_ARGUMENT;
+    if (params->tile_mod != 1 || params->tile_rem != 0) { g->error = "group_render: the group shares the frame out itself (tile_mod 1, tile_rem 0)"; return NORI_ERR_INVALID_ARGUMENT; }
+    if (split != kSplitTile && split != kSplitSample) { g->error = "group_render: split must be tile (0) or sample (1)"; return NORI_ERR_INVALID_ARGUMENT; }
+    if (merge != kMergeReduce && merge != kMergeGather) { g->error = "group_render: merge must be reduce (0) or gather (1)"; return NORI_ERR_INVALID_ARGUMENT; }
+    const int n = (int) g->ctx.size();
+    const int border = nori_hip_border_size(g->ctx[0]);
+    if (border < 0) { g->error = std::string("group_render: ") + nori_hip_last_error(g->ctx[0]); return NORI_ERR_NOT_READY; }
+    const int rows = height + 2 * border, cols = width + 2 * border;
+    const uint32_t tiles_x = (uint32_t) ((width + NORI_TILE_SIZE - 1) / NORI_TILE_SIZE);
+    if (merge == kMergeGather && (split != kSplitTile || tiles_x % (uint32_t) n != 0u)) {
+        g->error = "group_render: the gather merge needs the tile split and a tile-column count (" + std::to_string(tiles_x) + ") divisible by the number of devices (" + std::to_string(n) + "); use the reduce merge";
+        return NORI_ERR_INVALID_ARGUMENT;
+    }
+    if (params->seed_mode == NORI_SEED_NORI_BLOCK && n > 1) { g->error = "group_render: NORI_SEED_NORI_BLOCK renders whole frames on one device"; return NORI_ERR_UNSUPPORTED; }
+
+    /* buffers for this frame geometry */
+    const size_t frame_floats = (size_t) rows * cols * 4;
+    std::vector<std::vector<int32_t>> xs((size_t) n);
+    size_t pack_floats = 0;
+    if (merge == kMergeGather)
+        for (int k = 0; k < n; ++k) { xs[(size_t) k] = group_strip_columns(k, n, tiles_x, border, cols); pack_floats = std::max(pack_floats, xs[(size_t) k].size() * (size_t) rows * 4); }
+    size_t x_ints = 0;
+    for (int k = 0; k < n; ++k) x_ints = std::max(x_ints, xs[(size_t) k].size());
+    const size_t recv_floats = n == 1 ? 0 : merge == kMergeGather ? pack_floats : (g->rccl ? 0 : frame_floats);
+    if (g->frame_floats != frame_floats || g->pack_floats < pack_floats || g->x_ints < x_ints || g->recv_floats < recv_floats) {
+        g->free_buffers();
+        g->d_frame.assign((size_t) n, nullptr); g->d_pack.assign((size_t) n, nullptr); g->d_x.assign((size_t) n, nullptr);
+        g->d_recv.assign((size_t) n, nullptr); g->d_x_root.assign((size_t) n, nullptr);
+        for (int k = 0; k < n; ++k) {
+            GRP_HIP(hipSetDevice(g->devices[(size_t) k]));
+            GRP_HIP(hipMalloc((void **) &g->d_frame[(size_t) k], frame_floats * sizeof(float)));
+            if (pack_floats) GRP_HIP(hipMalloc((void **) &g->d_pack[(size_t) k], pack_floats * sizeof(float)));
+            if (x_ints) GRP_HIP(hipMalloc((void **) &g->d_x[(size_t) k], x_ints * sizeof(int32_t)));
+        }
+        GRP_HIP(hipSetDevice(g->devices[0]));
+        for (int k = 1; k < n; ++k) {      /* device 0 receives: strips (gather), or whole frames when the transport is a plain copy */
+            if (recv_floats) GRP_HIP(hipMalloc((void **) &g->d_recv[(size_t) k], recv_floats * sizeof(float)));
+            if (x_ints) GRP_HIP(hipMalloc((void **) &g->d_x_root[(size_t) k], x_ints * sizeof(int32_t)));
+        }
+        g->frame_floats = frame_floats; g->pack_floats = pack_floats; g->x_ints = x_ints; g->recv_floats = recv_floats;
+    }
+    if (merge == kMergeGather)
+        for (int k = 1; k < n; ++k) {
+            GRP_HIP(hipSetDevice(g->devices[(size_t) k]));
+            GRP_HIP(hipMemcpy(g->d_x[(size_t) k], xs[(size_t) k].data(), xs[(size_t) k].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            GRP_HIP(hipSetDevice(g->devices[0]));
+            GRP_HIP(hipMemcpy(g->d_x_root[(size_t) k], xs[(size_t) k].data(), xs[(size_t) k].size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        }
+
+    /* render: one host thread per device */
+    std::vector<int> rc((size_t) n, NORI_OK);
+    std::vector<nori_render_stats> st((size_t) n);
+    std::vector<std::string> errs((size_t) n);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n; ++k) th.emplace_back([&, k] {
+        const size_t i = (size_t) k;
+        if (hipSetDevice(g->devices[i]) != hipSuccess || hipMemsetAsync(g->d_frame[i], 0, frame_floats * sizeof(float), g->streams[i]) != hipSuccess) { rc[i] = NORI_ERR_INTERNAL; errs[i] = "clearing the frame failed"; return; }
+        const GroupShare sh = group_share(split, k, n, params->spp_begin, params->spp_count);
+        nori_render_params p = *params;
+        p.spp_begin = sh.spp_begin; p.spp_count = sh.spp_count; p.tile_mod = sh.tile_mod; p.tile_rem = sh.tile_rem; p.stream = g->streams[i];
+        std::memset(&st[i], 0, sizeof(st[i]));
+        rc[i] = nori_hip_render(g->ctx[i], &p, g->d_frame[i], &st[i]);      /* synchronises its stream (stats requested) */
+        if (rc[i] != NORI_OK) errs[i] = nori_hip_last_error(g->ctx[i]);
+    });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n; ++k)
+        if (rc[(size_t) k] != NORI_OK) { g->error = "device " + std::to_string(g->devices[(size_t) k]) + ": " + errs[(size_t) k]; return rc[(size_t) k]; }
+
+    /* merge on device 0: ImageBlock::put(ImageBlock&) across devices */
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    GRP_HIP(hipSetDevice(g->devices[0]));
+    GRP_HIP(hipEventCreate(&e0)); GRP_HIP(hipEventCreate(&e1));
+    GRP_HIP(hipEventRecord(e0, g->streams[0]));
+    const dim3 blk(256);
+    if ((n > 1 || g->rccl) && merge == kMergeReduce) {      /* (a forced one-rank RCCL group still calls ncclReduce: a smoke test of the library on one GPU) */
+        if (g->rccl) {
+            GRP_NCCL(g_rccl.GroupStart());
+            for (int k = 0; k < n; ++k) GRP_NCCL(g_rccl.Reduce(g->d_frame[(size_t) k], g->d_frame[(size_t) k], frame_floats, ncclFloat, ncclSum, 0, g->comms[(size_t) k], g->streams[(size_t) k]));
+            GRP_NCCL(g_rccl.GroupEnd());
+        } else {
+            for (int k = 1; k < n; ++k) {
+                GRP_HIP(hipMemcpyPeerAsync(g->d_recv[(size_t) k], g->devices[0], g->d_frame[(size_t) k], g->devices[(size_t) k], frame_floats * sizeof(float), g->streams[0]));
+                hipLaunchKernelGGL(add_frames_kernel, dim3((unsigned) ((frame_floats / 4 + 255) / 256)), blk, 0, g->streams[0], reinterpret_cast<float4 *>(g->d_frame[0]), reinterpret_cast<const float4 *>(g->d_recv[(size_t) k]), frame_floats / 4);
+            }
+        }
+    } else if (n > 1) {
+        for (int k = 1; k < n; ++k) {      /* every other device packs its strips */
+            const int w = (int) xs[(size_t) k].size();
+            GRP_HIP(hipSetDevice(g->devices[(size_t) k]));
+            hipLaunchKernelGGL(pack_strips_kernel, dim3((unsigned) ((w + 255) / 256), (unsigned) rows), blk, 0, g->streams[(size_t) k], reinterpret_cast<const float4 *>(g->d_frame[(size_t) k]), rows, cols, g->d_x[(size_t) k], w, reinterpret_cast<float4 *>(g->d_pack[(size_t) k]));
+            GRP_HIP(hipGetLastError());
+        }
+        if (g->rccl) {
+            GRP_NCCL(g_rccl.GroupStart());
+            for (int k = 1; k < n; ++k) {
+                const size_t cnt = xs[(size_t) k].size() * (size_t) rows * 4;
+                GRP_NCCL(g_rccl.Send(g->d_pack[(size_t) k], cnt, ncclFloat, 0, g->comms[(size_t) k], g->streams[(size_t) k]));
+                GRP_NCCL(g_rccl.Recv(g->d_recv[(size_t) k], cnt, ncclFloat, k, g->comms[0], g->streams[0]));
+            }
+            GRP_NCCL(g_rccl.GroupEnd());
+        } else {
+            for (int k = 1; k < n; ++k) {
+                GRP_HIP(hipSetDevice(g->devices[(size_t) k]));
+                GRP_HIP(hipStreamSynchronize(g->streams[(size_t) k]));      /* the strips are packed */
+                GRP_HIP(hipMemcpyPeerAsync(g->d_recv[(size_t) k], g->devices[0], g->d_pack[(size_t) k], g->devices[(size_t) k], xs[(size_t) k].size() * (size_t) rows * 4 * sizeof(float), g->streams[0]));
+            }
+        }
+        GRP_HIP(hipSetDevice(g->devices[0]));
+        for (int k = 1; k < n; ++k) {
+            const int w = (int) xs[(size_t) k].size();
+            hipLaunchKernelGGL(add_strips_kernel, dim3((unsigned) ((w + 255) / 256), (unsigned) rows), blk, 0, g->streams[0], reinterpret_cast<float4 *>(g->d_frame[0]), rows, cols, g->d_x_root[(size_t) k], w, reinterpret_cast<const float4 *>(g->d_recv[(size_t) k]));
+            GRP_HIP(hipGetLastError());
+        }
+    }
+    if (g->rccl && n > 1) for (int k = 1; k < n; ++k) { GRP_HIP(hipSetDevice(g->devices[(size_t) k])); GRP_HIP(hipStreamSynchronize(g->streams[(size_t) k])); }
+    GRP_HIP(hipSetDevice(g->devices[0]));
+    GRP_HIP(hipEventRecord(e1, g->streams[0]));
+    GRP_HIP(hipMemcpyAsync(rgbw, g->d_frame[0], frame_floats * sizeof(float), hipMemcpyDeviceToHost, g->streams[0]));
+    GRP_HIP(hipStreamSynchronize(g->streams[0]));
+    float ms = 0.0f;
+    GRP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    if (merge_ms) *merge_ms = ms;
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        for (int k = 0; k < n; ++k) {
+            const nori_render_stats &s = st[(size_t) k];
+            stats->n_camera_samples += s.n_camera_samples; stats->n_closest_rays += s.n_closest_rays; stats->n_shadow_rays += s.n_shadow_rays;
+            stats->n_node_tests += s.n_node_tests; stats->n_tri_tests += s.n_tri_tests; stats->n_invalid += s.n_invalid;
+            stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms);       /* the devices render side by side: the slowest counts */
+            stats->trace_ms = std::max(stats->trace_ms, s.trace_ms); stats->shade_ms = std::max(stats->shade_ms, s.shade_ms); stats->film_ms = std::max(stats->film_ms, s.film_ms);
+            stats->n_workgroups += s.n_workgroups; stats->n_trace_launches = std::max(stats->n_trace_launches, s.n_trace_launches);
+            stats->lds_bytes = s.lds_bytes; stats->engine = s.engine;
+        }
+    }
+    return NORI_OK;
+}
+
+} // extern "C"

@@ -1,6 +1,7 @@
 #include <nori/device.h>
 #include <cstdlib>
 #include <memory>
+#include <vector>
 
 NORI_NAMESPACE_BEGIN
 
@@ -26,6 +27,20 @@ Device &Device::shared() {
     static std::unique_ptr<Device> dev;
     if (!dev) dev.reset(new Device());
     return *dev;
+}
+
+DeviceGroup::DeviceGroup(int n) {
+    std::vector<int> devices;
+    for (int k = 0; k < n; ++k) devices.push_back(k);
+    int rc = nori_hip_group_create(devices.data(), n, &m_group);
+    if (rc != NORI_OK)
+        throw NoriException("Unable to set up %i GPUs: %s (the MI355X path has no CPU fallback)", n, nori_hip_group_last_error(nullptr));
+}
+
+DeviceGroup::~DeviceGroup() { nori_hip_group_destroy(m_group); }
+
+void DeviceGroup::check(int rc, const char *what) const {
+    if (rc != NORI_OK) throw NoriException("%s failed (%i): %s", what, rc, nori_hip_group_last_error(m_group));
 }
 
 NORI_NAMESPACE_END

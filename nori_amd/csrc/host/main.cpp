@@ -1,11 +1,13 @@
 /*
- * main.cpp -- `nori <scene.xml> [--no-gui] [--threads N] [--seed sample|block]`
+ * main.cpp -- `nori <scene.xml> [--no-gui] [--threads N] [--seed sample|block] [--gpus N] [--split tile|sample] [--merge reduce|gather]`
  * Command line of the reference (src/main.cpp:150-246).  There is no GUI on a
  * compute node: --no-gui is accepted and implied; --threads is accepted for
  * compatibility (the work runs on the GPU).  --seed block renders with the
  * reference's sampler streams (one pcg32 stream per 32x32 block,
  * src/independent.cpp:36-41; one GPU lane per block, slow by design) instead of
- * one stream per camera sample.  A <test> root runs during parsing
+ * one stream per camera sample.  --gpus N shares the frame over the first N GPUs
+ * of the node (render.cpp: what TBB workers are in the reference; --split / --merge
+ * choose how the work is cut and how the frames come together).  A <test> root runs during parsing
  * (its activate()), as in the reference; failures exit with -1.
  */
 #include <nori/bitmap.h>
@@ -15,7 +17,7 @@ using namespace nori;
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        cerr << "Syntax: " << argv[0] << " <scene.xml> [--no-gui] [--threads N] [--seed sample|block]" << endl;
+        cerr << "Syntax: " << argv[0] << " <scene.xml> [--no-gui] [--threads N] [--seed sample|block] [--gpus N] [--split tile|sample] [--merge reduce|gather]" << endl;
         return -1;
     }
     std::string sceneName;
@@ -36,6 +38,20 @@ int main(int argc, char **argv) {
                 return -1;
             }
             setenv("NORI_SEED", argv[++i], 1);
+            continue;
+        } else if (token == "--gpus") {
+            if (i + 1 >= argc || atoi(argv[i + 1]) <= 0) {
+                cerr << "\"--gpus\" argument expects a positive integer following it." << endl;
+                return -1;
+            }
+            setenv("NORI_GPUS", argv[++i], 1);
+            continue;
+        } else if (token == "--split" || token == "--merge") {
+            if (i + 1 >= argc) {
+                cerr << "\"" << token << "\" expects a value." << endl;
+                return -1;
+            }
+            setenv(token == "--split" ? "NORI_SPLIT" : "NORI_MERGE", argv[++i], 1);
             continue;
         }
         if (endsWith(token, ".xml")) {

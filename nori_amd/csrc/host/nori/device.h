@@ -30,4 +30,21 @@ private:
     int m_device = 0;
 };
 
+/* All GPUs of the node the render is shared over (nori_hip_group_*, include/nori_hip.h): what tbb::parallel_for over the
+ * image blocks (src/main.cpp:85-113) and the mutex-guarded ImageBlock::put(ImageBlock&) (src/block.cpp:93-102) are in the
+ * reference.  One context and one host thread per device inside the library; one RCCL merge over xGMI. */
+class DeviceGroup {
+public:
+    /* devices 0 .. n-1 of the node; throws NoriException ("device 1 not found ...") when one is missing */
+    explicit DeviceGroup(int n);
+    ~DeviceGroup();
+    DeviceGroup(const DeviceGroup &) = delete;
+    DeviceGroup &operator=(const DeviceGroup &) = delete;
+    nori_hip_group *group() const { return m_group; }
+    int size() const { return nori_hip_group_size(m_group); }
+    void check(int rc, const char *what) const;
+private:
+    nori_hip_group *m_group = nullptr;
+};
+
 NORI_NAMESPACE_END

@@ -230,6 +230,8 @@ public:
     const nori_scene_desc &getDesc() const;
     /* context with this scene uploaded and its BVH built (created on first use) */
     Device &device() const;
+    /* the same on the first n GPUs of the node, for renders shared over them (created on first use) */
+    DeviceGroup &deviceGroup(int n) const;
     /* printing the scene summary on activate (src/scene.cpp:41-43) can be silenced */
     static bool s_verbose;
 private:
@@ -242,6 +244,7 @@ private:
     mutable std::vector<nori_mesh_desc> m_meshDescs;
     mutable bool m_descValid = false;
     mutable std::unique_ptr<Device> m_device;
+    mutable std::unique_ptr<DeviceGroup> m_group;
 };
 
 /* ------------------------------------------------------------- ImageBlock */

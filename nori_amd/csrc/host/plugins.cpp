@@ -553,6 +553,15 @@ Device &Scene::device() const {
     }
     return *m_device;
 }
+DeviceGroup &Scene::deviceGroup(int n) const {
+    if (!m_group || m_group->size() != n) {
+        std::unique_ptr<DeviceGroup> g(new DeviceGroup(n));
+        const nori_scene_desc &desc = getDesc();
+        g->check(nori_hip_group_upload_scene(g->group(), &desc, NORI_ACCEL_AUTO), "nori_hip_group_upload_scene");
+        m_group = std::move(g);
+    }
+    return *m_group;
+}
 NORI_REGISTER_CLASS(Scene, "scene");
 
 NORI_NAMESPACE_END

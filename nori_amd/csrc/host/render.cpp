@@ -7,6 +7,12 @@
  * nori_hip_render -- block scheduling, sampling, Li and the filtered splat all
  * run in the render kernel -- and the full-frame RGBW block comes back for
  * toBitmap (src/block.cpp:45-51).
+ *
+ * NORI_GPUS=N in the environment (`nori scene.xml --gpus N`) shares the frame over the first N GPUs of the node: the
+ * blocks the reference's parallel_for hands to TBB workers (src/main.cpp:85-113) go to devices -- 16x16 tiles round
+ * robin (NORI_SPLIT=tile, default) or a range of the sample indices each (NORI_SPLIT=sample) -- and the mutex-guarded
+ * ImageBlock::put(ImageBlock&) (src/block.cpp:93-102) becomes one RCCL merge on the first device (NORI_MERGE=reduce,
+ * default, or gather): nori_hip_group_render_host, one host thread and one context per device inside the library.
  */
 #include <nori/bitmap.h>
 #include <nori/plugins.h>
@@ -43,7 +49,6 @@ std::unique_ptr<ImageBlock> renderScene(Scene *scene, nori_render_stats *stats) 
     std::unique_ptr<ImageBlock> result(new ImageBlock(camera->getOutputSize(), camera->getReconstructionFilter()));
     result->clear();
 
-    Device &dev = scene->device();          /* uploads the scene and builds the BVH on first use */
     nori_render_params params;
     std::memset(&params, 0, sizeof(params));
     params.spp_begin = 0;
@@ -55,6 +60,22 @@ std::unique_ptr<ImageBlock> renderScene(Scene *scene, nori_render_stats *stats) 
     const char *seed = std::getenv("NORI_SEED");
     params.seed_mode = (seed && std::string(seed) == "block") ? NORI_SEED_NORI_BLOCK : NORI_SEED_PER_SAMPLE;
     nori_render_stats local;
+    if (const char *gpus = std::getenv("NORI_GPUS")) {
+        const int n = std::atoi(gpus);
+        if (n < 1) throw NoriException("NORI_GPUS / --gpus expects a positive number of GPUs, got \"%s\"", gpus);
+        const char *sp = std::getenv("NORI_SPLIT"), *mg = std::getenv("NORI_MERGE");
+        const std::string split = sp ? sp : "tile", merge = mg ? mg : "reduce";
+        if (split != "tile" && split != "sample") throw NoriException("NORI_SPLIT / --split expects \"tile\" or \"sample\", got \"%s\"", split);
+        if (merge != "reduce" && merge != "gather") throw NoriException("NORI_MERGE / --merge expects \"reduce\" or \"gather\", got \"%s\"", merge);
+        DeviceGroup &grp = scene->deviceGroup(n);
+        float merge_ms = 0.0f;
+        grp.check(nori_hip_group_render_host(grp.group(), &params, split == "sample" ? NORI_SPLIT_SAMPLE : NORI_SPLIT_TILE,
+                                             merge == "gather" ? NORI_MERGE_GATHER : NORI_MERGE_REDUCE, camera->getOutputSize().x(), camera->getOutputSize().y(),
+                                             result->data(), stats ? stats : &local, &merge_ms), "nori_hip_group_render_host");
+        if (Scene::s_verbose) cout << "[" << n << " GPUs, " << split << " split, " << merge << " merge over " << nori_hip_group_transport(grp.group()) << ": " << merge_ms << " ms] ";
+        return result;
+    }
+    Device &dev = scene->device();          /* uploads the scene and builds the BVH on first use */
     dev.check(nori_hip_render_host(dev.ctx(), &params, result->data(), stats ? stats : &local), "nori_hip_render_host");
     return result;
 }

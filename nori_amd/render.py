@@ -222,6 +222,74 @@ class Renderer:
         return rgb
 
 
+class DeviceGroup:
+    """All GPUs of a node behind one call (nori_hip_group_*, include/nori_hip.h): the render loop of src/main.cpp:78-119
+    with the image blocks shared out over devices instead of TBB workers and ImageBlock::put(ImageBlock&) as one merge."""
+    SPLIT = {"tile": 0, "sample": 1}
+    MERGE = {"reduce": 0, "gather": 1}
+
+    def __init__(self, devices):
+        self._lib = capi.load_hip()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        h = C.c_void_p()
+        rc = self._lib.nori_hip_group_create(devs, len(devices), C.byref(h))
+        if rc != 0:
+            msg = self._lib.nori_hip_group_last_error(None)
+            raise NoriError(f"nori_hip_group_create({list(devices)}) failed: {capi.STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
+        self._h = h
+        self.scene: Optional[Scene] = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nori_hip_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.nori_hip_group_last_error(self._h)
+            raise NoriError(f"{what}: {capi.STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    @property
+    def size(self) -> int:
+        return int(self._lib.nori_hip_group_size(self._h))
+
+    @property
+    def transport(self) -> str:
+        return self._lib.nori_hip_group_transport(self._h).decode()
+
+    def upload(self, scene: Scene, builder: int = 0):
+        desc, keep = scene.c_desc()
+        self._check(self._lib.nori_hip_group_upload_scene(self._h, C.byref(desc), int(builder)), "group_upload_scene")
+        del keep
+        self.scene = scene
+        return self
+
+    def set_option(self, key: str, value) -> None:
+        for i in range(self.size):
+            ctx = self._lib.nori_hip_group_ctx(self._h, i)
+            if self._lib.nori_hip_set_option(ctx, key.encode(), str(value).encode()) != 0:
+                raise NoriError(f"set_option({key}) on group member {i}: {self._lib.nori_hip_last_error(ctx).decode()}")
+
+    def render_host(self, split="tile", merge="reduce", spp_count=None, spp_begin=0, count_traversal=False):
+        """(rgbw, stats dict, merge ms): the merged frame of all devices."""
+        c = self.scene.camera
+        b = self._lib.nori_hip_border_size(self._lib.nori_hip_group_ctx(self._h, 0))
+        spp = self.scene.sample_count if spp_count is None else spp_count
+        p = Renderer._params(spp_begin, spp, 1, 0, count_traversal, None)
+        rgbw = np.zeros((c.height + 2 * b, c.width + 2 * b, 4), np.float32)
+        st = capi.RenderStats()
+        ms = C.c_float(0.0)
+        self._check(self._lib.nori_hip_group_render_host(self._h, C.byref(p), self.SPLIT[split], self.MERGE[merge], c.width, c.height,
+                                                         ptr(rgbw), C.byref(st), C.byref(ms)), "group_render_host")
+        return rgbw, st.as_dict(), float(ms.value)
+
+
 def develop_host(rgbw: np.ndarray, border: int) -> np.ndarray:
     """ImageBlock::toBitmap (src/block.cpp:45-51) for a host RGBW frame.  Pure
     reshaping/division of an already rendered frame (output side, not the hot path)."""

@@ -113,6 +113,7 @@ def emu_lib():
             "emu_warp_pdf": (C.c_int, [C.c_int, C.c_float, _P, C.c_size_t, _P]),
             "emu_pcg32_floats": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, _P]),
             "emu_render": (C.c_int, [_P, C.POINTER(capi.RenderParams), _P, C.POINTER(capi.RenderStats)]),
+            "emu_group_render": (C.c_int, [_P, C.c_int, C.POINTER(capi.RenderParams), C.c_int, C.c_int, _P, C.POINTER(capi.RenderStats)]),
         }
         _emu = capi.bind(lib, protos)
     return _emu
@@ -326,3 +327,11 @@ class Emu(_CpuBackend):
         st = capi.RenderStats()
         assert self.lib.emu_render(self._h, C.byref(p), ptr(rgbw), C.byref(st)) == 0
         return rgbw, st.as_dict()
+
+    def group_render_host(self, n_ranks, split="tile", merge="reduce", spp_count=None):
+        """The device group's driver (threads, shares, merges: group_merge.h) with CPU ranks; rc != 0 -> None."""
+        p = self._params(spp_count, 0, 1, 0, False)
+        rgbw = np.zeros(self.frame_shape(), np.float32)
+        st = capi.RenderStats()
+        rc = self.lib.emu_group_render(self._h, int(n_ranks), C.byref(p), {"tile": 0, "sample": 1}[split], {"reduce": 0, "gather": 1}[merge], ptr(rgbw), C.byref(st))
+        return (rgbw, st.as_dict()) if rc == 0 else None

@@ -141,6 +141,7 @@ static f3 run_path_records(const DevScene &sc, const RayIn &cam, uint64_t rng_st
 
 
 #include "emu_wavesim.h"
+#include "../../nori_amd/csrc/device/group_merge.h"
 
 extern "C" {
 
@@ -489,3 +490,48 @@ int emu_render(emu_ctx *c, const nori_render_params *p, float *rgbw, nori_render
 }
 
 } // extern "C"
+
+
+/* The device group of libnori_hip (group.hip) with CPU ranks: the same shares, the same threads-then-merge driver and the
+   same strip lists (group_merge.h), the emulated device code as every rank's renderer.  Checked against ONE render of the
+   whole frame (tests/test_distributed_cpu.py). */
+extern "C" int emu_group_render(emu_ctx *c, int n_ranks, const nori_render_params *params, int split, int merge, float *rgbw, nori_render_stats *stats) {
+    if (!c || !params || !rgbw || n_ranks < 1) return NORI_ERR_INVALID_ARGUMENT;
+    const int W = c->dev.camera.width, H = c->dev.camera.height, border = c->dev.filter.border;
+    const int rows = H + 2 * border, cols = W + 2 * border;
+    const uint32_t tiles_x = (uint32_t) ((W + kTile - 1) / kTile);
+    if (merge == kMergeGather && (split != kSplitTile || tiles_x % (uint32_t) n_ranks != 0u)) return NORI_ERR_INVALID_ARGUMENT;
+    const size_t frame_floats = (size_t) rows * cols * 4;
+    std::vector<std::vector<float>> frames((size_t) n_ranks, std::vector<float>(frame_floats, 0.0f));
+    std::vector<nori_render_stats> st((size_t) n_ranks);
+    std::vector<int> rc((size_t) n_ranks, NORI_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_ranks; ++k) th.emplace_back([&, k] {
+        const GroupShare sh = group_share(split, k, n_ranks, params->spp_begin, params->spp_count);
+        nori_render_params p = *params;
+        p.spp_begin = sh.spp_begin; p.spp_count = sh.spp_count; p.tile_mod = sh.tile_mod; p.tile_rem = sh.tile_rem;
+        rc[(size_t) k] = emu_render(c, &p, frames[(size_t) k].data(), &st[(size_t) k]);
+    });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n_ranks; ++k) if (rc[(size_t) k] != NORI_OK) return rc[(size_t) k];
+    std::vector<float> &root = frames[0];
+    for (int k = 1; k < n_ranks; ++k) {
+        if (merge == kMergeGather) {
+            const std::vector<int32_t> x = group_strip_columns(k, n_ranks, tiles_x, border, cols);
+            std::vector<float> pack(x.size() * (size_t) rows * 4);
+            group_pack_strips(frames[(size_t) k].data(), rows, cols, x, pack.data());      /* "device k" */
+            group_add_strips(root.data(), rows, cols, x, pack.data());                     /* "device 0" */
+        } else {
+            for (size_t i = 0; i < frame_floats; ++i) root[i] += frames[(size_t) k][i];
+        }
+    }
+    std::memcpy(rgbw, root.data(), frame_floats * sizeof(float));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        for (int k = 0; k < n_ranks; ++k) {
+            stats->n_camera_samples += st[(size_t) k].n_camera_samples; stats->n_closest_rays += st[(size_t) k].n_closest_rays;
+            stats->n_shadow_rays += st[(size_t) k].n_shadow_rays; stats->n_invalid += st[(size_t) k].n_invalid;
+        }
+    }
+    return NORI_OK;
+}

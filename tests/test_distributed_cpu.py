@@ -27,8 +27,44 @@ def whole():
     return _whole()
 
 
+@pytest.mark.parametrize("world,split,merge", [(1, "tile", "reduce"), (1, "tile", "gather"), (2, "tile", "reduce"), (2, "tile", "gather"), (2, "sample", "reduce"), (3, "tile", "reduce"),
+                                               (3, "sample", "reduce"), (4, "tile", "gather"), (8, "tile", "reduce"), (8, "sample", "reduce")])
+def test_device_group_driver_on_cpu_ranks(whole, world, split, merge):
+    """The driver behind `nori scene.xml --gpus N` / nori_hip_group_render_host (group.hip): one thread per rank rendering its
+    share (group_merge.h), then the merge on rank 0 -- with the emulated device code as every rank's renderer.  Equal to ONE
+    render of the whole frame up to float summation order; equal ray counts."""
+    from nori_amd import workloads
+    from tests.backends import Emu
+    sc = workloads.load("pa4-cbox-path_mis", SIZE["width"], SIZE["height"], SIZE["spp"]).scene
+    got = Emu(sc).group_render_host(world, split, merge)
+    assert got is not None
+    ref, st = whole
+    np.testing.assert_allclose(got[0], ref, rtol=2e-5, atol=1e-6)
+    assert got[1]["n_closest_rays"] == st["n_closest_rays"] and got[1]["n_shadow_rays"] == st["n_shadow_rays"]
+
+
+def test_device_group_gather_rules_and_wide_frames():
+    """The gather merge needs whole tile columns per rank; eight ranks on a 128-px-wide frame (8 tile columns), and a border
+    so wide that a rank's own strips overlap (16 world < 16 + 2 border): every column is packed once."""
+    from nori_amd import workloads
+    from nori_amd.scene import RFilter
+    from tests import scenes
+    from tests.backends import Emu
+    sc = workloads.load("pa4-cbox-path_mis", 64, 48, 2).scene          # 4 tile columns
+    assert Emu(sc).group_render_host(3, "tile", "gather") is None      # 4 % 3 != 0
+    assert Emu(sc).group_render_host(2, "sample", "gather") is None    # gather is a tile-split merge
+    for world, width, radius in ((8, 128, 2.0), (2, 64, 8.4), (4, 64, 6.0)):
+        sc = scenes.cornell_box(width, 20, 2, "path_mis", rfilter=RFilter("gaussian", radius=radius, stddev=radius / 4))
+        e = Emu(sc)
+        ref, st = e.render_host()
+        for merge in ("gather", "reduce"):
+            got = e.group_render_host(world, "tile", merge)
+            np.testing.assert_allclose(got[0], ref, rtol=2e-5, atol=1e-6, err_msg=f"{world} ranks, {merge}, radius {radius}")
+            assert got[1]["n_closest_rays"] == st["n_closest_rays"]
+
+
 @pytest.mark.parametrize("world,split,merge", [(2, "tile", "reduce"), (2, "tile", "gather"), (2, "sample", "reduce"),
-                                               (3, "tile", "reduce"), (4, "tile", "gather")])
+                                               (3, "tile", "reduce"), (4, "tile", "gather"), (8, "tile", "reduce")])
 def test_bench_spawns_ranks_and_merges(tmp_path, whole, world, split, merge):
     """`python bench.py --gpus N` starts its own N ranks (no external launcher) and rank 0 holds the merged frame."""
     frame = tmp_path / "frame.npy"

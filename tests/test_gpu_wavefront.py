@@ -225,3 +225,67 @@ def test_contexts_own_their_buffers():
     c.set_option("engine", "wavefront")
     assert np.array_equal(c.render_host()[0], A1)
     b.close(); c.close()
+
+
+@pytest.mark.parametrize("members,split,merge", [(1, "tile", "reduce"), (2, "tile", "reduce"), (2, "tile", "gather"), (3, "sample", "reduce"), (4, "tile", "gather")])
+def test_device_group_shares_and_merges(members, split, merge):
+    """nori_hip_group_* (what `nori scene.xml --gpus N` calls): one context + one host thread per group member, every
+    member renders its share into its own frame, one merge on the first member.  On a one-GPU box the members are the same
+    device listed several times -- the whole path (threads, shares, pack / add kernels, the merge) runs, only the transport
+    is a device copy instead of RCCL.  The merged frame equals ONE render of the whole frame up to summation order."""
+    from nori_amd.render import DeviceGroup, Renderer
+    sc = scenes.cornell_box(64, 40, 12, "path_mis")
+    whole, st = Renderer(0).upload(sc).render_host()
+    g = DeviceGroup([0] * members).upload(sc)
+    assert g.size == members and g.transport == "copy"
+    got, gst, merge_ms = g.render_host(split, merge)
+    assert gst["n_camera_samples"] == st["n_camera_samples"]
+    assert gst["n_closest_rays"] == st["n_closest_rays"] and gst["n_shadow_rays"] == st["n_shadow_rays"]
+    np.testing.assert_allclose(got, whole, rtol=2e-5, atol=1e-6)
+    again, _, _ = g.render_host(split, merge)            # buffers are reused, frames cleared
+    assert np.array_equal(again, got)
+    g.close()
+
+
+def test_device_group_errors_and_one_rank_rccl(tmp_path):
+    """A device the node does not have is reported as such (`--gpus 2` on a one-GPU box fails at "device 1 not found", not
+    earlier and not later); the gather merge refuses shares that are not whole tile columns; and RCCL itself -- loaded
+    with dlopen, single-process communicators -- runs its reduce with a group of ONE real device."""
+    import subprocess
+    import torch
+    from nori_amd import NoriError, _capi
+    from nori_amd.render import DeviceGroup, Renderer
+    n_dev = torch.cuda.device_count()
+    with pytest.raises(NoriError, match=f"device {n_dev} not found"):
+        DeviceGroup(list(range(n_dev + 1)))
+    sc = scenes.cornell_box(48, 32, 4, "path_mis")        # 3 tile columns
+    g = DeviceGroup([0, 0]).upload(sc)
+    with pytest.raises(NoriError, match="gather merge needs"):
+        g.render_host("tile", "gather")
+    with pytest.raises(NoriError, match="gather merge needs"):
+        g.render_host("sample", "gather")
+    g.close()
+    os.environ["NORI_GROUP_TRANSPORT"] = "rccl"
+    try:
+        g = DeviceGroup([0]).upload(sc)
+        assert g.transport == "rccl"
+        got, _, _ = g.render_host("tile", "reduce")
+    finally:
+        del os.environ["NORI_GROUP_TRANSPORT"]
+    np.testing.assert_allclose(got, Renderer(0).upload(sc).render_host()[0], rtol=2e-5, atol=1e-6)
+    g.close()
+    # the CLI: --gpus beyond what the node has
+    (tmp_path / "box.obj").write_text("v -1 -1 -1\nv 1 -1 -1\nv 1 1 -1\nv -1 1 -1\nv -1 -1 1\nv 1 -1 1\nv 1 1 1\nv -1 1 1\n"
+                                      "f 1 2 3 4\nf 8 7 6 5\nf 1 5 6 2\nf 2 6 7 3\nf 3 7 8 4\nf 5 1 4 8\n")
+    (tmp_path / "scene.xml").write_text("""<scene><integrator type="path_mis"/>
+    <sampler type="independent"><integer name="sampleCount" value="8"/></sampler>
+    <camera type="perspective"><float name="fov" value="60"/><integer name="width" value="48"/><integer name="height" value="32"/>
+      <transform name="toWorld"><lookat origin="0,0,0.5" target="0,0,-1" up="0,1,0"/></transform></camera>
+    <mesh type="obj"><string name="filename" value="box.obj"/>
+      <bsdf type="diffuse"><color name="albedo" value="0.5, 0.5, 0.5"/></bsdf>
+      <emitter type="area"><color name="radiance" value="1, 1, 1"/></emitter></mesh></scene>""")
+    exe = os.path.join(_capi.LIB_DIR, "nori")
+    p = subprocess.run([exe, str(tmp_path / "scene.xml"), "--gpus", str(n_dev + 1)], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and f"device {n_dev} not found" in p.stdout + p.stderr
+    p = subprocess.run([exe, str(tmp_path / "scene.xml"), "--gpus", "1", "--split", "sample"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "1 GPUs, sample split" in p.stdout, p.stdout + p.stderr

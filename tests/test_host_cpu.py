@@ -46,6 +46,26 @@ def test_no_gpu_means_loud_failure_not_fallback():
         Renderer(0)
 
 
+def test_cli_gpus_without_gpu_fails_at_no_device(tmp_path):
+    """`nori scene.xml --gpus 2` parses the scene, flattens it and asks the library for two GPUs: on a box without any the
+    failure is the library's "no HIP device", through NoriException -- not a crash, not a CPU fallback."""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from nori_amd import _capi
+    (tmp_path / "tri.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    (tmp_path / "s.xml").write_text("""<scene><integrator type="normals"/><sampler type="independent"><integer name="sampleCount" value="1"/></sampler>
+      <camera type="perspective"><integer name="width" value="16"/><integer name="height" value="16"/></camera>
+      <mesh type="obj"><string name="filename" value="tri.obj"/></mesh></scene>""")
+    exe = os.path.join(_capi.LIB_DIR, "nori")
+    for extra in (["--gpus", "2"], ["--gpus", "2", "--split", "sample", "--merge", "reduce"]):
+        p = subprocess.run([exe, str(tmp_path / "s.xml")] + extra, capture_output=True, text=True, timeout=120)
+        assert p.returncode != 0 and "no HIP device available" in p.stdout + p.stderr, p.stdout + p.stderr
+    p = subprocess.run([exe, str(tmp_path / "s.xml"), "--gpus", "0"], capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "positive integer" in p.stdout + p.stderr
+
+
 def _write_scene(tmp_path, body, obj=True):
     if obj:
         (tmp_path / "tri.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nv 1 1 0\nvn 0 0 1\nvt 0 0\nvt 1 0\nvt 0 1\nvt 1 1\n"

@@ -4,7 +4,10 @@ reads for `roofline.traffic` and the VALU-issue evidence.   usage: python tools/
 Derived per kernel (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles; FETCH_SIZE reads half of a wide
 coalesced stream on gfx950 -> doubled; counters are summed over the chip):
   elapsed_cycles       GRBM_GUI_ACTIVE / 8 XCDs                         (cross-check: SQ_BUSY_CYCLES / 32 shader engines)
-  valu_busy_frac       4 x SQ_ACTIVE_INST_VALU / (1024 SIMDs x elapsed_cycles)      share of SIMD time issuing VALU
+  valu_busy_frac       SQ_INSTS_VALU x cycles_per_instr / (1024 SIMDs x elapsed_cycles)   share of SIMD time the VALU is occupied.
+                       SQ_ACTIVE_INST_VALU counts one unit per instruction, not its cycles (profiles/r3_valu_counter_calibration.txt);
+                       cycles_per_instr = the kernel's instruction mix x the measured cycles per class (tools/valu_mix.py ->
+                       profiles/*_valu_mix.json; 3.3 when no mix is on file).  <= 1 for any kernel that really runs.
   valu_lanes_per_instr SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU                  active lanes per VALU instruction (of 64)
   valu_useful_frac     valu_busy_frac x lanes / 64                                  share of VALU lane-cycles doing work
   hbm_bytes            (2 x FETCH_SIZE + WRITE_SIZE) x 1024
@@ -42,13 +45,29 @@ for f in sorted(glob.glob(os.path.join(d, f"{tag}_*_counter_collection.csv"))):
         launches[k][r["Counter_Name"]] += 1
 
 
-def derive(c):
+def valu_mix():
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_valu_mix.json"))):
+        try:
+            best = json.load(open(f))["kernels"]
+        except (OSError, ValueError, KeyError):
+            pass
+    return best or {}
+
+
+MIX = valu_mix()
+
+
+def derive(c, kernel=None):
     out = {}
     el = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
     if el > 0:
         out["elapsed_cycles"] = el
-    if el > 0 and "SQ_ACTIVE_INST_VALU" in c:
-        out["valu_busy_frac"] = round(4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * el), 4)
+    insts = c.get("SQ_INSTS_VALU", c.get("SQ_ACTIVE_INST_VALU"))
+    if el > 0 and insts is not None:
+        cyc = MIX.get(kernel, {}).get("cycles_per_instr", 3.3)
+        out["valu_cycles_per_instr"] = cyc
+        out["valu_busy_frac"] = round(min(1.0, insts * cyc / (1024.0 * el)), 4)
     if c.get("SQ_ACTIVE_INST_VALU"):
         out["valu_lanes_per_instr"] = round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / c["SQ_ACTIVE_INST_VALU"], 2)
     if "valu_busy_frac" in out and "valu_lanes_per_instr" in out:
@@ -66,14 +85,14 @@ def derive(c):
 
 kernels = {}
 for k, c in sorted(acc.items()):
-    kernels[k] = {"launches": max(launches[k].values()), "counters": {n: v for n, v in sorted(c.items())}, "derived": derive(c)}
+    kernels[k] = {"launches": max(launches[k].values()), "counters": {n: v for n, v in sorted(c.items())}, "derived": derive(c, k)}
 dom_prefix = "wf_extend" if engine == "wavefront" else "render_kernel"
 dom = collections.defaultdict(float)
 for k, c in acc.items():
     if k.startswith(dom_prefix):
         for n, v in c.items():
             dom[n] += v
-dd = derive(dom)
+dd = derive(dom, next((k for k in sorted(acc, key=lambda k: -acc[k].get("SQ_INSTS_VALU", 0)) if k.startswith(dom_prefix)), None))
 out = {"tag": tag, "workload": workload, "engine": engine, "device_source_sha": source_sha(),
        "collected_with": "tools/profile_round.sh: one rocprofv3 --kernel-trace --pmc run per counter group, one render pass each (tools/wf_probe.py, REPS=1)",
        "kernels": kernels, "dominant_kernel": dict(dd, name=dom_prefix + " (all launches of the pass)"),
