@@ -131,6 +131,24 @@ def test_parser_errors(tmp_path, body, msg):
         host.load_xml(path)
 
 
+def test_exr_files_read_by_an_independent_reader(tmp_path):
+    """The EXR bytes the host writes (src/bitmap.cpp:69-96 in the reference: RGB float channels, comments = "Generated by Nori")
+    are parsed by a second reader written from the file-layout specification (tests/exr_reader.py): header fields, required
+    attributes, alphabetical channel list, an offset table that points exactly at its scan line blocks, and the pixels."""
+    from tests.exr_reader import read_exr_rgb
+    rng = np.random.default_rng(4)
+    for shape in ((17, 23, 3), (1, 1, 3), (40, 3, 3)):
+        img = rng.uniform(-2, 50, shape).astype(np.float32)
+        img[0, 0] = [np.inf, 0.0, -0.0]
+        host.save_images(str(tmp_path / "w"), img)
+        hdr, rgb = read_exr_rgb(str(tmp_path / "w.exr"))
+        assert np.array_equal(rgb, img) and np.array_equal(np.signbit(rgb), np.signbit(img))
+        assert hdr["comments"] == "Generated by Nori" and hdr["compression"] == 0 and hdr["lineOrder"] == 0
+        assert hdr["dataWindow"] == hdr["displayWindow"] == (0, 0, shape[1] - 1, shape[0] - 1)
+        assert [c[:2] for c in hdr["channels"]] == [("B", 2), ("G", 2), ("R", 2)]
+        assert hdr["pixelAspectRatio"] == 1.0 and hdr["screenWindowWidth"] == 1.0 and hdr["screenWindowCenter"] == (0.0, 0.0)
+
+
 def test_exr_png_roundtrip(tmp_path):
     rng = np.random.default_rng(1)
     img = rng.uniform(0, 4, (17, 23, 3)).astype(np.float32)
