@@ -282,8 +282,13 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                    afford to keep them in registers during the shadow walk), not its flags or shadow direction. */
                 uint32_t fl0 = 0u;
                 f4 dB0; dB0.x = dB0.y = dB0.z = dB0.w = 0.0f;
-                if (!pend) { fl0 = S.flags[i]; dB0 = S.dB[i]; }
                 const f4 o = S.o[i], dA0 = S.dA[i];
+                if (!pend) { dB0 = S.dB[i]; fl0 = S.flags[i]; }
+#if !NORI_EXP_NO_PIN
+                /* (the compiler sinks the loads of `o` and `dA` below the test of the flags -- a second trip to HBM per refill;
+                   naming them as inputs of an empty asm statement pins all four loads in front of it) */
+                asm volatile("" :: "v"(o.x), "v"(dA0.x), "v"(fl0), "v"(dB0.x));
+#endif
                 const uint32_t fl = pend ? F_HAS_A : fl0;
                 if (fl & (F_HAS_A | F_HAS_B)) {      /* 0: empty slot */
                     const bool any = (fl & F_HAS_B) != 0u;

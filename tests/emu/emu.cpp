@@ -145,7 +145,7 @@ static f3 run_path_records(const DevScene &sc, const RayIn &cam, uint64_t rng_st
 
 extern "C" {
 
-/* tools/wave_sim.py: counts[level][12] for the first `max_levels` passes of a spp-sample frame under `policy` (6 ints) */
+/* tools/wave_sim.py: counts[level][14] for the first `max_levels` passes of a spp-sample frame under `policy` (7 ints) */
 int emu_wave_sim(emu_ctx *c, uint32_t spp, uint32_t max_levels, const int *policy, uint64_t *counts) {
     const DevScene &sc = c->dev;
     if (sc.integrator.type != 6) return NORI_ERR_INVALID_ARGUMENT;      /* path_mis only */
@@ -164,7 +164,7 @@ int emu_wave_sim(emu_ctx *c, uint32_t spp, uint32_t max_levels, const int *polic
                 RayIn cam; camera_sample_ray(sc.camera, mk2((float) px + j.x, (float) py + j.y), cam);
                 sim_capture_path<6>(sc, cam, rng.state, rng.inc, stack, levels, max_levels);
             }
-    SimPolicy P; P.refill_threshold = policy[0]; P.leaf_threshold = policy[1]; P.inner_repeat = policy[2]; P.postpone = policy[3]; P.chunk = policy[4]; P.sort_octant = policy[5];
+    SimPolicy P; P.refill_threshold = policy[0]; P.leaf_threshold = policy[1]; P.inner_repeat = policy[2]; P.postpone = policy[3]; P.chunk = policy[4]; P.sort_octant = policy[5]; P.pend_threshold = policy[6];
     for (size_t k = 0; k < levels.size() && k < max_levels; ++k) {
         std::vector<SimEntry> &e = levels[k];
         if (P.sort_octant)
@@ -172,7 +172,7 @@ int emu_wave_sim(emu_ctx *c, uint32_t spp, uint32_t max_levels, const int *polic
                 std::stable_sort(e.begin() + b, e.begin() + std::min(e.size(), b + 256), [](const SimEntry &x, const SimEntry &y) { return sim_octant(x) < sim_octant(y); });
         SimCounts C; std::memset(&C, 0, sizeof(C));
         for (size_t b = 0; b < e.size(); b += (size_t) P.chunk) sim_wave(sc, e.data() + b, std::min((size_t) P.chunk, e.size() - b), P, C);
-        std::memcpy(counts + k * 12, &C, sizeof(C));
+        std::memcpy(counts + k * 14, &C, sizeof(C));
     }
     return (int) levels.size();
 }

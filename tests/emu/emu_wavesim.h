@@ -21,10 +21,11 @@ struct SimPolicy {
     int postpone;            /* 1: a lane that reaches a leaf parks it and walks on until it holds a second one */
     int chunk;               /* paths per wave */
     int sort_octant;         /* 1: within blocks of 256 paths, order by the direction octant of the first ray */
+    int pend_threshold;      /* > 0: lanes whose shadow ray is answered start their continuation ray as soon as this many wait (no new paths) */
 };
 
 struct SimCounts {
-    uint64_t rays, trips, node_steps, node_lanes, leaf_steps, leaf_lanes, refills, refill_lanes, lane_node_steps, lane_leaf_steps, node_idle_lanes, node_leaf_lanes;
+    uint64_t rays, trips, node_steps, node_lanes, leaf_steps, leaf_lanes, refills, refill_lanes, lane_node_steps, lane_leaf_steps, node_idle_lanes, node_leaf_lanes, pend_restarts, pend_lanes;
 };
 
 struct SimLeafStack {        /* the leaf step's pop when it works on a parked leaf: nothing to pop, the leaf is done */
@@ -73,6 +74,14 @@ static void sim_wave(const DevScene &sc, const SimEntry *e, size_t n, const SimP
                 const SimEntry &en = e[pos++];
                 if (en.hasB) { sim_begin(sc, l, en.B, true, top); C.rays++; l.pendA = en.hasA; l.nextA = en.A; }
                 else if (en.hasA) { sim_begin(sc, l, en.A, false, top); C.rays++; }
+            }
+        }
+        else if (P.pend_threshold > 0) {
+            int np = 0;
+            for (auto &l : L) if (!sim_active(l) && l.pendA) ++np;
+            if (np >= P.pend_threshold) {
+                C.pend_restarts++; C.pend_lanes += (uint64_t) np;
+                for (auto &l : L) if (!sim_active(l) && l.pendA) { sim_begin(sc, l, l.nextA, false, top); l.pendA = false; C.rays++; }
             }
         }
         bool anyActive = false;
