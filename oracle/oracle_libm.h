@@ -22,6 +22,17 @@
 #include <cstring>
 #include <limits>
 
+#if defined(ORACLE_LIBM_GLIBC)
+/* liboracle_glibc.so: the reference's literal calls (std::sin / std::cos / std::log / std::exp of the host's libm).  Not bit
+   comparable with anything -- it is the independent witness: renders of the pinned-specification oracle and of the device
+   must agree with it within the image tolerance (tests: test_specified_libm_vs_host_libm_renders, test_gpu_parity), so
+   that a mistake shared by the two implementations of the specification cannot pass unnoticed. */
+namespace oracle_libm {
+inline void sincos(float x, float *s, float *c) { *s = std::sin(x); *c = std::cos(x); }
+inline float log(float x) { return std::log(x); }
+inline float exp(float x) { return std::exp(x); }
+} // namespace oracle_libm
+#else
 namespace oracle_libm {
 
 inline double horner(const double *c, int n, double z) {      /* c[0] + z (c[1] + z (... c[n-1])) */
@@ -83,3 +94,4 @@ inline float exp(float xf) {
 }
 
 } // namespace oracle_libm
+#endif

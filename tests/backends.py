@@ -64,7 +64,9 @@ def use_native_oracle() -> bool:
 def oracle_lib():
     global _oracle
     if _oracle is None:
-        lib = C.CDLL(_oracle_path or _make(os.path.join(ROOT, "oracle"), "liboracle.so"))
+        # NORI_ORACLE_LIBRARY: another build of the oracle, e.g. oracle/liboracle_glibc.so (host libm instead of the pinned
+        # specification) -- the independent witness of tests/test_oracle_goldens.py::test_specified_libm_vs_host_libm_renders
+        lib = C.CDLL(_oracle_path or os.environ.get("NORI_ORACLE_LIBRARY") or _make(os.path.join(ROOT, "oracle"), "liboracle.so"))
         protos = {
             "oracle_create": (C.c_int, [C.POINTER(capi.SceneDesc), C.POINTER(_P)]),
             "oracle_destroy": (None, [_P]),

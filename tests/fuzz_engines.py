@@ -60,7 +60,7 @@ def random_scene(rng):
 def one_round(seed, renderer_cls, oracle=False):
     rng = np.random.default_rng(seed)
     sc = random_scene(rng)
-    builder = int(rng.integers(0, 2))
+    builder = int(rng.integers(0, 3))      # host SAH, device radix tree, device PLOC
     mk = renderer_cls(0).upload(sc, builder=builder)
     wf = renderer_cls(0).upload(sc, builder=builder)
     wf.set_option("engine", "wavefront")

@@ -223,6 +223,27 @@ def test_render_matches_oracle(renderer_factory, integ, rf, size):
     assert_image_parity(A, B, r.border, f"{integ}/{rf} {size}")
 
 
+def test_render_matches_the_host_libm_oracle(renderer_factory, tmp_path):
+    """Device and oracle evaluate sin / cos / log / exp by one pinned specification -- which is why they agree bit for bit,
+    and why their agreement says nothing about the specification itself.  The independent witness is the oracle built with
+    the HOST libm's functions (oracle/liboracle_glibc.so: std::sin / cos / log / exp, as the reference calls them): the
+    device render must meet the image contract against it too, with equal ray counts."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "oracle", "liboracle_glibc.so")
+    subprocess.run(["make", "-C", os.path.join(root, "oracle"), "liboracle_glibc.so"], check=True, capture_output=True)
+    out = tmp_path / "glibc.npy"
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "oracle_render.py"), "cornell", "64", "48", "8", "path_mis", str(out)],
+                       capture_output=True, text=True, cwd=root, env=dict(os.environ, NORI_ORACLE_LIBRARY=lib), timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    sc = scenes.cornell_box(64, 48, 8, "path_mis", sphere_bsdfs=[Bsdf("microfacet", (0.2, 0.3, 0.1), 0.2), Bsdf("dielectric")])
+    r = renderer_factory(sc)
+    got, st = r.render_host()
+    assert [str(st["n_closest_rays"]), str(st["n_shadow_rays"])] == p.stdout.split()
+    assert_image_parity(np.load(out), got, r.border, "device vs host-libm oracle")
+
+
 def test_tile_and_sample_split_sum_to_whole(renderer_factory):
     sc = scenes.cornell_box(72, 40, 12, "path_mis")
     r = renderer_factory(sc)

@@ -289,3 +289,25 @@ def test_device_group_errors_and_one_rank_rccl(tmp_path):
     assert p.returncode != 0 and f"device {n_dev} not found" in p.stdout + p.stderr
     p = subprocess.run([exe, str(tmp_path / "scene.xml"), "--gpus", "1", "--split", "sample"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "1 GPUs, sample split" in p.stdout, p.stdout + p.stderr
+
+
+@pytest.mark.parametrize("builder,layout", [(0, "bvh2"), (1, "bvh2"), (2, "bvh2"), (0, "bvh4q"), (2, "bvh4q")])
+def test_lds_image_of_hot_records_changes_nothing(builder, layout):
+    """wf_extend walks the hottest nodes and leaf pair records from an image in LDS (rt_top.h: built once per acceleration
+    structure by a greedy walk from the root, links rewritten to LDS slots).  With the image switched off every link is a
+    memory link: the frame -- same paths, same film order -- must be the same bits, for every builder and both node layouts."""
+    from nori_amd.render import Renderer
+    sc = scenes.cornell_box(96, 64, 6, "path_mis", sphere_bsdfs=[Bsdf("microfacet", (0.2, 0.3, 0.1), 0.2), Bsdf("dielectric")])
+    frames = []
+    for off in (False, True):
+        if off:
+            os.environ["NORI_HIP_NO_TOP_IMAGE"] = "1"
+        try:
+            r = Renderer(0); r.set_option("accel_layout", layout); r.upload(sc, builder=builder); r.set_option("engine", "wavefront")
+            frames.append(r.render_host())
+            r.close()
+        finally:
+            os.environ.pop("NORI_HIP_NO_TOP_IMAGE", None)
+    (a, sa), (b, sb) = frames
+    assert np.array_equal(a, b)
+    assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
