@@ -120,6 +120,11 @@ __global__ void k_ploc_apply(PlocClusters in, PlocClusters out, PlocNodes nodes,
     const unsigned long long f = flags[i], r = incl[i] - f;      /* exclusive ranks */
     ploc_apply(in, out, nodes, nearest, i, (uint32_t) (f >> 32), (uint32_t) f & 1u, (uint32_t) (r >> 32), (uint32_t) r, node_base);
 }
+__global__ void k_treelet(PlocNodes nodes, TreeletData td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad, TreeletParams tp,
+                          uint32_t *visits, uint32_t n) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) treelet_climb(nodes, td, pos, idx, order, pad, tp, visits, n - 2u, k);
+}
 __global__ void k_ploc_leaf_positions(PlocNodes nodes, uint32_t n, const uint32_t *order, uint32_t *leaf_pos, uint32_t *order_out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -312,6 +317,28 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
             }
             if (node_base != n - 1u) return "lbvh: PLOC node count";
             out.ploc_iterations = iterations;
+            {   /* treelet restructuring (lbvh_steps.h): one launch per sweep, a thread per triangle climbing the tree */
+                /* two sweeps up to 2^20 triangles, none above (NORI_HIP_TREELET_SWEEPS overrides).  Measured (MI355X, profiles/r3_06_*):
+                   328 k-triangle AO scene: build 40 ms with two sweeps (host SAH: 103 ms), wf_extend 12.0 ms against the host tree's 11.8;
+                   10 M-triangle terrain: every sweep costs 340 ms (one thread per treelet, 1.1 KB of scratch each) and brings wf_extend from
+                   33.5 to 32.6 / 32.7 / 32.2 ms after 1 / 2 / 3 sweeps (host SAH tree: 29.5) -- not worth ten times PLOC's 30 ms.
+                   CPU probe (tools/builder_probe.py), 200 k-triangle terrain, wide nodes: node tests per ray 14.98 / 14.47 / 14.32 / 14.29
+                   after 0 / 1 / 2 / 3 sweeps (host SAH: 13.72); Cornell box, BVH2: 9.31 -> 8.49 (host SAH: 8.77). */
+                int sweeps = n <= (1u << 20) ? 2 : 0;
+                if (const char *e = getenv("NORI_HIP_TREELET_SWEEPS")) sweeps = std::max(0, atoi(e));
+                if (sweeps > 0) {
+                    Buf t_mn, t_mx, t_cost, t_visits;
+                    LB_TRY(t_mn.alloc((size_t) n * 16)); LB_TRY(t_mx.alloc((size_t) n * 16)); LB_TRY(t_cost.alloc((size_t) n * 4)); LB_TRY(t_visits.alloc((size_t) n * 4));
+                    TreeletData td{t_mn.as<f4>(), t_mx.as<f4>(), t_cost.as<float>()};
+                    TreeletParams tp; tp.c_node = 1.0f; tp.c_tri = 1.0f;
+                    for (int sw = 0; sw < sweeps; ++sw) {
+                        LB_TRY(hipMemsetAsync(t_visits.p, 0, (size_t) n * 4, 0));
+                        hipLaunchKernelGGL(k_treelet, dim3((n + 63) / 64), dim3(64), 0, 0, pn, td, dev.positions, dev.indices, order, pad, tp, t_visits.as<uint32_t>(), n);
+                    }
+                    LB_TRY(hipGetLastError());
+                    LB_TRY(hipDeviceSynchronize());      /* the buffers go out of scope here */
+                }
+            }
             /* the order of the tree's leaves, left to right: every node covers a contiguous range of it */
             hipLaunchKernelGGL(k_ploc_leaf_positions, dim3(gridN), dim3(B), 0, 0, pn, n, order, leaf_pos.as<uint32_t>(), vals_a.as<uint32_t>());
             hipLaunchKernelGGL(k_ploc_finish, dim3(gridN), dim3(B), 0, 0, pn, n - 1u, leaf_pos.as<uint32_t>(), rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());

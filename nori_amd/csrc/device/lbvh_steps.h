@@ -217,6 +217,144 @@ NORI_HD void tri_leaf_box(const f4 *pos, const uint32_t *idx, uint32_t g, float 
     mn4.x = mn.x - pad; mn4.y = mn.y - pad; mn4.z = mn.z - pad; mx4.x = mx.x + pad; mx4.y = mx.y + pad; mx4.z = mx.z + pad;
     mn4.w = mx4.w = 0.0f;
 }
+/* ---- treelet restructuring (Karras & Aila 2013) of the PLOC tree ----
+ * PLOC chooses every merge locally; what it leaves on the table sits inside small subtrees (a
+ * top-down SAH rebuild ABOVE the subtrees recovers only a third of the gap to the host's SAH tree).  A treelet is a node
+ * with the <= 7 subtrees that hang below it after repeatedly opening the child of largest surface area; for those <= 7
+ * leaves the topology of minimal SAH cost is found exactly -- dynamic programming over their 2^7 subsets -- and the
+ * treelet's inner nodes are rewired to it.  Bottom-up, whatever shape the tree has by now (a sweep rewires ids, so PLOC's
+ * creation order stops being a schedule after the first one): treelet_climb starts at every triangle and walks up the
+ * parent links; at a node the FIRST of the two arrivals stops, the second -- both subtrees below are finished --
+ * optimizes the node's treelet and climbs on.  Which thread does a node is a matter of timing; what it computes is not.
+ * Per node: box (xyz of two f4), SAH cost of its subtree  C(node) = c_node A(node) + C(left) + C(right),  C(triangle) =
+ * c_tri A(triangle).  Treelets that contain an unbounded box (numerically collinear triangles) are left alone. */
+constexpr int kTreeletLeaves = 7;
+struct TreeletData { f4 *nmn, *nmx; float *cost; };
+struct TreeletParams { float c_node, c_tri; };
+
+NORI_HD void treelet_child(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
+                           TreeletParams tp, uint32_t child, f3 &mn, f3 &mx, float &cost, uint32_t &count) {
+    if (child & kLeafBit) {
+        f4 a, b; tri_leaf_box(pos, idx, order[child & ~kLeafBit], pad, a, b);
+        mn = xyz(a); mx = xyz(b); count = 1u;
+        cost = tp.c_tri * half_area(mn, mx);
+    } else {
+        mn = xyz(td.nmn[child]); mx = xyz(td.nmx[child]); count = nodes.count[child]; cost = td.cost[child];
+    }
+}
+NORI_HD void treelet_set_parent(const PlocNodes &nodes, uint32_t child, uint32_t parent) {
+    if (child & kLeafBit) nodes.parent_prim[child & ~kLeafBit] = parent; else nodes.parent_node[child] = parent;
+}
+/* box and cost of node `id` from its children (first sweep: nothing is known yet), then the optimal treelet below it */
+NORI_HD void treelet_optimize(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
+                              TreeletParams tp, uint32_t id) {
+    uint32_t leaf[kTreeletLeaves], cnt[kTreeletLeaves], inner[kTreeletLeaves];      /* treelet leaves; the inner node ids the treelet owns (inner[0] = id) */
+    f3 lmn[kTreeletLeaves], lmx[kTreeletLeaves]; float lcost[kTreeletLeaves];
+    int k = 2, n_inner = 1;
+    inner[0] = id;
+    leaf[0] = nodes.left[id]; leaf[1] = nodes.right[id];
+    for (int i = 0; i < 2; ++i) treelet_child(nodes, td, pos, idx, order, pad, tp, leaf[i], lmn[i], lmx[i], lcost[i], cnt[i]);
+    bool bounded = lmx[0].x < kBoxInf && lmx[1].x < kBoxInf;
+    {   /* this node as it stands */
+        const f3 mn = mk3(fminf(lmn[0].x, lmn[1].x), fminf(lmn[0].y, lmn[1].y), fminf(lmn[0].z, lmn[1].z));
+        const f3 mx = mk3(fmaxf(lmx[0].x, lmx[1].x), fmaxf(lmx[0].y, lmx[1].y), fmaxf(lmx[0].z, lmx[1].z));
+        f4 a, b; a.x = mn.x; a.y = mn.y; a.z = mn.z; a.w = 0.0f; b.x = mx.x; b.y = mx.y; b.z = mx.z; b.w = 0.0f;
+        td.nmn[id] = a; td.nmx[id] = b;
+        td.cost[id] = bounded ? tp.c_node * half_area(mn, mx) + (lcost[0] + lcost[1]) : 1e30f;
+    }
+    if (!bounded) return;
+    while (k < kTreeletLeaves) {      /* open the inner treelet leaf of largest area */
+        int best = -1; float bestArea = -1.0f;
+        for (int i = 0; i < k; ++i) {
+            if (leaf[i] & kLeafBit) continue;
+            const float a = half_area(lmn[i], lmx[i]);
+            if (a > bestArea) { bestArea = a; best = i; }
+        }
+        if (best < 0) break;
+        const uint32_t open = leaf[best];
+        inner[n_inner++] = open;
+        const uint32_t a = nodes.left[open], b = nodes.right[open];
+        leaf[best] = a; leaf[k] = b;
+        treelet_child(nodes, td, pos, idx, order, pad, tp, a, lmn[best], lmx[best], lcost[best], cnt[best]);
+        treelet_child(nodes, td, pos, idx, order, pad, tp, b, lmn[k], lmx[k], lcost[k], cnt[k]);
+        if (!(lmx[best].x < kBoxInf) || !(lmx[k].x < kBoxInf)) return;
+        ++k;
+    }
+    if (k < 3) return;                  /* two leaves: one topology */
+    /* dynamic programming over the subsets of the k leaves */
+    const int full = (1 << k) - 1;
+    float area[1 << kTreeletLeaves], copt[1 << kTreeletLeaves];
+    unsigned char part[1 << kTreeletLeaves];
+    for (int S = 1; S <= full; ++S) {
+        f3 mn = mk3(kInf), mx = mk3(-kInf);
+        for (int i = 0; i < k; ++i)
+            if (S & (1 << i)) { mn = mk3(fminf(mn.x, lmn[i].x), fminf(mn.y, lmn[i].y), fminf(mn.z, lmn[i].z)); mx = mk3(fmaxf(mx.x, lmx[i].x), fmaxf(mx.y, lmx[i].y), fmaxf(mx.z, lmx[i].z)); }
+        area[S] = half_area(mn, mx);
+    }
+    for (int i = 0; i < k; ++i) copt[1 << i] = lcost[i];
+    for (int S = 3; S <= full; ++S) {
+        if ((S & (S - 1)) == 0) continue;                   /* a single leaf */
+        float best = kInf; int bestP = 0;
+        const int delta = (S - 1) & S;                       /* S without its lowest bit: the partitions P that keep the lowest bit out are all of them once */
+        int P = (-delta) & S;
+        do {
+            const float c = copt[P] + copt[S ^ P];
+            if (c < best) { best = c; bestP = P; }
+            P = (P - delta) & S;
+        } while (P != 0);
+        copt[S] = tp.c_node * area[S] + best;
+        part[S] = (unsigned char) bestP;
+    }
+    if (!(copt[full] < td.cost[id] * 0.99999f)) return;     /* nothing to gain: leave the subtree as PLOC built it */
+    /* rewire: the treelet's inner ids take the subsets of the optimal topology, top down */
+    int stack_S[kTreeletLeaves]; uint32_t stack_id[kTreeletLeaves]; int sp = 0, used = 1;
+    stack_S[sp] = full; stack_id[sp] = id; ++sp;
+    while (sp > 0) {
+        --sp;
+        const int S = stack_S[sp]; const uint32_t me = stack_id[sp];
+        const int halves[2] = {(int) part[S], S ^ (int) part[S]};
+        uint32_t child_id[2];
+        for (int h = 0; h < 2; ++h) {
+            const int T = halves[h];
+            if ((T & (T - 1)) == 0) {                        /* one leaf of the treelet */
+                int i = 0; while (!(T & (1 << i))) ++i;
+                child_id[h] = leaf[i];
+            } else {
+                child_id[h] = inner[used++];
+                stack_S[sp] = T; stack_id[sp] = child_id[h]; ++sp;
+            }
+            treelet_set_parent(nodes, child_id[h], me);
+        }
+        nodes.left[me] = child_id[0]; nodes.right[me] = child_id[1];
+        f3 mn = mk3(kInf), mx = mk3(-kInf); uint32_t c = 0u;
+        for (int i = 0; i < k; ++i)
+            if (S & (1 << i)) { mn = mk3(fminf(mn.x, lmn[i].x), fminf(mn.y, lmn[i].y), fminf(mn.z, lmn[i].z)); mx = mk3(fmaxf(mx.x, lmx[i].x), fmaxf(mx.y, lmx[i].y), fmaxf(mx.z, lmx[i].z)); c += cnt[i]; }
+        f4 a, b; a.x = mn.x; a.y = mn.y; a.z = mn.z; a.w = 0.0f; b.x = mx.x; b.y = mx.y; b.z = mx.z; b.w = 0.0f;
+        td.nmn[me] = a; td.nmx[me] = b; td.cost[me] = copt[S]; nodes.count[me] = c;
+    }
+}
+
+/* One sweep = treelet_climb for every triangle position k (visits[] zeroed before).  On the device the arrival counter is an
+   atomic with a fence on either side: what the other subtree's thread wrote must be visible, and this CU's L1 may still
+   hold lines from before it was written (MI355X: the vector L1 is not refreshed by other CUs' stores). */
+NORI_HD void treelet_climb(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
+                           TreeletParams tp, uint32_t *visits, uint32_t root_id, uint32_t k) {
+    uint32_t p = nodes.parent_prim[k];
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __threadfence();
+        const uint32_t before = atomicAdd(&visits[p], 1u);
+        __threadfence();
+#else
+        const uint32_t before = visits[p]++;
+#endif
+        if (before == 0u) return;
+        treelet_optimize(nodes, td, pos, idx, order, pad, tp, p);
+        if (p == root_id) return;
+        p = nodes.parent_node[p];
+    }
+}
+
 /* min / max segment tree over the boxes in the builder's order: leaves at [N + k], node i = union of 2 i, 2 i + 1 */
 NORI_HD void seg_tree_combine(uint32_t i, f4 *tmin, f4 *tmax) {
     const f4 a = tmin[2 * i], b = tmin[2 * i + 1], c = tmax[2 * i], d = tmax[2 * i + 1];

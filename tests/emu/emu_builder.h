@@ -9,6 +9,7 @@
  */
 #pragma once
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -90,6 +91,18 @@ inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint3
             }
             if (node_base != n - 1u) return "PLOC node count";
             if (stats) stats->ploc_iterations = iterations;
+            {   /* treelet restructuring (lbvh_steps.h), as build_bvh_lbvh_device runs it */
+                int sweeps = n <= (1u << 20) ? 2 : 0;
+                if (const char *e = std::getenv("NORI_HIP_TREELET_SWEEPS")) sweeps = std::max(0, atoi(e));
+                std::vector<f4> nmn(n), nmx(n); std::vector<float> ncost(n);
+                TreeletData td{nmn.data(), nmx.data(), ncost.data()};
+                TreeletParams tp; tp.c_node = 1.0f; tp.c_tri = 1.0f;
+                std::vector<uint32_t> visits(n);
+                for (int sw = 0; sw < sweeps; ++sw) {
+                    std::fill(visits.begin(), visits.end(), 0u);
+                    for (uint32_t k = 0; k < n; ++k) treelet_climb(pn, td, pos, idx, order.data(), pad, tp, visits.data(), n - 2u, k);
+                }
+            }
             for (uint32_t k = 0; k < n; ++k) { leaf_pos[k] = ploc_first_position(pn, n - 1u, kLeafBit | k); order2[leaf_pos[k]] = order[k]; }
             for (uint32_t id = 0; id + 1 < n; ++id) rnodes[n - 2u - id] = ploc_finish(pn, n - 1u, id, leaf_pos.data(), pin.data(), plf.data());
             order.swap(order2);
