@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "film.h"
@@ -209,6 +210,118 @@ __global__ __launch_bounds__(kB) void film_block_reference_kernel(int width, int
     if ((threadIdx.x & 63u) == 0u && invalid) atomicAdd(st.d_invalid, invalid);
 }
 
+/* The same sums in the same order, with every sample fetched 2 border + 1 times instead of (2 border + 1)^2 times.
+ *
+ * For ONE output pixel the reference's order is a chain: source rows ascending, within a row the sources left to right,
+ * within a source its samples by index.  Chains of different output pixels are independent, and at any moment the
+ * outputs that take from source row sy are the 2 border + 1 accumulator rows [sy, sy + 2 border]; each of them meets the
+ * row's sources in 2 border + 1 PHASES: in phase j the output at column ox adds source sx = ox - (2 border - j) -- every
+ * output its own source, all with the same horizontal tap k = 2 border - j.  So, per source row and per phase, the row's
+ * samples are staged through LDS chunk by chunk (premultiplied: L wx[k] -- (L wx) wy keeps the reference's
+ * association, src/block.cpp:88-90 -- the weight wx[k] itself for the W channel, and wy for all 2 border + 1 rows), and
+ * every thread -- one output pixel of a ring of 2 border + 1 accumulator rows -- adds its source's samples of the chunk in
+ * order.  When a source row is done, the accumulator row that just received its last source is written out and its ring
+ * slot starts the row that enters below. */
+constexpr int kRefChunk = 32;          /* samples of one source pixel staged per round (16 for filters of more than 11 taps: LDS) */
+#define NORI_REF_UNROLL 4      /* terms whose LDS reads are in flight together (2: 8.5 ms, 4: 8.4, 8: 12.9 -- registers) */
+constexpr int kRefMaxSlots = 4;        /* (2 * 8 + 1) * (32 + 16) / 256 rounded up */
+
+__global__ __launch_bounds__(kB) void film_block_reference_staged_kernel(int width, int height, FilterRec fr, const float *__restrict__ filter_table,
+                                                                         FilmStore st, uint32_t n_spp, uint32_t tiles_x, uint32_t blocks_x, int chunk) {
+    extern __shared__ __attribute__((aligned(16))) float s_ref[];      /* [chunk][32] float4 (r wx, g wx, b wx, wx), then wy[taps][chunk][32] */
+    __shared__ float ftab[kFilterRes + 1];
+    if (threadIdx.x <= kFilterRes) ftab[threadIdx.x] = filter_table[threadIdx.x];
+    const int tid = (int) threadIdx.x;
+    const int bx = (int) (blockIdx.x % blocks_x), by = (int) (blockIdx.x / blocks_x);
+    const int offx = bx * kBlock32, offy = by * kBlock32;
+    const int bw = min(kBlock32, width - offx), bh = min(kBlock32, height - offy);
+    const int border = fr.border, taps = 2 * border + 1, cols = bw + 2 * border;
+    const int stride = kBlock32 + 2 * border;
+    const float radius = fr.radius, lookup = fr.lookup_factor;
+    float4 *dst = reinterpret_cast<float4 *>(st.block_acc) + (size_t) blockIdx.x * stride * stride;
+    const int plane = chunk * kBlock32;
+    float4 *s_lw = reinterpret_cast<float4 *>(s_ref);      /* one ds_read_b128 per term: consecutive lanes read consecutive float4s (conflict free) */
+    float *s_wy = s_ref + 4 * plane;                       /* s_wy[m][s][sx] */
+    const int n_slots = taps * cols;
+    float4 acc[kRefMaxSlots];
+    for (int a = 0; a < kRefMaxSlots; ++a) acc[a] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    unsigned long long invalid = 0;
+    __syncthreads();
+    for (int sy = 0; sy < bh; ++sy) {
+        const int py = offy + sy;
+        for (int j = 0; j < taps; ++j) {
+            const int k = taps - 1 - j;                       /* output column = source column + k */
+            for (uint32_t c0 = 0; c0 < n_spp; c0 += (uint32_t) chunk) {
+                const int cs = (int) min((uint32_t) chunk, n_spp - c0);
+                /* stage samples [c0, c0 + cs) of the row's bw source pixels (requesting a thread's four samples ahead of their
+                   weights measured slower: 10.7 against 8.4 ms) */
+                for (int e = tid; e < cs * bw; e += kB) {
+                    const int sl = e / bw, sx = e - sl * bw;
+                    const int px = offx + sx;
+                    const uint32_t tile = (uint32_t) (py / kTile) * tiles_x + (uint32_t) (px / kTile);
+                    const int lx = px % kTile, ly = py % kTile;
+                    const uint32_t pix = (uint32_t) ((((lx >> 3) | ((ly >> 3) << 1)) << 6) | ((lx & 7) | ((ly & 7) << 3)));      /* inverse of film_tile_pixel */
+                    const size_t idx = (size_t) tile * n_spp * 256u + pix + (size_t) (c0 + (uint32_t) sl) * 256u;
+                    const f4 L = st.L[idx];
+                    const f2 p = st.pos[idx];
+                    const bool ok = color_valid(mk3(L.x, L.y, L.z));
+                    if (j == 0 && !ok) ++invalid;              /* every sample is staged once with j == 0 */
+                    const float bpx = p.x - 0.5f - (float) (offx - border), bpy = p.y - 0.5f - (float) (offy - border);
+                    const float fx = (float) (sx + k);
+                    const bool inx = ok && fx >= bpx - radius && fx <= bpx + radius;
+                    const float wx = inx ? ftab[(int) (fabsf(fx - bpx) * lookup)] : 0.0f;
+                    const int o = sl * kBlock32 + sx;
+                    /* a sample outside the pixel's bounding box (block.cpp:76-80) or rejected by isValid() (:63-67) gets weight 0 and
+                       radiance 0: it adds (0 * 0) * wy = +0, which leaves an accumulator's bits alone (it is never -0) */
+                    s_lw[o] = make_float4((inx ? L.x : 0.0f) * wx, (inx ? L.y : 0.0f) * wx, (inx ? L.z : 0.0f) * wx, 1.0f * wx);
+                    for (int m = 0; m < taps; ++m) {
+                        const float fy = (float) (sy + m);
+                        const bool iny = ok && fy >= bpy - radius && fy <= bpy + radius;
+                        s_wy[m * plane + o] = iny ? ftab[(int) (fabsf(fy - bpy) * lookup)] : 0.0f;
+                    }
+                }
+                __syncthreads();
+                for (int a = 0; a < kRefMaxSlots; ++a) {
+                    const int slot = tid + a * kB;
+                    if (slot >= n_slots) break;
+                    const int q = slot / cols, ox = slot - q * cols;
+                    const int sx = ox - k;
+                    if (sx < 0 || sx >= bw) continue;
+                    /* the accumulator row of ring slot q that is active at source row sy: oy in [sy, sy + taps) with oy % taps == q */
+                    const int oy = sy + ((q - sy % taps) + taps) % taps;
+                    const float *wy = s_wy + (oy - sy) * plane + sx;
+                    float4 v = acc[a];
+                    int sl = 0;
+                    for (; sl + NORI_REF_UNROLL <= cs; sl += NORI_REF_UNROLL) {      /* several terms' LDS reads in flight, then their adds in order */
+                        float4 lw[NORI_REF_UNROLL]; float w[NORI_REF_UNROLL];
+#pragma unroll
+                        for (int u = 0; u < NORI_REF_UNROLL; ++u) { lw[u] = s_lw[(sl + u) * kBlock32 + sx]; w[u] = wy[(sl + u) * kBlock32]; }
+#pragma unroll
+                        for (int u = 0; u < NORI_REF_UNROLL; ++u) { v.x += lw[u].x * w[u]; v.y += lw[u].y * w[u]; v.z += lw[u].z * w[u]; v.w += lw[u].w * w[u]; }
+                    }
+                    for (; sl < cs; ++sl) {
+                        const float4 lw = s_lw[sl * kBlock32 + sx];
+                        const float w = wy[sl * kBlock32];
+                        v.x += lw.x * w; v.y += lw.y * w; v.z += lw.z * w; v.w += lw.w * w;
+                    }
+                    acc[a] = v;
+                }
+                __syncthreads();
+            }
+        }
+        /* accumulator row sy has received its last source row (sy); at the block's last source row all open rows have */
+        for (int a = 0; a < kRefMaxSlots; ++a) {
+            const int slot = tid + a * kB;
+            if (slot >= n_slots) break;
+            const int q = slot / cols, ox = slot - q * cols;
+            const int oy = sy + ((q - sy % taps) + taps) % taps;
+            if (oy == sy || sy == bh - 1) { dst[oy * stride + ox] = acc[a]; acc[a] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) invalid += __shfl_down(invalid, off);
+    if ((threadIdx.x & 63u) == 0u && invalid) atomicAdd(st.d_invalid, invalid);
+}
+
 /* ImageBlock::put(ImageBlock&) in the order the blocks arrive from BlockGenerator: every frame pixel adds the blocks
    covering it by ascending spiral rank */
 __global__ void film_resolve_reference_kernel(int width, int height, int border, uint32_t blocks_x, uint32_t blocks_y,
@@ -338,7 +451,14 @@ std::string film_reference_order(FilmStore &store, const FilmStore &view, const 
     FILM_TRY(hipMemcpyAsync(store.spiral_rank, rank.data(), (size_t) nb * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t) stream));
     FILM_TRY(hipStreamSynchronize((hipStream_t) stream));                       /* `rank` is a host temporary */
     FilmStore v = view; v.block_acc = store.block_acc; v.spiral_rank = store.spiral_rank;
-    hipLaunchKernelGGL(film_block_reference_kernel, dim3(nb), dim3(kB), 0, (hipStream_t) stream, w, h, sc.filter, d_filter_table, v, n_spp, tiles_x, bxn);
+    static const bool unstaged = getenv("NORI_HIP_FILM_REF_UNSTAGED") != nullptr;      /* the first implementation, for A / B: one thread per output pixel reading its sources from memory */
+    if (unstaged) hipLaunchKernelGGL(film_block_reference_kernel, dim3(nb), dim3(kB), 0, (hipStream_t) stream, w, h, sc.filter, d_filter_table, v, n_spp, tiles_x, bxn);
+    else {
+        int chunk = 2 * border + 1 > 11 ? kRefChunk / 2 : kRefChunk;
+        if (const char *e = getenv("NORI_HIP_FILM_REF_CHUNK")) chunk = std::min(kRefChunk, std::max(4, atoi(e)));
+        hipLaunchKernelGGL(film_block_reference_staged_kernel, dim3(nb), dim3(kB), (size_t) (4 + 2 * border + 1) * chunk * kBlock32 * sizeof(float), (hipStream_t) stream,
+                           w, h, sc.filter, d_filter_table, v, n_spp, tiles_x, bxn, chunk);
+    }
     const int cols = w + 2 * border, rows = h + 2 * border;
     hipLaunchKernelGGL(film_resolve_reference_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, (hipStream_t) stream, w, h, border, bxn, byn,
                        (const float *) store.block_acc, (const uint32_t *) store.spiral_rank, d_rgbw);
