@@ -403,6 +403,9 @@ def cpu_baseline_and_parity(wl, r, frame, args):
               "pixels": int(covered.sum()), "rays_cpu": int(rays), "rays_gpu": int(gst["n_closest_rays"] + gst["n_shadow_rays"]),
               "w_channel_max_abs_diff": float(np.abs(A[..., 3] - B[..., 3]).max())}
     parity["ok"] = bool(parity["frac_within_1e-3"] >= 0.999 and parity["mean_rel"] <= 1e-4)
+    bsdfs = {m.bsdf.type for m in wl.scene.meshes}
+    if "dielectric" in bsdfs:      # what the comparison cannot vouch for: nothing in the reference pins this plugin
+        parity["unpinned_by_reference"] = "Dielectric::sample (src/dielectric.cpp:31-33 is a stub; no reference test touches it): oracle and device share the documented choice -- Fresnel-weighted reflect / refract, weight 1"
     return cpu, parity
 
 

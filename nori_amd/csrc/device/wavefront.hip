@@ -351,17 +351,23 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
    A workgroup owns a contiguous range of rounds (256 paths each) and reserves output space in
    chunks of <= kShadeChunk records with one atomic per chunk, sized by the survival rate it sees;
    what it leaves unused of its last chunk is marked empty (flags = 0) and dropped by the next pass. */
+/* threads per wf_shade workgroup (A/B: NORI_SHADE_BLOCK) */
+#ifndef NORI_SHADE_BLOCK
+#define NORI_SHADE_BLOCK 256
+#endif
+constexpr int kSB = NORI_SHADE_BLOCK;
+
 template <int INTEG, bool FIRST>
-__global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
+__global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
     const WfState S = b.st[cur], D = b.st[cur ^ 1];
     const uint32_t s_first = bt.s_first, n_spp = bt.n_spp;
     __shared__ uint4 s_tab[kShadeTabWords / 4];
     shade_tables_to_lds(sc, s_tab);      /* mesh / emitter tables: LDS instead of L2 round trips (shade_tables.h) */
     const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
-    const uint32_t rounds_total = (n + kB - 1) / kB;
+    const uint32_t rounds_total = (n + kSB - 1) / kSB;
     const uint32_t rounds_per_block = (rounds_total + gridDim.x - 1) / gridDim.x;
     const uint32_t r0 = blockIdx.x * rounds_per_block, r1 = min(rounds_total, r0 + rounds_per_block);
-    const uint32_t chunk_len = min(kShadeChunk, rounds_per_block * kB);
+    const uint32_t chunk_len = min(kShadeChunk, rounds_per_block * kSB);
     __shared__ uint32_t s_wcnt[2][4], s_newbase;
     uint32_t out_base = 0u, out_used = 0u, out_len = 0u;     /* workgroup-uniform */
     bool overflow = false;
@@ -377,18 +383,18 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
        into L2 by one extra load costs the 128th register and spills: slower) */
     uint32_t pf_fl = 0u, pf_sidx = 0u; f4 pf_L, pf_h;
     pf_L.x = pf_L.y = pf_L.z = pf_L.w = 0.0f; pf_h = pf_L;
-    if (!FIRST && r0 < r1 && r0 * kB + threadIdx.x < n) {
-        const uint32_t i0 = r0 * kB + threadIdx.x;
+    if (!FIRST && r0 < r1 && r0 * kSB + threadIdx.x < n) {
+        const uint32_t i0 = r0 * kSB + threadIdx.x;
         pf_fl = ld_w<2>(&S.flags[i0]); pf_sidx = ld_w<2>(&S.sidx[i0]); pf_L = ld_f4<2>(&S.L_pdf[i0]); pf_h = ld_f4<1>(&b.hit[i0]);
     }
 #endif
     for (uint32_t r = r0; r < r1; ++r) {
-        const uint32_t i = r * kB + threadIdx.x;
+        const uint32_t i = r * kSB + threadIdx.x;
         bool survive = false;
 #if NORI_EXP_SHADE_PREFETCH
         const uint32_t c_fl = pf_fl, c_sidx = pf_sidx; const f4 c_L = pf_L, c_h = pf_h;
-        if (!FIRST && r + 1u < r1 && i + kB < n) {
-            pf_fl = ld_w<2>(&S.flags[i + kB]); pf_sidx = ld_w<2>(&S.sidx[i + kB]); pf_L = ld_f4<2>(&S.L_pdf[i + kB]); pf_h = ld_f4<1>(&b.hit[i + kB]);
+        if (!FIRST && r + 1u < r1 && i + kSB < n) {
+            pf_fl = ld_w<2>(&S.flags[i + kSB]); pf_sidx = ld_w<2>(&S.sidx[i + kSB]); pf_L = ld_f4<2>(&S.L_pdf[i + kSB]); pf_h = ld_f4<1>(&b.hit[i + kSB]);
         }
 #endif
         f4 n_o, n_dA, n_dB, n_T, n_L, n_Ld;
@@ -454,7 +460,7 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
         const unsigned long long mask = __ballot(survive);
         if (lane == 0) s_wcnt[r & 1u][wave] = (uint32_t) __popcll(mask);
         __syncthreads();
-        const uint32_t c0 = s_wcnt[r & 1u][0], c1 = s_wcnt[r & 1u][1], c2 = s_wcnt[r & 1u][2], c3 = s_wcnt[r & 1u][3];
+        const uint32_t c0 = s_wcnt[r & 1u][0], c1 = kSB > 64 ? s_wcnt[r & 1u][1] : 0u, c2 = kSB > 128 ? s_wcnt[r & 1u][2] : 0u, c3 = kSB > 192 ? s_wcnt[r & 1u][3] : 0u;
         const uint32_t c = c0 + c1 + c2 + c3;
         uint32_t off = (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
         off += wave > 0 ? c0 : 0u; off += wave > 1 ? c1 : 0u; off += wave > 2 ? c2 : 0u;
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(kB, 4) void wf_shade(DevScene sc, WfBuf b, int cur,
         if (c > room) { out_base = new_base; out_used = c - room; out_len = want; }
         else out_used += c;
     }
-    for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kB) D.flags[out_base + k] = 0u;
+    for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kSB) D.flags[out_base + k] = 0u;
     if (overflow && threadIdx.x == 0) b.ctr[C_OVERFLOW] = 1u;
 }
 
@@ -549,7 +555,7 @@ int shade_grid(size_t paths) { return (int) std::min<size_t>(kShadeGridMax, std:
    wf_shade workgroup's last chunk (a round that does not fit is split across two chunks, so
    nothing else is ever left empty) */
 size_t state_capacity(size_t paths) {
-    return paths + (size_t) kShadeChunk * (size_t) shade_grid(paths) + 1024;
+    return paths + (size_t) kShadeChunk * (size_t) shade_grid(paths) * (size_t) (kB / kSB) + 1024;
 }
 
 struct Pool {
@@ -625,7 +631,7 @@ void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, 
 }
 
 void launch_shade(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &bt, bool first, int grid_, hipStream_t s) {
-    const dim3 grid(grid_), block(kB);
+    const dim3 grid(grid_ * (kB / kSB)), block(kSB);
     switch (sc.integrator.type) {
 #define SH(I) case I: if (first) hipLaunchKernelGGL((wf_shade<I, true>), grid, block, 0, s, sc, b, cur, bt); \
                       else hipLaunchKernelGGL((wf_shade<I, false>), grid, block, 0, s, sc, b, cur, bt); break;
