@@ -383,3 +383,26 @@ def test_ploc_trees_cost_less_than_radix_trees():
             e.close()
         assert cost["ploc"] < cost["lbvh"], (name, cost)
         assert cost["ploc"] < 1.10 * cost["sah"], (name, cost)
+
+
+def test_treelet_sweeps_improve_the_ploc_tree():
+    """Treelet restructuring after PLOC (lbvh_steps.h: the optimal topology of every <= 7-leaf treelet, bottom-up): fewer node
+    tests per ray than the clustering alone, on the Cornell box no more than the host's SAH tree needs, and the same hits as the
+    brute-force scan however many sweeps ran."""
+    from nori_amd import workloads
+    sc = workloads.load("pa4-cbox-path_mis", width=32, height=32, spp=2).scene
+    rays = scenes.random_rays(4000, seed=21)
+    ref = Oracle(sc).intersect(rays)
+    nodes = {}
+    for sweeps in (0, 1, 2):
+        e = _with_env({"NORI_EMU_BUILDER": "ploc", "NORI_HIP_ACCEL_LAYOUT": "bvh2", "NORI_HIP_TREELET_SWEEPS": str(sweeps)}, lambda: Emu(sc))
+        got = e.intersect(rays)
+        assert all(np.array_equal(ref[k], got[k], equal_nan=ref[k].dtype.kind == "f") for k in ref.dtype.names), sweeps
+        _, st = e.render_host(count_traversal=True)
+        nodes[sweeps] = st["n_node_tests"] / (st["n_closest_rays"] + st["n_shadow_rays"])
+        e.close()
+    e = _with_env({"NORI_EMU_BUILDER": "sah", "NORI_HIP_ACCEL_LAYOUT": "bvh2"}, lambda: Emu(sc))
+    _, st = e.render_host(count_traversal=True)
+    sah = st["n_node_tests"] / (st["n_closest_rays"] + st["n_shadow_rays"])
+    assert nodes[1] < 0.95 * nodes[0] and nodes[2] <= nodes[1] * 1.01, nodes
+    assert nodes[2] < 1.02 * sah, (nodes, sah)
