@@ -440,10 +440,40 @@ static int upload(nori_hip_ctx *ctx, std::vector<void *> &pool, const std::vecto
     return NORI_OK;
 }
 
-/* rt_top.h: one thread walks the first levels of the finished tree (any builder, either layout) and writes the image of
-   its hottest records -- a few dozen dependent loads, once per acceleration structure */
-__global__ void top_image_kernel(DevScene sc, f4 *image) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) top_image_build(sc.nodes, sc.tris, sc.root, sc.wide != 0u, sc.n_triangles, image);
+/* rt_top.h: the image of the tree's hottest records (any builder, either layout), once per acceleration structure.  One wave:
+   every lane runs the selection (identically -- they all write the same values), the scan for the next best candidate is
+   shared out over the lanes; the candidate lists live in LDS. */
+struct TopWaveArgMax {
+    template <class F> __device__ int operator()(int n, F score) const {
+        int best = -1; float bs = -1.0f;
+        for (int i = (int) (threadIdx.x & 63u); i < n; i += 64) { const float sc = score(i); if (sc > bs) { bs = sc; best = i; } }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float os = __shfl_xor(bs, off); const int oi = __shfl_xor(best, off);
+            if (os > bs || (os == bs && oi >= 0 && (best < 0 || oi < best))) { bs = os; best = oi; }
+        }
+        return best;
+    }
+};
+__global__ __launch_bounds__(64) void top_image_kernel(DevScene sc, const f4 *records, TopLayout layout, int max_nodes, f4 *image) {
+    __shared__ int32_t s_link[kTopMaxCand]; __shared__ float s_area[kTopMaxCand];
+    __shared__ int16_t s_parent[kTopMaxCand]; __shared__ int8_t s_which[kTopMaxCand];
+    TopWork w; w.link = s_link; w.area = s_area; w.parent = s_parent; w.which = s_which;
+    top_image_build_with(sc.nodes, records, layout, sc.tris, sc.root, sc.wide != 0u, sc.n_triangles, max_nodes, image, w, TopWaveArgMax());
+}
+
+/* rt_nodeq.h: the 32-B records of a BVH2 tree -- the grid from the root's children, then one thread per node.
+   status[0] = 1: the grid is valid; status[1] != 0: some node has an unbounded box (the tree does not qualify) */
+__global__ void nodeq_grid_kernel(DevScene sc, NodeqGrid *grid, uint32_t *status) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { NodeqGrid g; const bool ok = nodeq_grid(sc.nodes, sc.root, g); if (ok) *grid = g; status[0] = ok ? 1u : 0u; status[1] = 0u; }
+}
+__global__ void nodeq_convert_kernel(const f4 *nodes, uint32_t n_nodes, const NodeqGrid *grid, const uint32_t *status_in, f4 *out, uint32_t *status) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes || status_in[0] == 0u) return;
+    const NodeqGrid g = *grid;
+    f4 q[4] = {nodes[(size_t) i * kNodeQuads], nodes[(size_t) i * kNodeQuads + 1], nodes[(size_t) i * kNodeQuads + 2], nodes[(size_t) i * kNodeQuads + 3]};
+    f4 r[2];
+    if (!nodeq_from_node(q, g, r)) { atomicAdd(&status[1], 1u); r[0].x = r[0].y = r[0].z = r[0].w = 0.0f; r[1] = r[0]; }
+    out[(size_t) i * kNodeqQuads] = r[0]; out[(size_t) i * kNodeqQuads + 1] = r[1];
 }
 
 static void free_pool(std::vector<void *> &pool) {
@@ -582,15 +612,42 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     }
     ctx->dev.root = ctx->bvh.root;
     ctx->dev.wide = ctx->bvh.wide ? 1u : 0u;
-    ctx->dev.top_image = nullptr;
-    if (ctx->dev.n_triangles > 0 && getenv("NORI_HIP_NO_TOP_IMAGE") == nullptr) {      /* what wf_extend keeps in LDS (rt_top.h) */
-        void *img = nullptr;
-        HIP_TRY(ctx, hipMalloc(&img, kTopImageQuads * sizeof(f4)));
-        ctx->allocs_accel.push_back(img);
-        hipLaunchKernelGGL(top_image_kernel, dim3(1), dim3(64), 0, 0, ctx->dev, reinterpret_cast<f4 *>(img));
-        HIP_TRY(ctx, hipGetLastError());
-        HIP_TRY(ctx, hipDeviceSynchronize());
-        ctx->dev.top_image = reinterpret_cast<const f4 *>(img);
+    ctx->dev.top_image = nullptr; ctx->dev.top_image_quads = 0u;
+    ctx->dev.nodes_q = nullptr; ctx->dev.top_image_q = nullptr; ctx->dev.top_image_q_quads = 0u;
+    const bool want_image = ctx->dev.n_triangles > 0 && getenv("NORI_HIP_NO_TOP_IMAGE") == nullptr;
+    if (ctx->dev.n_triangles > 0 && !ctx->bvh.wide && ctx->bvh.root >= 0 && ctx->bvh.n_nodes > 0 && getenv("NORI_HIP_NO_NODEQ") == nullptr) {
+        /* the nodes once more as 32-B records (rt_nodeq.h): what wf_extend's node loop reads */
+        void *nq = nullptr, *aux = nullptr;
+        HIP_TRY(ctx, hipMalloc(&nq, (size_t) ctx->bvh.n_nodes * kNodeqQuads * sizeof(f4)));
+        ctx->allocs_accel.push_back(nq);
+        HIP_TRY(ctx, hipMalloc(&aux, sizeof(NodeqGrid) + 2 * sizeof(uint32_t)));
+        NodeqGrid *d_grid = reinterpret_cast<NodeqGrid *>(aux);
+        uint32_t *d_status = reinterpret_cast<uint32_t *>(d_grid + 1);
+        hipLaunchKernelGGL(nodeq_grid_kernel, dim3(1), dim3(64), 0, 0, ctx->dev, d_grid, d_status);
+        hipLaunchKernelGGL(nodeq_convert_kernel, dim3((ctx->bvh.n_nodes + 255u) / 256u), dim3(256), 0, 0, ctx->dev.nodes, (uint32_t) ctx->bvh.n_nodes, d_grid, d_status,
+                           reinterpret_cast<f4 *>(nq), d_status);
+        struct { NodeqGrid g; uint32_t status[2]; } h;
+        const hipError_t e1 = hipGetLastError(), e2 = hipMemcpy(&h, aux, sizeof(h), hipMemcpyDeviceToHost);      /* (synchronises) */
+        (void) hipFree(aux);
+        HIP_TRY(ctx, e1); HIP_TRY(ctx, e2);
+        if (h.status[0] == 1u && h.status[1] == 0u) { ctx->dev.nodes_q = reinterpret_cast<const f4 *>(nq); ctx->dev.grid = h.g; }
+    }
+    if (want_image) {      /* what wf_extend keeps in LDS (rt_top.h): the hot records, with 64-B and -- if the tree has them -- 32-B nodes */
+        int limit = kTopMaxNodes;
+        if (const char *e = getenv("NORI_HIP_TOP_NODES")) limit = std::max(1, atoi(e));
+        for (int q = 0; q < (ctx->dev.nodes_q ? 2 : 1); ++q) {
+            void *img = nullptr;
+            HIP_TRY(ctx, hipMalloc(&img, kTopImageMaxQuads * sizeof(f4)));
+            ctx->allocs_accel.push_back(img);
+            const int max_nodes = std::min(limit, wf_top_capacity(ctx->bvh.wide, q == 1));
+            hipLaunchKernelGGL(top_image_kernel, dim3(1), dim3(64), 0, 0, ctx->dev, q == 1 ? ctx->dev.nodes_q : ctx->dev.nodes, top_layout(q == 1), max_nodes,
+                               reinterpret_cast<f4 *>(img));
+            HIP_TRY(ctx, hipGetLastError());
+            f4 header;
+            HIP_TRY(ctx, hipMemcpy(&header, img, sizeof(f4), hipMemcpyDeviceToHost));      /* (synchronises) */
+            if (q == 1) { ctx->dev.top_image_q = reinterpret_cast<const f4 *>(img); ctx->dev.top_image_q_quads = f2u(header.w); }
+            else { ctx->dev.top_image = reinterpret_cast<const f4 *>(img); ctx->dev.top_image_quads = f2u(header.w); }
+        }
     }
     ctx->stack_depth = ctx->bvh.max_depth + 1 <= 32 ? 32 : 64;
     nori_accel_info &in = ctx->info;

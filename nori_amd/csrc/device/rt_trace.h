@@ -16,6 +16,7 @@
 #pragma once
 #include "rt_types.h"
 #include "rt_top.h"
+#include "rt_nodeq.h"
 
 #if defined(NORI_TRAV_HISTOGRAM) && !defined(__HIP_DEVICE_COMPILE__)
 /* CPU harness only (tools/trav_histogram.py): visits per node and per leaf pair record */
@@ -154,7 +155,7 @@ NORI_HD TopNodesP top_nodes_pointer(const f4 *generic) { return generic; }
 
 NORI_HD void node_fetch(const DevScene &sc, TopNodesP top, int node, f4 &q0, f4 &q1, f4 &q2, f4 &q3) {
     if (top != nullptr && (node & kTopBit)) {
-        const TopNodesP nq = top + 1 + (node & 31) * kTopStrideQuads;      /* kTopNodes <= 32 slots behind the header quad */
+        const TopNodesP nq = top + (node & kTopQuadMask);      /* the link names the record's quad offset in the image */
         q0 = top_quad(nq); q1 = top_quad(nq + 1); q2 = top_quad(nq + 2); q3 = top_quad(nq + 3);
     } else {
         const f4 *nq = sc.nodes + (size_t) node * kNodeQuads;
@@ -181,6 +182,41 @@ NORI_HD void trav_inner_step(const DevScene &sc, Stack &stack, Trav &tv, Travers
     const bool hl = (nl <= fl) && (fl >= 0.0f) && (nl <= tv.hit.t);
     const bool hr = (nr <= fr) && (fr >= 0.0f) && (nr <= tv.hit.t);
     const int cl = (int) f2u(q3.x), cr = (int) f2u(q3.y);
+    if (hl && hr) {
+        const bool leftFirst = nl <= nr;
+        stack.push(leftFirst ? cr : cl);
+        tv.node = leftFirst ? cl : cr;
+    } else if (hl) {
+        tv.node = cl;
+    } else if (hr) {
+        tv.node = cr;
+    } else {
+        trav_pop(stack, tv);
+    }
+}
+
+/* one inner-node step on the 32-B record of the node (rt_nodeq.h): the C++ statement of what wf_extend's hand-written loop
+   does (wavefront.hip, bvh2_node_loop_asm) -- same operations, same order -- and what the CPU harness walks.  `top`: the LDS
+   image with 32-B node records (sc.top_image_q). */
+template <bool COUNT, class Stack>
+NORI_HD void trav_inner_step_q(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, TopNodesP top = nullptr) {
+    f4 q0, q1;
+    if (top != nullptr && (tv.node & kTopBit)) {
+        const TopNodesP nq = top + (tv.node & kTopQuadMask);
+        q0 = top_quad(nq); q1 = top_quad(nq + 1);
+    } else {
+        const f4 *nq = sc.nodes_q + (size_t) tv.node * kNodeqQuads;
+        q0 = nq[0]; q1 = nq[1];
+    }
+    if (COUNT) cnt.nodes++;
+    NORI_HIST(0, (uint32_t) tv.node);
+    NodeqRay R;
+    nodeq_ray(sc.grid, tv.o, tv.rcp, R);
+    float nl, fl, nr, fr;
+    nodeq_slabs(q0, q1, R, nl, fl, nr, fr);
+    const bool hl = (nl <= fl) && (fl >= 0.0f) && (nl <= tv.hit.t);
+    const bool hr = (nr <= fr) && (fr >= 0.0f) && (nr <= tv.hit.t);
+    const int cl = (int) f2u(q1.z), cr = (int) f2u(q1.w);
     if (hl && hr) {
         const bool leftFirst = nl <= nr;
         stack.push(leftFirst ? cr : cl);
@@ -307,7 +343,7 @@ NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
     const uint32_t cursor = ~(uint32_t) tv.node;
     f4 q0, q1, q2, q3, q4;
     const bool cached = top != nullptr && (cursor & (uint32_t) kTopBit) != 0u;
-    const TopNodesP lq = top + 1 + kTopNodes * kTopStrideQuads + ((cursor >> 3) & 15u) * kPairQuads;      /* kTopPairs <= 16 */
+    const TopNodesP lq = top + ((cursor >> 3) & (uint32_t) kTopPairMask) * kPairQuads;
     const f4 *tq = sc.tris + (size_t) (cursor >> 3) * kPairQuads;
     if (cached) { q0 = top_quad(lq); q1 = top_quad(lq + 1); q2 = top_quad(lq + 2); q3 = top_quad(lq + 3); q4 = top_quad(lq + 4); }
     else { q0 = tq[0]; q1 = tq[1]; q2 = tq[2]; q3 = tq[3]; q4 = tq[4]; }
@@ -338,8 +374,9 @@ NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
 
 /* Run a traversal to completion (batch kernels, tests).
  * Returns true if something was hit; for closest-hit `hit` holds t,u,v,tri,mesh.
- * In the CPU harness the walk goes through the image of the hot records (rt_top.h) when the scene has one -- the links
- * and records wf_extend reads from LDS, checked there against the brute-force scan; on the device this function serves
+ * In the CPU harness the walk goes through the image of the hot records (rt_top.h) when the scene has one, and through the
+ * 32-B node records (rt_nodeq.h) when the tree has them -- the links and records wf_extend reads, checked there against the
+ * brute-force scan; on the device this function serves
  * the batch twins and wf_finish, which keep nothing in LDS. */
 template <bool COUNT, class Stack>
 NORI_HD bool traverse(const DevScene &sc, const RayIn &ray, bool any, Stack &stack, Hit &hit, TraversalCounters &cnt) {
@@ -347,13 +384,17 @@ NORI_HD bool traverse(const DevScene &sc, const RayIn &ray, bool any, Stack &sta
     trav_begin<kLayoutAny>(sc, ray, any, stack, tv);
 #if defined(__HIP_DEVICE_COMPILE__)
     const TopNodesP top = nullptr;
+    const bool use_q = false;
 #else
-    const TopNodesP top = sc.top_image;
+    /* the harness walks the 32-B records when the tree has them (rt_nodeq.h): wf_extend's default node loop */
+    const bool use_q = sc.nodes_q != nullptr && !sc.wide;
+    const TopNodesP top = use_q ? sc.top_image_q : sc.top_image;
     if (top != nullptr && trav_active(tv)) tv.node = (int) f2u(top[0].x);
 #endif
     while (trav_active(tv)) {
         if (trav_at_inner(tv)) {
             if (sc.wide) trav_wide_step<COUNT>(sc, stack, tv, cnt, top);
+            else if (use_q) trav_inner_step_q<COUNT>(sc, stack, tv, cnt, top);
             else trav_inner_step<COUNT>(sc, stack, tv, cnt, top);
         } else trav_leaf_step<COUNT>(sc, stack, tv, cnt, top);
     }

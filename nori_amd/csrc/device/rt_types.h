@@ -330,6 +330,9 @@ struct IntegratorRec {
     float energy[3];
 };
 
+/* grid of the 32-B node records (rt_nodeq.h): plane position = mn + q scale per axis */
+struct NodeqGrid { float mn[3], scale[3]; };
+
 struct DevScene {
     const f4 *nodes;
     const f4 *tris;
@@ -343,12 +346,17 @@ struct DevScene {
     const uint32_t *tri_mesh;   /* mesh id per global triangle */
     const f4 *shade_tris;       /* kShadeQuads per global triangle: the shading data pre-gathered */
     const f4 *top_image;        /* the hot records of the tree as wf_extend keeps them in LDS (rt_top.h), or null */
+    const f4 *nodes_q;          /* the tree's nodes as 32-B records (rt_nodeq.h), same indices as `nodes`; null: the tree does not qualify */
+    const f4 *top_image_q;      /* the LDS image with 32-B node records (valid with nodes_q) */
     uint32_t n_emitters;
     uint32_t n_meshes;
     uint32_t n_triangles;
     uint32_t n_cdf;             /* entries of emitter_cdf */
     int32_t root;               /* child-link code of the root */
     uint32_t wide;              /* nodes are WIDE nodes (BVH4, quantised boxes) instead of BVH2 nodes */
+    uint32_t top_image_quads;   /* quads of top_image in use (its header's .w) */
+    uint32_t top_image_q_quads;
+    NodeqGrid grid;             /* of nodes_q */
     CameraRec camera;
     FilterRec filter;
     IntegratorRec integrator;

@@ -43,6 +43,9 @@ size_t wavefront_held_bytes(const WfEngine *engine, const FilmStore &film);
 std::string wavefront_render(WfEngine &engine, FilmStore &film_store, const DevScene &sc, const float *d_filter_table,
                              const WfLaunch &launch, float *d_rgbw, void *stream, WfStats &stats);
 
+/* node records of the LDS image (rt_top.h) that fit next to wf_extend's traversal stacks, per node layout */
+int wf_top_capacity(bool wide_nodes, bool records_32b);
+
 /* -DNORI_COUNT_EXCURSIONS builds: adds this translation unit's excursion counters (rt_types.h) to out[4], optionally
    resetting them; false in the product build */
 bool wavefront_excursions(unsigned long long out[4], bool reset);

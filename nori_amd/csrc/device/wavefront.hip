@@ -88,7 +88,9 @@ struct WfBatch {
     uint32_t tile_mod, tile_rem, tiles_x;
     int32_t tile_w;
     int32_t inner_repeat;               /* wf_extend: node steps repeat while at least this many lanes are at inner nodes (65: never) */
+    uint32_t flags;                     /* kBatch* */
 };
+constexpr uint32_t kBatchNoAsmLoop = 1u;       /* wf_extend: the compiler's node loop instead of the hand-written one (A/B, tests) */
 
 /* Per-lane traversal stack in LDS ([entry][thread], bank = lane -> conflict free).
    Trees no deeper than DEPTH: one register (the address of the next free slot); entry 0 holds the
@@ -97,7 +99,7 @@ struct WfBatch {
    a global buffer.  A small DEPTH keeps wf_extend at 8 waves/SIMD however deep the tree is (a
    64-entry LDS stack would allow 2), which is what hides the HBM latency of scenes that do not fit
    in L2. */
-template <int DEPTH, bool SPILL>
+template <int DEPTH, bool SPILL, int BLOCK = kB>
 struct LdsStackW {
     int *base; int sp;
     int *spill; uint32_t spill_stride;      /* wave-uniform base, lanes in flight */
@@ -106,30 +108,44 @@ struct LdsStackW {
     }
     __device__ __forceinline__ void reset() { sp = 0; }
     __device__ __forceinline__ void push(int v) {
-        if (sp < DEPTH) base[sp * kB] = v;
-        else spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * kB + threadIdx.x] = v;
+        if (sp < DEPTH) base[sp * BLOCK] = v;
+        else spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * BLOCK + threadIdx.x] = v;
         sp++;
     }
     __device__ __forceinline__ int pop_or(int empty_value) {
         if (sp == 0) return empty_value;
         sp--;
-        if (sp < DEPTH) return base[sp * kB];
-        return spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * kB + threadIdx.x];
+        if (sp < DEPTH) return base[sp * BLOCK];
+        return spill[(size_t) (sp - DEPTH) * spill_stride + blockIdx.x * BLOCK + threadIdx.x];
     }
     static constexpr int kLdsEntries = DEPTH;
 };
 
-template <int DEPTH>
-struct LdsStackW<DEPTH, false> {
-    int *top;       /* next free slot */
-    char *smem_;
-    __device__ __forceinline__ void init(char *smem, int *, uint32_t) { smem_ = smem; top = reinterpret_cast<int *>(smem) + threadIdx.x; }
-    __device__ __forceinline__ void reset() {
-        int *b = reinterpret_cast<int *>(smem_) + threadIdx.x;
-        b[0] = kTravDone; top = b + kB;
+/* LDS as the hardware addresses it: 32-bit byte addresses, so that the walk's stack pointer is ONE register the hand-written
+   node loop below can use as it is */
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ __forceinline__ uint32_t lds_address(const void *generic) {
+    return (uint32_t) reinterpret_cast<uintptr_t>((const __attribute__((address_space(3))) char *) generic);
+}
+__device__ __forceinline__ lds_int_t *lds_int_at(uint32_t address) { return reinterpret_cast<lds_int_t *>(address); }
+
+template <int DEPTH, int BLOCK>
+struct LdsStackW<DEPTH, false, BLOCK> {
+    uint32_t top;         /* LDS address of the next free slot */
+    uint32_t wave_base;   /* of slot 0 of the wave's lane 0 (wave-uniform): slot k of thread l lives at (k BLOCK + l) ints, bank = lane */
+    __device__ __forceinline__ void init(char *smem, int *, uint32_t) {
+        wave_base = (uint32_t) __builtin_amdgcn_readfirstlane((int) (lds_address(smem) + (threadIdx.x & ~63u) * 4u)); top = 0u;
     }
-    __device__ __forceinline__ void push(int v) { *top = v; top += kB; }
-    __device__ __forceinline__ int pop_or(int) { top -= kB; return *top; }
+    /* the lane's column is found anew at every reset (two v_mbcnt in a volatile statement): as a value the compiler knows to be
+       constant it would live in a register for the whole kernel -- the one it then spills */
+    __device__ __forceinline__ void reset() {
+        uint32_t lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        const uint32_t base = wave_base + lane * 4u;
+        *lds_int_at(base) = kTravDone; top = base + BLOCK * 4u;
+    }
+    __device__ __forceinline__ void push(int v) { *lds_int_at(top) = v; top += BLOCK * 4u; }
+    __device__ __forceinline__ int pop_or(int) { top -= BLOCK * 4u; return *lds_int_at(top); }
     static constexpr int kLdsEntries = DEPTH + 1;
 };
 
@@ -162,11 +178,11 @@ template <int LEVEL, class T> __device__ __forceinline__ T ld_w(const T *p) { if
 
 /* The hot records of the tree (rt_top.h: the image is built once per acceleration structure) into the workgroup's LDS.
    Returns the link a walk starts with. */
-__device__ int top_image_to_lds(const DevScene &sc, f4 *top) {
-    if (sc.top_image == nullptr) {      /* no image: nothing cached, every link is a memory link */
+__device__ int top_image_to_lds(const DevScene &sc, f4 *top, const f4 *image, uint32_t quads) {
+    if (image == nullptr) {      /* no image: nothing cached, every link is a memory link */
         if (threadIdx.x == 0) { f4 h; h.x = __uint_as_float((uint32_t) sc.root); h.y = h.z = h.w = 0.0f; top[0] = h; }
     } else {
-        for (int q = (int) threadIdx.x; q < kTopImageQuads; q += kB) top[q] = sc.top_image[q];
+        for (uint32_t q = threadIdx.x; q < quads; q += blockDim.x) top[q] = image[q];
     }
     __syncthreads();
     return __builtin_amdgcn_readfirstlane((int) __float_as_uint(top[0].x));
@@ -192,18 +208,188 @@ __device__ __forceinline__ bool first_vertex(const DevScene &sc, const WfBatch &
     return true;
 }
 
+/* The BVH2 node loop of wf_extend, hand-written for gfx950, on the 32-B node records of rt_nodeq.h:
+ *
+ *     do { if (trav_at_inner(tv)) trav_inner_step_q(sc, stack, tv, tc, top); } while (lanes at inner nodes >= repeat);
+ *
+ * (rt_trace.h; BoundingBox::rayIntersect of include/nori/bbox.h:323-350 for both children).  What bounds wf_extend is the number
+ * of vector-memory instructions a CU issues -- each occupies its address path for ~16 cycles however few lanes take part, and the
+ * arithmetic and scalar pipes are half idle (measured by adding instructions of each kind to this loop: one more
+ * global_load_dwordx4 per node step costs 6.3 ms per frame, a dwordx2 5.2, a dword 2.8, sixteen v_mov 1.7, sixteen s_mov 0.4, the
+ * LDS reads over again 0.8) -- so the loop reads a node in TWO loads where the 64-B record takes four, and pays for it in arithmetic:
+ * per plane one v_cvt_f32_u32 (SDWA: a 16-bit half of a dword) and one v_fma, per axis two v_bfi that pick the dword with the near
+ * planes by the sign of the ray's direction.  Written as assembly because the child selection is four v_cndmask and two
+ * exec-masked LDS operations (push where both children are hit, pop where none is) where the compiler builds three nested
+ * regions with their save / restore / skip-branch triples, and because the loads must not be widened, merged or re-ordered.
+ * Same operations in the same order as trav_inner_step_q -- the CPU harness walks that one, against the linear scan.
+ * gfx950 hazards honoured by hand: a VALU-written vcc is read by v_cndmask two instructions later at the earliest.
+ * Records are addressed as base + (node << 5) in 32 bits: the caller takes this path for trees below 2^25 nodes only. */
+#ifndef NORI_ASM_NODE_LOOP
+#define NORI_ASM_NODE_LOOP 1
+#endif
+#define NORI_SDWA(dst, src, half) "v_cvt_f32_u32_sdwa " dst ", " src " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_" half "\n\t"
+#if NORI_EXP_SENS == 1
+#define NORI_EXP_Q_GLOBAL "\n\tglobal_load_dwordx4 v[36:39], v40, %[nodes] offset:16\n"
+#else
+#define NORI_EXP_Q_GLOBAL
+#endif
+#if NORI_EXP_SENS == 2
+#define NORI_EXP_Q_LDS "ds_read_b128 v[32:35], v40\n\tds_read_b128 v[36:39], v40 offset:16\n\t"
+#else
+#define NORI_EXP_Q_LDS
+#endif
+#if NORI_EXP_SENS == 3
+#define NORI_EXP_Q_ALU "v_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\t"
+#elif NORI_EXP_SENS == 4
+#define NORI_EXP_Q_ALU "s_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\t"
+#elif NORI_EXP_SENS == 5
+#define NORI_EXP_Q_ALU "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
+#else
+#define NORI_EXP_Q_ALU
+#endif
+template <int STACK_STRIDE>      /* bytes between a lane's stack slots */
+__device__ __forceinline__ void bvh2q_node_loop_asm(int &node_io, uint32_t &stack_top, float tmax, const NodeqRay &R, int mx, int my, int mz,
+                                                    const f4 *nodes_q, uint32_t image_address, int repeat) {
+    int r_node = node_io;
+    uint32_t r_sp = stack_top;
+    unsigned long long all, inner, hl, hr, t, u;      /* lane masks (scalar register pairs the compiler picks) */
+    /* v[32:35] = x lo, x hi, y lo, y hi; v[36:39] = z lo, z hi, left link, right link; v40 .. v45: the near / far dwords per axis */
+    asm volatile(
+        "s_mov_b64 %[all], exec\n\t"
+        "v_cmp_lt_i32 %[t], -1, %[node]\n"                        /* lanes at an inner node */
+        "1:\n\t"
+        "s_and_b64 exec, %[all], %[t]\n\t"
+        "s_cbranch_execz 3f\n\t"
+        /* fetch: the node's record from the LDS image (link carries kTopBit: quad offset in its low bits) or from memory */
+        "v_cmp_lt_u32 vcc, 0x3fffffff, %[node]\n\t"
+        "s_mov_b64 %[inner], exec\n\t"
+        "s_and_b64 exec, %[inner], vcc\n\t"
+        "v_and_b32 v40, 0xffff, %[node]\n\t"
+        "v_lshl_add_u32 v40, v40, 4, %[image]\n\t"
+        "ds_read_b128 v[32:35], v40\n\t"
+        "ds_read_b128 v[36:39], v40 offset:16\n\t"
+        NORI_EXP_Q_LDS
+        "s_andn2_b64 exec, %[inner], vcc\n\t"
+        "s_cbranch_execz 2f\n\t"
+        "v_lshlrev_b32 v40, 5, %[node]\n\t"                       /* (other lanes than the ones that just used v40) */
+        "global_load_dwordx4 v[32:35], v40, %[nodes]\n\t"
+        "global_load_dwordx4 v[36:39], v40, %[nodes] offset:16\n"
+        NORI_EXP_Q_GLOBAL
+        "2:\n\t"
+        "s_mov_b64 exec, %[inner]\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+        NORI_EXP_Q_ALU
+        /* per axis the dword with the near planes and the one with the far planes (mask = sign of the direction) */
+        "v_bfi_b32 v40, %[mx], v33, v32\n\t"
+        "v_bfi_b32 v41, %[mx], v32, v33\n\t"
+        "v_bfi_b32 v42, %[my], v35, v34\n\t"
+        "v_bfi_b32 v43, %[my], v34, v35\n\t"
+        "v_bfi_b32 v44, %[mz], v37, v36\n\t"
+        "v_bfi_b32 v45, %[mz], v36, v37\n\t"
+        /* t = q A + (B -+ S) per plane, near = max over the axes, far = min; the dwords of the record are free by now.
+           (Both children of an axis in one v_pk_fma_f32 -- six packed instead of twelve plain multiply-adds -- measured 3.5 ms
+           per frame slower: the coefficients as register pairs cost the kernel a spill.) */
+        NORI_SDWA("v32", "v40", "0") NORI_SDWA("v33", "v42", "0") NORI_SDWA("v34", "v44", "0")
+        "v_fma_f32 v32, v32, %[ax], %[bnx]\n\t"
+        "v_fma_f32 v33, v33, %[ay], %[bny]\n\t"
+        "v_fma_f32 v34, v34, %[az], %[bnz]\n\t"
+        "v_max3_f32 v32, v32, v33, v34\n\t"                       /* v32: near, left child */
+        NORI_SDWA("v33", "v41", "0") NORI_SDWA("v34", "v43", "0") NORI_SDWA("v35", "v45", "0")
+        "v_fma_f32 v33, v33, %[ax], %[bfx]\n\t"
+        "v_fma_f32 v34, v34, %[ay], %[bfy]\n\t"
+        "v_fma_f32 v35, v35, %[az], %[bfz]\n\t"
+        "v_min3_f32 v33, v33, v34, v35\n\t"                       /* v33: far, left child */
+        NORI_SDWA("v34", "v40", "1") NORI_SDWA("v35", "v42", "1") NORI_SDWA("v36", "v44", "1")
+        "v_fma_f32 v34, v34, %[ax], %[bnx]\n\t"
+        "v_fma_f32 v35, v35, %[ay], %[bny]\n\t"
+        "v_fma_f32 v36, v36, %[az], %[bnz]\n\t"
+        "v_max3_f32 v34, v34, v35, v36\n\t"                       /* v34: near, right child */
+        NORI_SDWA("v35", "v41", "1") NORI_SDWA("v36", "v43", "1") NORI_SDWA("v37", "v45", "1")
+        "v_fma_f32 v35, v35, %[ax], %[bfx]\n\t"
+        "v_fma_f32 v36, v36, %[ay], %[bfy]\n\t"
+        "v_fma_f32 v37, v37, %[az], %[bfz]\n\t"
+        "v_min3_f32 v35, v35, v36, v37\n\t"                       /* v35: far, right child */
+        "v_cmp_le_f32 vcc, v32, v33\n\t"
+        "v_cmp_le_f32 %[t], v32, %[tm]\n\t"
+        "v_cmp_le_f32 %[hl], 0, v33\n\t"
+        "v_cmp_le_f32 %[hr], v34, v35\n\t"
+        "v_cmp_le_f32 %[u], v34, %[tm]\n\t"
+        "s_and_b64 %[hl], %[hl], vcc\n\t"
+        "v_cmp_le_f32 vcc, 0, v35\n\t"
+        "s_and_b64 %[hl], %[hl], %[t]\n\t"                        /* left child hit */
+        "s_and_b64 %[hr], %[hr], %[u]\n\t"
+        "s_and_b64 %[hr], %[hr], vcc\n\t"                         /* right child hit */
+        /* selection: both -> the nearer one next, the other pushed; one -> that one; none -> pop */
+        "v_cmp_le_f32 vcc, v32, v34\n\t"
+        "s_and_b64 %[t], %[hl], %[hr]\n\t"                        /* both */
+        "s_or_b64 %[hr], %[hl], %[hr]\n\t"                        /* any */
+        "v_cndmask_b32 v40, v39, v38, vcc\n\t"
+        "v_cndmask_b32 v41, v38, v39, vcc\n\t"
+        "v_cndmask_b32 v42, v39, v38, %[hl]\n\t"
+        "v_cndmask_b32 %[node], v42, v40, %[t]\n\t"
+        "s_mov_b64 exec, %[t]\n\t"
+        "ds_write_b32 %[sp], v41\n\t"
+        "v_add_u32 %[sp], %[stride], %[sp]\n\t"
+        "s_andn2_b64 exec, %[inner], %[hr]\n\t"
+        "v_subrev_u32 %[sp], %[stride], %[sp]\n\t"
+        "ds_read_b32 %[node], %[sp]\n\t"
+        "s_mov_b64 exec, %[all]\n\t"
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "v_cmp_lt_i32 %[t], -1, %[node]\n\t"
+        "s_bcnt1_i32_b64 vcc_lo, %[t]\n\t"
+        "s_cmp_ge_u32 vcc_lo, %[repeat]\n\t"
+        "s_cbranch_scc1 1b\n"
+        "3:\n\t"
+        "s_mov_b64 exec, %[all]\n\t"
+        : [node] "+v"(r_node), [sp] "+v"(r_sp), [all] "=&s"(all), [inner] "=&s"(inner), [hl] "=&s"(hl), [hr] "=&s"(hr), [t] "=&s"(t), [u] "=&s"(u)
+        : [tm] "v"(tmax), [ax] "v"(R.A[0]), [ay] "v"(R.A[1]), [az] "v"(R.A[2]), [bnx] "v"(R.Bn[0]), [bny] "v"(R.Bn[1]), [bnz] "v"(R.Bn[2]),
+          [bfx] "v"(R.Bf[0]), [bfy] "v"(R.Bf[1]), [bfz] "v"(R.Bf[2]), [mx] "v"(mx), [my] "v"(my), [mz] "v"(mz),
+          [nodes] "s"(nodes_q), [image] "s"(image_address), [repeat] "s"(repeat), [stride] "n"(STACK_STRIDE)
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45",
+          "vcc", "scc", "memory");
+    node_io = r_node;
+    stack_top = r_sp;
+}
+
+/* hit_pack (wf_records.h) for wf_extend: the constants of "no closest hit" (t = inf, u = v = 0) are made from a zero the compiler
+   cannot see through -- it otherwise keeps them as a register quad across the whole kernel, and with the register budget of 8 waves
+   per SIMD that quad is what it spills (a scratch reload in front of every record store) */
+__device__ __forceinline__ f4 hit_pack_here(const Hit *closest, bool shadow_occluded) {
+    float z; asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    f4 h; h.x = u2f(0x7f800000u | f2u(z)); h.y = z; h.z = z;
+    uint32_t w = kMissA;
+    if (closest) { h.x = closest->t; h.y = closest->u; h.z = closest->v; if (closest->tri != kNoHit) w = closest->tri; }
+    h.w = u2f(w | (shadow_occluded ? kOccludedB : 0u));
+    return h;
+}
+
 /* Accel::rayIntersect for every path of copy `cur`: the shadow ray (if any) first, then the
    continuation ray, by the same lane; one 16-B hit record per path. */
-template <int STACK, bool SPILL, bool COUNT, bool FIRST, bool WIDE>
-__global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
+/* BLOCK: threads per workgroup.  Every workgroup holds its own copy of the LDS image next to its stacks, so the bigger the
+   workgroup the bigger the image can be: BVH2 trees run in workgroups of 1024 threads (two per CU: 2 x (68 KB of stacks +
+   12 KB of image)), wide-node trees -- whose kernels need more than 64 registers, i.e. 5 or 6 waves per SIMD -- in workgroups of 256. */
+/* -DNORI_WF_PROFILE=1 (diagnostic builds, tools/build_variant.sh): where the waves of wf_extend spend their cycles -- refill
+   (results out, new rays in), node loop, triangle step -- summed over waves into stats slots 6, S_NODES, S_TRIS and 7 (total) */
+#ifndef NORI_WF_PROFILE
+#define NORI_WF_PROFILE 0
+#endif
+#if NORI_WF_PROFILE
+#define NORI_PROF_MARK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); acc += now_ - prof_t; prof_t = now_; }
+#else
+#define NORI_PROF_MARK(acc)
+#endif
+template <int STACK, bool SPILL, bool COUNT, bool FIRST, bool WIDE, bool ASM, int BLOCK>
+__global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LdsStackW<STACK, SPILL> stack;
-    stack.init(smem, b.stack_spill, gridDim.x * kB);
+    LdsStackW<STACK, SPILL, BLOCK> stack;
+    stack.init(smem, b.stack_spill, gridDim.x * BLOCK);
     /* the first levels of the tree in LDS (rt_trace.h, node_fetch): behind the stacks */
-    f4 *top = reinterpret_cast<f4 *>(smem + (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int));
-    const int root_link = top_image_to_lds(sc, top);
+    f4 *top = reinterpret_cast<f4 *>(smem + (size_t) LdsStackW<STACK, SPILL, BLOCK>::kLdsEntries * BLOCK * sizeof(int));
+    /* the kernel with the hand-written node loop walks the 32-B records: its image holds those */
+    const int root_link = ASM ? top_image_to_lds(sc, top, sc.top_image_q, sc.top_image_q_quads) : top_image_to_lds(sc, top, sc.top_image, sc.top_image_quads);
     const TopNodesP top_lds = top_nodes_pointer(top);
+    const uint32_t image_address = lds_address(smem) + (uint32_t) (LdsStackW<STACK, SPILL, BLOCK>::kLdsEntries * BLOCK * sizeof(int));      /* of top */
     const WfState S = b.st[cur];
     const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
     /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
@@ -221,7 +407,7 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
        touches the counter (a single hot word sustains only ~90 atomics/us --
        MI355X_MICROARCH.md, row "dequeue" -- which used to cost 0.2 ms per tail iteration). */
     /* wave_id is the same in all lanes of a wave: readfirstlane tells the compiler, so the chunk cursor lives in SGPRs */
-    const uint32_t n_waves = gridDim.x * (kB / 64u), wave_id = (uint32_t) __builtin_amdgcn_readfirstlane((int) (blockIdx.x * (kB / 64u) + (threadIdx.x >> 6)));
+    const uint32_t n_waves = gridDim.x * (BLOCK / 64u), wave_id = (uint32_t) __builtin_amdgcn_readfirstlane((int) (blockIdx.x * (BLOCK / 64u) + (threadIdx.x >> 6)));
     const uint32_t static_limit = (uint32_t) ((thresholds >> 16) & 0xfff) * n_waves;
     const uint32_t kChunk = n <= static_limit ? (((n + n_waves - 1u) / n_waves + 63u) & ~63u)      /* all static */
                                               : min(1024u, max(64u, (n / (n_waves * (uint32_t) ((thresholds >> 28) & 0xf))) & ~63u));
@@ -230,6 +416,10 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
     uint32_t nClosest = 0, nShadow = 0, nCam = 0;      /* wave-uniform: counted from ballots at the refill */
     uint32_t zc[Z_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};      /* wave-uniform census */
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
+#if NORI_WF_PROFILE
+    unsigned long long prof_t = __builtin_amdgcn_s_memrealtime(), prof_refill = 0ull, prof_node = 0ull, prof_leaf = 0ull;
+    const unsigned long long prof_t0 = prof_t;
+#endif
     while (true) {
         /* a lane is idle when it has no ray in flight: either it needs a new path, or its path's
            shadow ray is answered and the continuation ray is still to be traced (rid bit 1) */
@@ -252,7 +442,7 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                idle and write together.  An idle lane keeps its answer in tv.hit until then. */
             if (unsaved && !trav_active(tv)) {
                 if (pend) rid |= tv.hit.tri != kNoHit ? 1u : 0u;      /* the shadow ray is answered; the continuation ray of the same vertex is next */
-                else st_f4<1>(&b.hit[rid >> 2], tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u));
+                else st_f4<1>(&b.hit[rid >> 2], tv.any ? hit_pack_here(nullptr, tv.hit.tri != kNoHit) : hit_pack_here(&tv.hit, (rid & 1u) != 0u));
                 unsaved = false;
             }
             const unsigned long long fresh = idle & ~pending;
@@ -271,7 +461,7 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                         startedA = true;
                         unsaved = trav_active(tv);
                         if (unsaved) tv.node = root_link;
-                        if (!trav_active(tv)) st_f4<1>(&b.hit[i], hit_pack(nullptr, false));
+                        if (!trav_active(tv)) st_f4<1>(&b.hit[i], hit_pack_here(nullptr, false));
                     }
                 }
             } else if (pend || (!trav_active(tv) && rank < avail)) {
@@ -302,7 +492,7 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                     if (unsaved) tv.node = root_link;
                     if (!trav_active(tv)) {            /* empty scene: nothing occludes, nothing is hit */
                         if (rid & 2u) { startedA = true; rid &= ~2u; }      /* the continuation ray counts as traced, too */
-                        st_f4<1>(&b.hit[i], hit_pack(nullptr, false));
+                        st_f4<1>(&b.hit[i], hit_pack_here(nullptr, false));
                     }
                 }
             }
@@ -314,10 +504,22 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
             if (exhausted && __ballot((rid & 2u) != 0u) == 0ull) break;
             continue;
         }
+        NORI_PROF_MARK(prof_refill)
         /* inner-node steps run every trip, and again at once while enough lanes are at inner nodes (a tight loop without the
            refill test and the leaf vote: the trip's bookkeeping costs as much as a node step); the (rarer) triangle
            step only when enough lanes wait at a leaf or nobody has an inner node to test */
         if (COUNT) zc[Z_TRIPS]++;
+        if constexpr (ASM) {
+            static_assert(!WIDE && !SPILL && !COUNT, "the hand-written node loop: BVH2 nodes as 32-B records, LDS-only stack");
+            /* the ray's plane coefficients (rt_nodeq.h), made anew for every pass through here: kept across the triangle step and
+               the refill they would cost twelve registers the kernel does not have */
+            f3 qo = tv.o, qr = tv.rcp;
+            asm volatile("" : "+v"(qo.x), "+v"(qo.y), "+v"(qo.z), "+v"(qr.x), "+v"(qr.y), "+v"(qr.z));
+            NodeqRay R;
+            nodeq_ray(sc.grid, qo, qr, R);
+            bvh2q_node_loop_asm<BLOCK * 4>(tv.node, stack.top, tv.hit.t, R, (int) f2u(qr.x) >> 31, (int) f2u(qr.y) >> 31, (int) f2u(qr.z) >> 31,
+                                           sc.nodes_q, image_address, bt.inner_repeat);
+        } else
         do {
             if (COUNT) { const int ni = __popcll(__ballot(trav_at_inner(tv))); if (ni) { zc[Z_INNER_TRIPS]++; zc[Z_INNER_LANES] += (uint32_t) ni; } }
             if (trav_at_inner(tv)) {
@@ -325,16 +527,18 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
                 else trav_inner_step<COUNT>(sc, stack, tv, tc, top_lds);
             }
         } while (__popcll(__ballot(trav_at_inner(tv))) >= bt.inner_repeat);
+        NORI_PROF_MARK(prof_node)
         const bool atLeaf = trav_at_leaf(tv);
         const int nLeaf = __popcll(__ballot(atLeaf));
         const bool innerLeft = __ballot(trav_at_inner(tv)) != 0ull;
         if (COUNT && nLeaf && (nLeaf >= leaf_threshold || !innerLeft)) { zc[Z_LEAF_TRIPS]++; zc[Z_LEAF_LANES] += (uint32_t) nLeaf; }
         if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT>(sc, stack, tv, tc, top_lds);
+        NORI_PROF_MARK(prof_leaf)
     }
     /* the answers still held in registers when the wave ran out of paths (no lane is pending here: the loop ends only
        when no continuation ray is left): a path with a shadow ray only ends on it (tv.any); otherwise the closest hit
        + the shadow answer */
-    if (unsaved) st_f4<1>(&b.hit[rid >> 2], tv.any ? hit_pack(nullptr, tv.hit.tri != kNoHit) : hit_pack(&tv.hit, (rid & 1u) != 0u));
+    if (unsaved) st_f4<1>(&b.hit[rid >> 2], tv.any ? hit_pack_here(nullptr, tv.hit.tri != kNoHit) : hit_pack_here(&tv.hit, (rid & 1u) != 0u));
     /* counters: one atomic per wave */
     if (COUNT) for (int off = 32; off > 0; off >>= 1) { tc.nodes += (uint32_t) __shfl_down((int) tc.nodes, off); tc.tris += (uint32_t) __shfl_down((int) tc.tris, off); }
     if (lane == 0) {
@@ -342,6 +546,10 @@ __global__ __launch_bounds__(kB, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevS
         if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
         if (FIRST && nCam) atomicAdd(&b.stats[S_CAM], (unsigned long long) nCam);
         if (COUNT) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
+#if NORI_WF_PROFILE
+        atomicAdd(&b.stats[6], prof_refill); atomicAdd(&b.stats[S_NODES], prof_node); atomicAdd(&b.stats[S_TRIS], prof_leaf);
+        atomicAdd(&b.stats[7], __builtin_amdgcn_s_memrealtime() - prof_t0);
+#endif
         if (COUNT && b.census) for (int k = 0; k < Z_COUNT; ++k) if (zc[k]) atomicAdd(&b.census[k], (unsigned long long) zc[k]);
     }
 }
@@ -606,14 +814,29 @@ std::string ensure_pool(Pool &pool, size_t records) {
     return std::string();
 }
 
+/* threads per wf_extend workgroup and workgroups per CU the LDS image is sized for, per node layout (see wf_extend) */
+constexpr int kExtendBlockBvh2 = 1024, kExtendBlockWide = kB;
+constexpr int kExtendWgsBvh2 = 2, kExtendWgsWide = 6;
+constexpr size_t kLdsPerCu = 160 * 1024;
 template <int STACK, bool SPILL, bool COUNT, bool FIRST>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, const WfBatch &bt, hipStream_t s) {
-    const size_t lds = (size_t) LdsStackW<STACK, SPILL>::kLdsEntries * kB * sizeof(int) + kTopImageQuads * sizeof(f4);
+    const size_t image = (size_t) std::max(1u, sc.top_image_quads) * sizeof(f4);
     if (sc.wide) {
         /* wide trees push up to three children per step: always the spilling stack */
-        if (SPILL) hipLaunchKernelGGL((wf_extend<STACK, true, COUNT, FIRST, true>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill, bt);
+        const size_t lds = (size_t) LdsStackW<STACK, SPILL, kExtendBlockWide>::kLdsEntries * kExtendBlockWide * sizeof(int) + image;
+        if (SPILL) hipLaunchKernelGGL((wf_extend<STACK, true, COUNT, FIRST, true, false, kExtendBlockWide>), dim3(grid), dim3(kExtendBlockWide), lds, s, sc, b, cur, refill, bt);
     } else {
-        hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST, false>), dim3(grid), dim3(kB), lds, s, sc, b, cur, refill, bt);
+        /* the hand-written node loop (bvh2q_node_loop_asm) walks the tree's 32-B records (rt_nodeq.h: trees without unbounded boxes),
+           addresses them by 32-bit byte offsets (trees below 2^25 nodes -- a BVH2 tree has fewer nodes than triangles) and keeps its
+           stack in LDS; everything else takes the compiler's loop over the 64-B nodes */
+        constexpr bool kAsm = NORI_ASM_NODE_LOOP && !SPILL && !COUNT;
+        const bool use_asm = kAsm && sc.nodes_q != nullptr && sc.n_triangles < (1u << 25) && (bt.flags & kBatchNoAsmLoop) == 0u;
+        const size_t lds = (size_t) LdsStackW<STACK, SPILL, kExtendBlockBvh2>::kLdsEntries * kExtendBlockBvh2 * sizeof(int) +
+                           (size_t) std::max(1u, use_asm ? sc.top_image_q_quads : sc.top_image_quads) * sizeof(f4);
+        if (use_asm)
+            hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST, false, kAsm, kExtendBlockBvh2>), dim3(grid), dim3(kExtendBlockBvh2), lds, s, sc, b, cur, refill, bt);
+        else
+            hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST, false, false, kExtendBlockBvh2>), dim3(grid), dim3(kExtendBlockBvh2), lds, s, sc, b, cur, refill, bt);
     }
 }
 
@@ -653,6 +876,16 @@ void launch_finish(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &b
 } // namespace
 
 namespace nrt {
+
+int wf_top_capacity(bool wide_nodes, bool records_32b) {
+    /* 16 stack entries per lane in LDS (+ 1: the "done" marker of the non-spilling stack), the image in what is left */
+    const size_t per_wg = kLdsPerCu / (wide_nodes ? kExtendWgsWide : kExtendWgsBvh2), stacks = (size_t) 17 * (wide_nodes ? kExtendBlockWide : kExtendBlockBvh2) * sizeof(int);
+    const int stride = records_32b ? kTopStrideQuadsQ : kTopStrideQuads;
+    int n = 0;
+    while (n < kTopMaxNodes && stacks + (size_t) top_image_quads(n + 1, stride) * sizeof(f4) <= per_wg) ++n;
+    return n;
+}
+
 
 /* Everything a context keeps between render calls: the path-state pool, the pipes' streams and
    events, what the device offers.  One per nori_hip_ctx (= per GPU); nothing here is process-global,
@@ -810,16 +1043,18 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     if (const char *e = getenv("NORI_HIP_WF_FINISH_PATHS")) finish_paths = std::max(256, atoi(e)) & ~255;
     const int finish_grid = finish_paths / kB;
     /* LDS per workgroup: stack entries (+1: the "done" marker of the non-spilling stack) + the top-node cache */
-    int per_cu = std::max(1, std::min(8, (int) (160 * 1024 / ((lds_stack + 1) * kB * sizeof(int) + kTopImageQuads * sizeof(f4)))));
+    const int extend_block = sc.wide ? kExtendBlockWide : kExtendBlockBvh2;
+    const size_t lds_per_wg = (size_t) (lds_stack + 1) * extend_block * sizeof(int) + (size_t) std::max(1u, std::max(sc.top_image_quads, sc.top_image_q_quads)) * sizeof(f4);
+    int per_cu = std::max(1, std::min(2048 / extend_block, (int) (kLdsPerCu / lds_per_wg)));      /* workgroups per CU */
     /* every workgroup of the persistent grid must be resident from the start (a workgroup that starts late owns a
        static share of the paths and works it off alone): the wide-node kernels are built for 6 waves per SIMD
        (their first-pass variant for 5: measured 3.47 vs 3.29 Grays/s on the terrain against 5 everywhere) */
-    if (sc.wide) per_cu = std::min(per_cu, 6);
+    if (sc.wide) per_cu = std::min(per_cu, kExtendWgsWide);
     if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
-    if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(8, std::max(1, atoi(e)));
+    if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(2048 / extend_block, std::max(1, atoi(e)));
     const int extend_grid = eng.n_cus * per_cu;
     if (L.stack_depth > 16) {      /* wf_finish keeps 16 entries in LDS */
-        const size_t per_pipe_ints = (size_t) (L.stack_depth - 16) * std::max(extend_grid, finish_grid) * kB, ints = per_pipe_ints * n_pipes;
+        const size_t per_pipe_ints = (size_t) (L.stack_depth - 16) * std::max(extend_grid * extend_block, finish_grid * kB), ints = per_pipe_ints * n_pipes;
         if (g_pool.spill_ints < ints) {
             if (g_pool.spill) (void) hipFree(g_pool.spill);
             g_pool.spill = nullptr; g_pool.spill_ints = 0;
@@ -835,6 +1070,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
        around the triangle step compiles with 56 B of scratch and runs 50 % slower) */
     int inner_repeat = 24;
     if (const char *e = getenv("NORI_HIP_WF_INNER_REPEAT")) inner_repeat = std::min(65, std::max(1, atoi(e)));
+    const bool no_asm_loop = getenv("NORI_HIP_WF_NO_ASM_LOOP") != nullptr && atoi(getenv("NORI_HIP_WF_NO_ASM_LOOP")) != 0;
     int sync_every = 6;      /* path-loop iterations between two readbacks of the path count */
     if (const char *e = getenv("NORI_HIP_WF_SYNC_EVERY")) sync_every = std::min(64, std::max(1, atoi(e)));
     const bool census = getenv("NORI_HIP_CENSUS") != nullptr;
@@ -861,6 +1097,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             P.bt.tile_first = P.t0; P.bt.n_tiles = nt; P.bt.s_first = L.spp_begin + P.s0; P.bt.n_spp = ns;
             P.bt.tile_mod = L.tile_mod; P.bt.tile_rem = L.tile_rem; P.bt.tiles_x = L.tiles_x; P.bt.tile_w = L.tile_w;
             P.bt.inner_repeat = inner_repeat;
+            P.bt.flags = no_asm_loop ? kBatchNoAsmLoop : 0u;
             WF_TRY(hipMemsetAsync(P.b.ctr, 0, C_COUNT * sizeof(uint32_t), P.stream));
             stats.n_batches++;
             P.cur = 0; P.first = true; P.active = true; any = true; P.batch_rounds = 0;
@@ -936,6 +1173,13 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     for (int k = 0; k < 2; ++k) {
         stats.n_camera += h[k * S_COUNT + S_CAM]; stats.n_closest += h[k * S_COUNT + S_CLOSEST]; stats.n_shadow += h[k * S_COUNT + S_SHADOW];
         stats.n_nodes += h[k * S_COUNT + S_NODES]; stats.n_tris += h[k * S_COUNT + S_TRIS];
+#if NORI_WF_PROFILE
+        { const double tot = (double) h[k * S_COUNT + 7];
+          if (tot > 0.0) fprintf(stderr, "[wf_extend profile] wave cycles: refill %.3f, node loop %.3f, triangle step %.3f of %.4g total\n", h[k * S_COUNT + 6] / tot,
+                  h[k * S_COUNT + S_NODES] / tot, h[k * S_COUNT + S_TRIS] / tot, tot);
+          else fprintf(stderr, "[wf_extend profile] raw %llu %llu %llu %llu %llu %llu %llu %llu\n", h[k * S_COUNT], h[k * S_COUNT + 1], h[k * S_COUNT + 2], h[k * S_COUNT + 3],
+                       h[k * S_COUNT + 4], h[k * S_COUNT + 5], h[k * S_COUNT + 6], h[k * S_COUNT + 7]); }
+#endif
     }
     stats.n_invalid = film_invalid_count(film, s);
     timer.collect(stats.class_ms, stats.class_launches);

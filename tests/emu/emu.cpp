@@ -43,6 +43,7 @@ struct emu_ctx {
     HostBvh bvh;
     DevScene dev;
     std::vector<f4> top_image;      /* rt_top.h: the records wf_extend keeps in LDS; the harness walks through them too */
+    std::vector<f4> nodes_q, top_image_q;      /* rt_nodeq.h: the 32-B node records and the image that holds them */
     std::string error;
 };
 
@@ -60,11 +61,30 @@ static void bind(emu_ctx *c) {
     d.n_cdf = (uint32_t) h.emitter_cdf.size();
     d.root = c->bvh.root;
     d.wide = c->bvh.wide ? 1u : 0u;
+    /* the nodes as 32-B records (rt_nodeq.h) when the tree qualifies -- the harness then walks those, as wf_extend does */
+    const char *nqe = std::getenv("NORI_EMU_NODEQ");
+    d.nodes_q = nullptr; d.top_image_q = nullptr; d.top_image_q_quads = 0u; d.top_image = nullptr; d.top_image_quads = 0u;
+    if (d.n_triangles > 0 && !d.wide && d.root >= 0 && !(nqe && atoi(nqe) == 0) && nodeq_grid(d.nodes, d.root, d.grid)) {
+        const size_t n_nodes = c->bvh.nodes.size() / kNodeQuads;
+        c->nodes_q.assign(n_nodes * kNodeqQuads, f4());
+        bool ok = true;
+        for (size_t i = 0; i < n_nodes; ++i) ok &= nodeq_from_node(d.nodes + i * kNodeQuads, d.grid, c->nodes_q.data() + i * kNodeqQuads);
+        if (ok) d.nodes_q = c->nodes_q.data();
+    }
     const char *ti = std::getenv("NORI_EMU_TOP_IMAGE");
     if (d.n_triangles > 0 && !(ti && atoi(ti) == 0)) {
-        c->top_image.assign(kTopImageQuads, f4());
-        top_image_build(d.nodes, d.tris, d.root, d.wide != 0u, d.n_triangles, c->top_image.data());
+        /* as many node records as the device keeps (wavefront.hip, wf_top_capacity) unless told otherwise */
+        const char *tn = std::getenv("NORI_EMU_TOP_NODES");
+        c->top_image.assign(kTopImageMaxQuads, f4());
+        top_image_build(d.nodes, d.nodes, top_layout(false), d.tris, d.root, d.wide != 0u, d.n_triangles, tn ? atoi(tn) : (d.wide ? 126 : 143), c->top_image.data());
         d.top_image = c->top_image.data();
+        d.top_image_quads = f2u(c->top_image[0].w);
+        if (d.nodes_q) {
+            c->top_image_q.assign(kTopImageMaxQuads, f4());
+            top_image_build(d.nodes, d.nodes_q, top_layout(true), d.tris, d.root, false, d.n_triangles, tn ? atoi(tn) : 358, c->top_image_q.data());
+            d.top_image_q = c->top_image_q.data();
+            d.top_image_q_quads = f2u(c->top_image_q[0].w);
+        }
     }
     d.camera = h.camera; d.filter = h.filter; d.integrator = h.integrator;
 }
