@@ -51,6 +51,7 @@ OPS_NODE, OPS_TRI, OPS_RAY = 52, 54, 9      # algorithmic f32 vector ops per two
 OPS_NODE_WIDE = 103                          # ... per WIDE node test (four quantised boxes: 21 setup + 6 selects + 48 planes + 16 min/max + 12 compares)
 # the same work as the kernel ISSUES it (rt_trace.h): VALU instructions per unit of the shipped code
 ISSUED_NODE, ISSUED_TRI, ISSUED_RAY = 30, 37.5, 9      # slab_two: 6 v_pk + 12 v_fma + 4 min3/max3 + 2 v_mul + 6 v_cmp; tri_pair_test: ~75 per PAIR of triangles
+ISSUED_NODE_32B = 40                          # the hand-written loop on 32-B records: 6 v_bfi + 12 v_cvt (SDWA) + 12 v_fma + 4 min3/max3 + 6 v_cmp
 ISSUED_NODE_WIDE = 85
 VALU_ISSUE_SLOTS = 256 * 4 * 2.4e9 / 2.4 * 64          # lane-instructions per second at the measured best case of 2.4 cycles per wave64 instruction
 FLOP_PEAK_TFLOPS = 157.3                               # MI355X_MICROARCH.md: f32 vector peak (v_pk_fma_f32: 2 lanes x 2 flops)
@@ -295,8 +296,13 @@ def main():
         # the three ways to price the same traversal work (all <= 1): `valu_frac` = textbook operation count (52 / 54 / 9) against
         # one lane-operation per lane per clock; `flop_frac` = the same count against the f32 FLOP peak (packed FMA: 4 flops
         # per lane per clock -- reachable only by v_pk_fma); `issued_frac` = the VALU instructions the shipped code issues
-        # per unit (30 / 37.5 / 9), as lane-instructions, against the issue rate of the fastest instructions
-        issued = counted["n_node_tests"] * (ISSUED_NODE_WIDE if wide else ISSUED_NODE) + counted["n_tri_tests"] * ISSUED_TRI + rays_c * ISSUED_RAY
+        # per unit (30 / 37.5 / 9; 40 per node test in the loop over 32-B records), as lane-instructions, against the issue rate
+        # of the fastest instructions
+        # (the wavefront engine walks a BVH2 tree that has 32-B node records and fits the LDS stack with its hand-written loop)
+        node_loop_32b = engine == "wavefront" and not wide and info.get("node_records_32b", 0) == 1 and info["max_depth"] + 1 <= 16
+        issued_node = ISSUED_NODE_WIDE if wide else ISSUED_NODE_32B if node_loop_32b else ISSUED_NODE
+        issued = counted["n_node_tests"] * issued_node + counted["n_tri_tests"] * ISSUED_TRI + rays_c * ISSUED_RAY
+        roof["node_record_bytes"] = 32 if node_loop_32b else int(info["node_bytes"])
         roof["flop_frac"] = round(ops / (t_ms * 1e-3) / 1e12 / FLOP_PEAK_TFLOPS, 5)
         roof["issued_valu_instr"] = int(issued)
         roof["issued_frac"] = round(issued / (t_ms * 1e-3) / VALU_ISSUE_SLOTS, 5)

@@ -261,7 +261,9 @@ typedef struct nori_accel_info {
     float build_ms;
     float sah_cost;
     uint32_t node_children;  /* boxes one node record holds: 2 (BVH2) or 4 (wide nodes, quantised boxes) */
-    uint32_t reserved;
+    uint32_t node_records_32b;  /* 1: the tree also exists as 32-B node records (two children's boxes as 16-bit planes on one
+                                grid + the links), which the wavefront engine's hand-written node loop walks when the tree's
+                                traversal stack fits LDS (depth <= 16); BVH2 trees without unbounded boxes only */
 } nori_accel_info;
 
 typedef struct nori_hip_ctx nori_hip_ctx;

@@ -90,7 +90,7 @@ class AccelInfo(C.Structure):
     _fields_ = [("n_triangles", C.c_uint32), ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32),
                 ("max_depth", C.c_uint32), ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
                 ("total_bytes", C.c_uint64), ("build_ms", C.c_float), ("sah_cost", C.c_float),
-                ("node_children", C.c_uint32), ("reserved", C.c_uint32)]
+                ("node_children", C.c_uint32), ("node_records_32b", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

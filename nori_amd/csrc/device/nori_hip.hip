@@ -639,7 +639,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
             void *img = nullptr;
             HIP_TRY(ctx, hipMalloc(&img, kTopImageMaxQuads * sizeof(f4)));
             ctx->allocs_accel.push_back(img);
-            const int max_nodes = std::min(limit, wf_top_capacity(ctx->bvh.wide, q == 1));
+            const int max_nodes = std::min(limit, wf_top_capacity(ctx->bvh.wide, q == 1, ctx->bvh.max_depth + 1 > 16));
             hipLaunchKernelGGL(top_image_kernel, dim3(1), dim3(64), 0, 0, ctx->dev, q == 1 ? ctx->dev.nodes_q : ctx->dev.nodes, top_layout(q == 1), max_nodes,
                                reinterpret_cast<f4 *>(img));
             HIP_TRY(ctx, hipGetLastError());
@@ -655,7 +655,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     in.max_depth = ctx->bvh.max_depth; in.node_bytes = kNodeQuads * 16; in.tri_bytes = kPairQuads * 16 / 2;
     in.total_bytes = ctx->lbvh_bytes ? ctx->lbvh_bytes : (uint64_t) ctx->bvh.nodes.size() * 16 + (uint64_t) ctx->bvh.tris.size() * 16;
     in.build_ms = ctx->bvh.build_ms; in.sah_cost = ctx->bvh.sah_cost;
-    in.node_children = ctx->bvh.wide ? 4u : 2u; in.reserved = 0u;
+    in.node_children = ctx->bvh.wide ? 4u : 2u; in.node_records_32b = ctx->dev.nodes_q != nullptr ? 1u : 0u;
     ctx->have_accel = true;
     return NORI_OK;
 }

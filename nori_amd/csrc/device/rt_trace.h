@@ -338,7 +338,7 @@ NORI_HD void tri_pair_test(const f4 &q0, const f4 &q1, const f4 &q2, const f4 &q
 
 /* one leaf step: ONE PAIR of triangles, then advance within the leaf.  `top`: the LDS image (rt_top.h) -- a cursor
    with kTopBit names a pair record cached there */
-template <bool COUNT, class Stack>
+template <bool COUNT, bool MESH = true, class Stack>
 NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, TopNodesP top = nullptr) {
     const uint32_t cursor = ~(uint32_t) tv.node;
     f4 q0, q1, q2, q3, q4;
@@ -351,7 +351,19 @@ NORI_HD void trav_leaf_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
     NORI_HIST(1, cursor >> 3);
     TriPairHit r;
     tri_pair_test(q0, q1, q2, q3, q4, tv.o, tv.d, tv.mint, tv.hit.t, r);
-    if (r.ok[0] || r.ok[1]) {
+    /* MESH = false (wf_extend, which does not keep hit.mesh: wf_shade fetches the mesh with the shading record, hit_unpack): the
+       update of the hit written as selects -- one v_cndmask per field and candidate.  As branches the compiler builds a region per
+       outcome, each with its own copies of the four fields: 32 register moves and ten skip branches per leaf step.  Same decisions. */
+    if (!MESH) {
+        const uint32_t gid0 = f2u(q4.z), gid1 = f2u(q4.w);
+        const bool any = tv.any;
+        const bool take0 = any ? r.ok[0] : (r.ok[0] && r.t[0] <= tv.hit.t && !(r.t[0] == tv.hit.t && tv.hit.tri != kNoHit && gid0 < tv.hit.tri));
+        const float t0 = take0 ? r.t[0] : tv.hit.t, u0 = take0 ? r.u[0] : tv.hit.u, v0 = take0 ? r.v[0] : tv.hit.v;
+        const uint32_t tri0 = take0 ? gid0 : tv.hit.tri;
+        const bool take1 = any ? (r.ok[1] && !r.ok[0]) : (r.ok[1] && r.t[1] <= t0 && !(r.t[1] == t0 && tri0 != kNoHit && gid1 < tri0));
+        tv.hit.t = take1 ? r.t[1] : t0; tv.hit.u = take1 ? r.u[1] : u0; tv.hit.v = take1 ? r.v[1] : v0; tv.hit.tri = take1 ? gid1 : tri0;
+        if (any && (r.ok[0] || r.ok[1])) { tv.node = kTravDone; return; }
+    } else if (r.ok[0] || r.ok[1]) {
         const f4 q5 = cached ? top_quad(lq + 5) : tq[5];
         if (tv.any) {
             const int k = r.ok[0] ? 0 : 1;
@@ -388,6 +400,7 @@ NORI_HD bool traverse(const DevScene &sc, const RayIn &ray, bool any, Stack &sta
 #else
     /* the harness walks the 32-B records when the tree has them (rt_nodeq.h): wf_extend's default node loop */
     const bool use_q = sc.nodes_q != nullptr && !sc.wide;
+    static const bool leaf_select = [] { const char *e = std::getenv("NORI_EMU_LEAF_SELECT"); return e == nullptr || std::atoi(e) != 0; }();
     const TopNodesP top = use_q ? sc.top_image_q : sc.top_image;
     if (top != nullptr && trav_active(tv)) tv.node = (int) f2u(top[0].x);
 #endif
@@ -396,8 +409,17 @@ NORI_HD bool traverse(const DevScene &sc, const RayIn &ray, bool any, Stack &sta
             if (sc.wide) trav_wide_step<COUNT>(sc, stack, tv, cnt, top);
             else if (use_q) trav_inner_step_q<COUNT>(sc, stack, tv, cnt, top);
             else trav_inner_step<COUNT>(sc, stack, tv, cnt, top);
-        } else trav_leaf_step<COUNT>(sc, stack, tv, cnt, top);
+        } else {
+#if !defined(__HIP_DEVICE_COMPILE__)
+            if (leaf_select) trav_leaf_step<COUNT, false>(sc, stack, tv, cnt, top);      /* wf_extend's form of the leaf step */
+            else
+#endif
+            trav_leaf_step<COUNT>(sc, stack, tv, cnt, top);
+        }
     }
+#if !defined(__HIP_DEVICE_COMPILE__)
+    if (leaf_select && tv.hit.tri != kNoHit) tv.hit.mesh = sc.tri_mesh[tv.hit.tri];      /* (that form does not keep the mesh) */
+#endif
     hit = tv.hit;
     return hit.tri != kNoHit;
 }

@@ -44,7 +44,7 @@ std::string wavefront_render(WfEngine &engine, FilmStore &film_store, const DevS
                              const WfLaunch &launch, float *d_rgbw, void *stream, WfStats &stats);
 
 /* node records of the LDS image (rt_top.h) that fit next to wf_extend's traversal stacks, per node layout */
-int wf_top_capacity(bool wide_nodes, bool records_32b);
+int wf_top_capacity(bool wide_nodes, bool records_32b, bool deeper_than_lds_stack);
 
 /* -DNORI_COUNT_EXCURSIONS builds: adds this translation unit's excursion counters (rt_types.h) to out[4], optionally
    resetting them; false in the product build */

@@ -149,6 +149,42 @@ struct LdsStackW<DEPTH, false, BLOCK> {
     static constexpr int kLdsEntries = DEPTH + 1;
 };
 
+/* The stack of the hand-written node loop for trees deeper than DEPTH: the LDS stack above, and what does not fit goes to a
+   per-lane column of a global buffer.  The loop itself only knows the LDS part (one register: `top`); a lane whose LDS part
+   is full makes it hand the step to the C++ code (wf_extend), which pushes and pops through this class.  The number of
+   entries a lane has in the global column is kept in the LDS slot behind its last stack slot -- the slot `top` points at
+   exactly when the LDS part is full -- so it costs no register.  Full is a wave-uniform comparison: top >= limit. */
+template <int DEPTH, int BLOCK>
+struct LdsStackHybrid {
+    uint32_t top;
+    uint32_t wave_base, limit;      /* wave-uniform: LDS address of slot 0 of lane 0 / of the counter slot of lane 0 */
+    int *spill; uint32_t spill_stride;
+    __device__ __forceinline__ void init(char *smem, int *spill_, uint32_t stride_) {
+        wave_base = (uint32_t) __builtin_amdgcn_readfirstlane((int) (lds_address(smem) + (threadIdx.x & ~63u) * 4u));
+        limit = wave_base + (uint32_t) (DEPTH + 1) * BLOCK * 4u; top = 0u; spill = spill_; spill_stride = stride_;
+    }
+    __device__ __forceinline__ void reset() {
+        uint32_t lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        const uint32_t base = wave_base + lane * 4u;
+        *lds_int_at(base) = kTravDone; *lds_int_at(base + (uint32_t) (DEPTH + 1) * BLOCK * 4u) = 0; top = base + BLOCK * 4u;
+    }
+    __device__ __forceinline__ void push(int v) {
+        if (top < limit) { *lds_int_at(top) = v; top += BLOCK * 4u; }
+        else { const int n = *lds_int_at(top); spill[(size_t) n * spill_stride + blockIdx.x * BLOCK + threadIdx.x] = v; *lds_int_at(top) = n + 1; }
+    }
+    __device__ __forceinline__ int pop_or(int) {
+        if (top >= limit) {
+            const int n = *lds_int_at(top);
+            if (n > 0) { *lds_int_at(top) = n - 1; return spill[(size_t) (n - 1) * spill_stride + blockIdx.x * BLOCK + threadIdx.x]; }
+        }
+        top -= BLOCK * 4u; return *lds_int_at(top);
+    }
+    static constexpr int kLdsEntries = DEPTH + 2;
+};
+template <int STACK, bool SPILL, bool ASM, int BLOCK> struct ExtendStack { typedef LdsStackW<STACK, SPILL, BLOCK> type; };
+template <int STACK, int BLOCK> struct ExtendStack<STACK, true, true, BLOCK> { typedef LdsStackHybrid<STACK, BLOCK> type; };
+
 __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
 
 /* Streaming accesses to the path state: every record is written once and read once per pass, tens of GB -- nothing of
@@ -247,108 +283,137 @@ __device__ __forceinline__ bool first_vertex(const DevScene &sc, const WfBatch &
 #else
 #define NORI_EXP_Q_ALU
 #endif
-template <int STACK_STRIDE>      /* bytes between a lane's stack slots */
-__device__ __forceinline__ void bvh2q_node_loop_asm(int &node_io, uint32_t &stack_top, float tmax, const NodeqRay &R, int mx, int my, int mz,
-                                                    const f4 *nodes_q, uint32_t image_address, int repeat) {
+/* CHECK_FULL (trees deeper than the LDS stack, LdsStackHybrid): before a step, lanes whose LDS stack is full (top >= stack_limit)
+   end the loop -- returns true, and the caller does that step in C++. */
+template <int STACK_STRIDE, bool CHECK_FULL>      /* STACK_STRIDE: bytes between a lane's stack slots */
+__device__ __forceinline__ bool bvh2q_node_loop_asm(int &node_io, uint32_t &stack_top, float tmax, const NodeqRay &R, int mx, int my, int mz,
+                                                    const f4 *nodes_q, uint32_t image_address, int repeat, int leaf_threshold, int busy_max,
+                                                    uint32_t stack_limit) {
     int r_node = node_io;
     uint32_t r_sp = stack_top;
     unsigned long long all, inner, hl, hr, t, u;      /* lane masks (scalar register pairs the compiler picks) */
+    int cnt, slow;
     /* v[32:35] = x lo, x hi, y lo, y hi; v[36:39] = z lo, z hi, left link, right link; v40 .. v45: the near / far dwords per axis */
-    asm volatile(
-        "s_mov_b64 %[all], exec\n\t"
-        "v_cmp_lt_i32 %[t], -1, %[node]\n"                        /* lanes at an inner node */
-        "1:\n\t"
-        "s_and_b64 exec, %[all], %[t]\n\t"
-        "s_cbranch_execz 3f\n\t"
-        /* fetch: the node's record from the LDS image (link carries kTopBit: quad offset in its low bits) or from memory */
-        "v_cmp_lt_u32 vcc, 0x3fffffff, %[node]\n\t"
-        "s_mov_b64 %[inner], exec\n\t"
-        "s_and_b64 exec, %[inner], vcc\n\t"
-        "v_and_b32 v40, 0xffff, %[node]\n\t"
-        "v_lshl_add_u32 v40, v40, 4, %[image]\n\t"
-        "ds_read_b128 v[32:35], v40\n\t"
-        "ds_read_b128 v[36:39], v40 offset:16\n\t"
-        NORI_EXP_Q_LDS
-        "s_andn2_b64 exec, %[inner], vcc\n\t"
-        "s_cbranch_execz 2f\n\t"
-        "v_lshlrev_b32 v40, 5, %[node]\n\t"                       /* (other lanes than the ones that just used v40) */
-        "global_load_dwordx4 v[32:35], v40, %[nodes]\n\t"
-        "global_load_dwordx4 v[36:39], v40, %[nodes] offset:16\n"
-        NORI_EXP_Q_GLOBAL
-        "2:\n\t"
-        "s_mov_b64 exec, %[inner]\n\t"
-        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
-        NORI_EXP_Q_ALU
-        /* per axis the dword with the near planes and the one with the far planes (mask = sign of the direction) */
-        "v_bfi_b32 v40, %[mx], v33, v32\n\t"
-        "v_bfi_b32 v41, %[mx], v32, v33\n\t"
-        "v_bfi_b32 v42, %[my], v35, v34\n\t"
-        "v_bfi_b32 v43, %[my], v34, v35\n\t"
-        "v_bfi_b32 v44, %[mz], v37, v36\n\t"
-        "v_bfi_b32 v45, %[mz], v36, v37\n\t"
-        /* t = q A + (B -+ S) per plane, near = max over the axes, far = min; the dwords of the record are free by now.
-           (Both children of an axis in one v_pk_fma_f32 -- six packed instead of twelve plain multiply-adds -- measured 3.5 ms
-           per frame slower: the coefficients as register pairs cost the kernel a spill.) */
-        NORI_SDWA("v32", "v40", "0") NORI_SDWA("v33", "v42", "0") NORI_SDWA("v34", "v44", "0")
-        "v_fma_f32 v32, v32, %[ax], %[bnx]\n\t"
-        "v_fma_f32 v33, v33, %[ay], %[bny]\n\t"
-        "v_fma_f32 v34, v34, %[az], %[bnz]\n\t"
-        "v_max3_f32 v32, v32, v33, v34\n\t"                       /* v32: near, left child */
-        NORI_SDWA("v33", "v41", "0") NORI_SDWA("v34", "v43", "0") NORI_SDWA("v35", "v45", "0")
-        "v_fma_f32 v33, v33, %[ax], %[bfx]\n\t"
-        "v_fma_f32 v34, v34, %[ay], %[bfy]\n\t"
-        "v_fma_f32 v35, v35, %[az], %[bfz]\n\t"
-        "v_min3_f32 v33, v33, v34, v35\n\t"                       /* v33: far, left child */
-        NORI_SDWA("v34", "v40", "1") NORI_SDWA("v35", "v42", "1") NORI_SDWA("v36", "v44", "1")
-        "v_fma_f32 v34, v34, %[ax], %[bnx]\n\t"
-        "v_fma_f32 v35, v35, %[ay], %[bny]\n\t"
-        "v_fma_f32 v36, v36, %[az], %[bnz]\n\t"
-        "v_max3_f32 v34, v34, v35, v36\n\t"                       /* v34: near, right child */
-        NORI_SDWA("v35", "v41", "1") NORI_SDWA("v36", "v43", "1") NORI_SDWA("v37", "v45", "1")
-        "v_fma_f32 v35, v35, %[ax], %[bfx]\n\t"
-        "v_fma_f32 v36, v36, %[ay], %[bfy]\n\t"
-        "v_fma_f32 v37, v37, %[az], %[bfz]\n\t"
-        "v_min3_f32 v35, v35, v36, v37\n\t"                       /* v35: far, right child */
-        "v_cmp_le_f32 vcc, v32, v33\n\t"
-        "v_cmp_le_f32 %[t], v32, %[tm]\n\t"
-        "v_cmp_le_f32 %[hl], 0, v33\n\t"
-        "v_cmp_le_f32 %[hr], v34, v35\n\t"
-        "v_cmp_le_f32 %[u], v34, %[tm]\n\t"
-        "s_and_b64 %[hl], %[hl], vcc\n\t"
-        "v_cmp_le_f32 vcc, 0, v35\n\t"
-        "s_and_b64 %[hl], %[hl], %[t]\n\t"                        /* left child hit */
-        "s_and_b64 %[hr], %[hr], %[u]\n\t"
-        "s_and_b64 %[hr], %[hr], vcc\n\t"                         /* right child hit */
-        /* selection: both -> the nearer one next, the other pushed; one -> that one; none -> pop */
-        "v_cmp_le_f32 vcc, v32, v34\n\t"
-        "s_and_b64 %[t], %[hl], %[hr]\n\t"                        /* both */
-        "s_or_b64 %[hr], %[hl], %[hr]\n\t"                        /* any */
-        "v_cndmask_b32 v40, v39, v38, vcc\n\t"
-        "v_cndmask_b32 v41, v38, v39, vcc\n\t"
-        "v_cndmask_b32 v42, v39, v38, %[hl]\n\t"
-        "v_cndmask_b32 %[node], v42, v40, %[t]\n\t"
-        "s_mov_b64 exec, %[t]\n\t"
-        "ds_write_b32 %[sp], v41\n\t"
-        "v_add_u32 %[sp], %[stride], %[sp]\n\t"
-        "s_andn2_b64 exec, %[inner], %[hr]\n\t"
-        "v_subrev_u32 %[sp], %[stride], %[sp]\n\t"
-        "ds_read_b32 %[node], %[sp]\n\t"
-        "s_mov_b64 exec, %[all]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "v_cmp_lt_i32 %[t], -1, %[node]\n\t"
-        "s_bcnt1_i32_b64 vcc_lo, %[t]\n\t"
-        "s_cmp_ge_u32 vcc_lo, %[repeat]\n\t"
-        "s_cbranch_scc1 1b\n"
-        "3:\n\t"
-        "s_mov_b64 exec, %[all]\n\t"
-        : [node] "+v"(r_node), [sp] "+v"(r_sp), [all] "=&s"(all), [inner] "=&s"(inner), [hl] "=&s"(hl), [hr] "=&s"(hr), [t] "=&s"(t), [u] "=&s"(u)
-        : [tm] "v"(tmax), [ax] "v"(R.A[0]), [ay] "v"(R.A[1]), [az] "v"(R.A[2]), [bnx] "v"(R.Bn[0]), [bny] "v"(R.Bn[1]), [bnz] "v"(R.Bn[2]),
-          [bfx] "v"(R.Bf[0]), [bfy] "v"(R.Bf[1]), [bfz] "v"(R.Bf[2]), [mx] "v"(mx), [my] "v"(my), [mz] "v"(mz),
-          [nodes] "s"(nodes_q), [image] "s"(image_address), [repeat] "s"(repeat), [stride] "n"(STACK_STRIDE)
-        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45",
-          "vcc", "scc", "memory");
+#define NORI_QLOOP_FULL_CHECK "v_cmp_le_u32 vcc, %[limit], %[sp]\n\ts_cbranch_vccnz 4f\n\t"
+#define NORI_QLOOP(FULL_CHECK) \
+    asm volatile( \
+        "s_mov_b64 %[all], exec\n\t" \
+        "s_mov_b32 %[slow], 0\n\t" \
+        "v_cmp_lt_i32 %[t], -1, %[node]\n"                        /* lanes at an inner node */ \
+        "1:\n\t" \
+        "s_and_b64 exec, %[all], %[t]\n\t" \
+        "s_cbranch_execz 3f\n\t" \
+        FULL_CHECK \
+        /* fetch: the node's record from the LDS image (link carries kTopBit: quad offset in its low bits) or from memory */ \
+        "v_cmp_lt_u32 vcc, 0x3fffffff, %[node]\n\t" \
+        "s_mov_b64 %[inner], exec\n\t" \
+        "s_and_b64 exec, %[inner], vcc\n\t" \
+        "v_and_b32 v40, 0xffff, %[node]\n\t" \
+        "v_lshl_add_u32 v40, v40, 4, %[image]\n\t" \
+        "ds_read_b128 v[32:35], v40\n\t" \
+        "ds_read_b128 v[36:39], v40 offset:16\n\t" \
+        NORI_EXP_Q_LDS \
+        "s_andn2_b64 exec, %[inner], vcc\n\t" \
+        "s_cbranch_execz 2f\n\t" \
+        "v_lshlrev_b32 v40, 5, %[node]\n\t"                       /* (other lanes than the ones that just used v40) */ \
+        "global_load_dwordx4 v[32:35], v40, %[nodes]\n\t" \
+        "global_load_dwordx4 v[36:39], v40, %[nodes] offset:16\n" \
+        NORI_EXP_Q_GLOBAL \
+        "2:\n\t" \
+        "s_mov_b64 exec, %[inner]\n\t" \
+        "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t" \
+        NORI_EXP_Q_ALU \
+        /* per axis the dword with the near planes and the one with the far planes (mask = sign of the direction) */ \
+        "v_bfi_b32 v40, %[mx], v33, v32\n\t" \
+        "v_bfi_b32 v41, %[mx], v32, v33\n\t" \
+        "v_bfi_b32 v42, %[my], v35, v34\n\t" \
+        "v_bfi_b32 v43, %[my], v34, v35\n\t" \
+        "v_bfi_b32 v44, %[mz], v37, v36\n\t" \
+        "v_bfi_b32 v45, %[mz], v36, v37\n\t" \
+        /* t = q A + (B -+ S) per plane, near = max over the axes, far = min; the dwords of the record are free by now. \
+           (Both children of an axis in one v_pk_fma_f32 -- six packed instead of twelve plain multiply-adds -- measured 3.5 ms \
+           per frame slower: the coefficients as register pairs cost the kernel a spill.) */ \
+        NORI_SDWA("v32", "v40", "0") NORI_SDWA("v33", "v42", "0") NORI_SDWA("v34", "v44", "0") \
+        "v_fma_f32 v32, v32, %[ax], %[bnx]\n\t" \
+        "v_fma_f32 v33, v33, %[ay], %[bny]\n\t" \
+        "v_fma_f32 v34, v34, %[az], %[bnz]\n\t" \
+        "v_max3_f32 v32, v32, v33, v34\n\t"                       /* v32: near, left child */ \
+        NORI_SDWA("v33", "v41", "0") NORI_SDWA("v34", "v43", "0") NORI_SDWA("v35", "v45", "0") \
+        "v_fma_f32 v33, v33, %[ax], %[bfx]\n\t" \
+        "v_fma_f32 v34, v34, %[ay], %[bfy]\n\t" \
+        "v_fma_f32 v35, v35, %[az], %[bfz]\n\t" \
+        "v_min3_f32 v33, v33, v34, v35\n\t"                       /* v33: far, left child */ \
+        NORI_SDWA("v34", "v40", "1") NORI_SDWA("v35", "v42", "1") NORI_SDWA("v36", "v44", "1") \
+        "v_fma_f32 v34, v34, %[ax], %[bnx]\n\t" \
+        "v_fma_f32 v35, v35, %[ay], %[bny]\n\t" \
+        "v_fma_f32 v36, v36, %[az], %[bnz]\n\t" \
+        "v_max3_f32 v34, v34, v35, v36\n\t"                       /* v34: near, right child */ \
+        NORI_SDWA("v35", "v41", "1") NORI_SDWA("v36", "v43", "1") NORI_SDWA("v37", "v45", "1") \
+        "v_fma_f32 v35, v35, %[ax], %[bfx]\n\t" \
+        "v_fma_f32 v36, v36, %[ay], %[bfy]\n\t" \
+        "v_fma_f32 v37, v37, %[az], %[bfz]\n\t" \
+        "v_min3_f32 v35, v35, v36, v37\n\t"                       /* v35: far, right child */ \
+        "v_cmp_le_f32 vcc, v32, v33\n\t" \
+        "v_cmp_le_f32 %[t], v32, %[tm]\n\t" \
+        "v_cmp_le_f32 %[hl], 0, v33\n\t" \
+        "v_cmp_le_f32 %[hr], v34, v35\n\t" \
+        "v_cmp_le_f32 %[u], v34, %[tm]\n\t" \
+        "s_and_b64 %[hl], %[hl], vcc\n\t" \
+        "v_cmp_le_f32 vcc, 0, v35\n\t" \
+        "s_and_b64 %[hl], %[hl], %[t]\n\t"                        /* left child hit */ \
+        "s_and_b64 %[hr], %[hr], %[u]\n\t" \
+        "s_and_b64 %[hr], %[hr], vcc\n\t"                         /* right child hit */ \
+        /* selection: both -> the nearer one next, the other pushed; one -> that one; none -> pop.  "Left next" as a lane mask \
+           (scalar unit): both and left nearer, or left alone */ \
+        "v_cmp_le_f32 vcc, v32, v34\n\t" \
+        "s_and_b64 %[t], %[hl], %[hr]\n\t"                        /* both */ \
+        "s_or_b64 %[u], %[hl], %[hr]\n\t"                         /* any */ \
+        "s_and_b64 vcc, vcc, %[t]\n\t" \
+        "s_andn2_b64 %[hl], %[hl], %[hr]\n\t" \
+        "s_or_b64 vcc, vcc, %[hl]\n\t" \
+        "v_cndmask_b32 %[node], v39, v38, vcc\n\t"              /* the child walked next ... */ \
+        "v_cndmask_b32 v40, v38, v39, vcc\n\t"                  /* ... and the other one */ \
+        "s_mov_b64 exec, %[t]\n\t" \
+        "ds_write_b32 %[sp], v40\n\t" \
+        "v_add_u32 %[sp], %[stride], %[sp]\n\t" \
+        "s_andn2_b64 exec, %[inner], %[u]\n\t" \
+        "v_subrev_u32 %[sp], %[stride], %[sp]\n\t" \
+        "ds_read_b32 %[node], %[sp]\n\t" \
+        "s_mov_b64 exec, %[all]\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        /* again at once while enough lanes are at inner nodes -- or while some are and the trip around the loop outside would do \
+           nothing else: no triangle step (too few lanes at a leaf) and no refill (too few idle lanes, or nothing to hand out) */ \
+        "v_cmp_lt_i32 %[t], -1, %[node]\n\t" \
+        "s_bcnt1_i32_b64 vcc_lo, %[t]\n\t" \
+        "s_cmp_ge_u32 vcc_lo, %[repeat]\n\t" \
+        "s_cbranch_scc1 1b\n\t" \
+        "s_cmp_eq_u32 vcc_lo, 0\n\t" \
+        "s_cbranch_scc1 3f\n\t" \
+        "s_mov_b32 %[cnt], vcc_lo\n\t"                                /* lanes at inner nodes */ \
+        "v_cmp_lt_u32 vcc, 0x80000000, %[node]\n\t"             /* lanes at a leaf */ \
+        "s_bcnt1_i32_b64 vcc_lo, vcc\n\t" \
+        "s_cmp_ge_u32 vcc_lo, %[leafth]\n\t" \
+        "s_cbranch_scc1 3f\n\t" \
+        "s_add_u32 vcc_lo, vcc_lo, %[cnt]\n\t"                        /* lanes with a ray in flight */ \
+        "s_cmp_le_i32 vcc_lo, %[busymax]\n\t"                     /* idle lanes >= the refill threshold (and there is something to refill with) */ \
+        "s_cbranch_scc0 1b\n" \
+        "s_branch 3f\n" \
+        "4:\n\t" \
+        "s_mov_b32 %[slow], 1\n" \
+        "3:\n\t" \
+        "s_mov_b64 exec, %[all]\n\t" \
+        : [node] "+v"(r_node), [sp] "+v"(r_sp), [all] "=&s"(all), [inner] "=&s"(inner), [hl] "=&s"(hl), [hr] "=&s"(hr), [t] "=&s"(t), [u] "=&s"(u), [cnt] "=&s"(cnt), [slow] "=&s"(slow) \
+        : [tm] "v"(tmax), [ax] "v"(R.A[0]), [ay] "v"(R.A[1]), [az] "v"(R.A[2]), [bnx] "v"(R.Bn[0]), [bny] "v"(R.Bn[1]), [bnz] "v"(R.Bn[2]), \
+          [bfx] "v"(R.Bf[0]), [bfy] "v"(R.Bf[1]), [bfz] "v"(R.Bf[2]), [mx] "v"(mx), [my] "v"(my), [mz] "v"(mz), \
+          [nodes] "s"(nodes_q), [image] "s"(image_address), [repeat] "s"(repeat), [leafth] "s"(leaf_threshold), [busymax] "s"(busy_max), [limit] "s"(stack_limit), [stride] "n"(STACK_STRIDE) \
+        : "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", \
+          "vcc", "scc", "memory")
+    if (CHECK_FULL) { NORI_QLOOP(NORI_QLOOP_FULL_CHECK); } else { NORI_QLOOP(""); }
+#undef NORI_QLOOP
+#undef NORI_QLOOP_FULL_CHECK
     node_io = r_node;
     stack_top = r_sp;
+    return slow != 0;
 }
 
 /* hit_pack (wf_records.h) for wf_extend: the constants of "no closest hit" (t = inf, u = v = 0) are made from a zero the compiler
@@ -382,14 +447,15 @@ template <int STACK, bool SPILL, bool COUNT, bool FIRST, bool WIDE, bool ASM, in
 __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    LdsStackW<STACK, SPILL, BLOCK> stack;
+    typedef typename ExtendStack<STACK, SPILL, ASM, BLOCK>::type Stack;
+    Stack stack;
     stack.init(smem, b.stack_spill, gridDim.x * BLOCK);
     /* the first levels of the tree in LDS (rt_trace.h, node_fetch): behind the stacks */
-    f4 *top = reinterpret_cast<f4 *>(smem + (size_t) LdsStackW<STACK, SPILL, BLOCK>::kLdsEntries * BLOCK * sizeof(int));
+    f4 *top = reinterpret_cast<f4 *>(smem + (size_t) Stack::kLdsEntries * BLOCK * sizeof(int));
     /* the kernel with the hand-written node loop walks the 32-B records: its image holds those */
     const int root_link = ASM ? top_image_to_lds(sc, top, sc.top_image_q, sc.top_image_q_quads) : top_image_to_lds(sc, top, sc.top_image, sc.top_image_quads);
     const TopNodesP top_lds = top_nodes_pointer(top);
-    const uint32_t image_address = lds_address(smem) + (uint32_t) (LdsStackW<STACK, SPILL, BLOCK>::kLdsEntries * BLOCK * sizeof(int));      /* of top */
+    const uint32_t image_address = lds_address(smem) + (uint32_t) (Stack::kLdsEntries * BLOCK * sizeof(int));      /* of top */
     const WfState S = b.st[cur];
     const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
     /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
@@ -510,15 +576,22 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(D
            step only when enough lanes wait at a leaf or nobody has an inner node to test */
         if (COUNT) zc[Z_TRIPS]++;
         if constexpr (ASM) {
-            static_assert(!WIDE && !SPILL && !COUNT, "the hand-written node loop: BVH2 nodes as 32-B records, LDS-only stack");
+            static_assert(!WIDE && !COUNT, "the hand-written node loop: BVH2 nodes as 32-B records");
             /* the ray's plane coefficients (rt_nodeq.h), made anew for every pass through here: kept across the triangle step and
                the refill they would cost twelve registers the kernel does not have */
             f3 qo = tv.o, qr = tv.rcp;
             asm volatile("" : "+v"(qo.x), "+v"(qo.y), "+v"(qo.z), "+v"(qr.x), "+v"(qr.y), "+v"(qr.z));
             NodeqRay R;
             nodeq_ray(sc.grid, qo, qr, R);
-            bvh2q_node_loop_asm<BLOCK * 4>(tv.node, stack.top, tv.hit.t, R, (int) f2u(qr.x) >> 31, (int) f2u(qr.y) >> 31, (int) f2u(qr.z) >> 31,
-                                           sc.nodes_q, image_address, bt.inner_repeat);
+            uint32_t stack_limit = 0xffffffffu;
+            if constexpr (SPILL) stack_limit = stack.limit;
+            const bool full = bvh2q_node_loop_asm<BLOCK * 4, SPILL>(tv.node, stack.top, tv.hit.t, R, (int) f2u(qr.x) >> 31, (int) f2u(qr.y) >> 31, (int) f2u(qr.z) >> 31,
+                                           sc.nodes_q, image_address, bt.inner_repeat, leaf_threshold,
+                                           /* lanes in flight at or below which the refill at the top of the loop would run: never (-1) if
+                                              it has nothing to hand out */
+                                           (!exhausted || __ballot((rid & 2u) != 0u) != 0ull) ? 64 - refill_threshold : -1, stack_limit);
+            /* a lane's LDS stack is full (trees deeper than it): this step in C++, through the stack's global part */
+            if (SPILL && full && trav_at_inner(tv)) trav_inner_step_q<false>(sc, stack, tv, tc, top_lds);
         } else
         do {
             if (COUNT) { const int ni = __popcll(__ballot(trav_at_inner(tv))); if (ni) { zc[Z_INNER_TRIPS]++; zc[Z_INNER_LANES] += (uint32_t) ni; } }
@@ -532,7 +605,7 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(D
         const int nLeaf = __popcll(__ballot(atLeaf));
         const bool innerLeft = __ballot(trav_at_inner(tv)) != 0ull;
         if (COUNT && nLeaf && (nLeaf >= leaf_threshold || !innerLeft)) { zc[Z_LEAF_TRIPS]++; zc[Z_LEAF_LANES] += (uint32_t) nLeaf; }
-        if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT>(sc, stack, tv, tc, top_lds);
+        if (atLeaf && (nLeaf >= leaf_threshold || !innerLeft)) trav_leaf_step<COUNT, false>(sc, stack, tv, tc, top_lds);
         NORI_PROF_MARK(prof_leaf)
     }
     /* the answers still held in registers when the wave ran out of paths (no lane is pending here: the loop ends only
@@ -829,10 +902,10 @@ void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int 
         /* the hand-written node loop (bvh2q_node_loop_asm) walks the tree's 32-B records (rt_nodeq.h: trees without unbounded boxes),
            addresses them by 32-bit byte offsets (trees below 2^25 nodes -- a BVH2 tree has fewer nodes than triangles) and keeps its
            stack in LDS; everything else takes the compiler's loop over the 64-B nodes */
-        constexpr bool kAsm = NORI_ASM_NODE_LOOP && !SPILL && !COUNT;
+        constexpr bool kAsm = NORI_ASM_NODE_LOOP && !COUNT;
         const bool use_asm = kAsm && sc.nodes_q != nullptr && sc.n_triangles < (1u << 25) && (bt.flags & kBatchNoAsmLoop) == 0u;
-        const size_t lds = (size_t) LdsStackW<STACK, SPILL, kExtendBlockBvh2>::kLdsEntries * kExtendBlockBvh2 * sizeof(int) +
-                           (size_t) std::max(1u, use_asm ? sc.top_image_q_quads : sc.top_image_quads) * sizeof(f4);
+        const size_t lds = (use_asm ? (size_t) ExtendStack<STACK, SPILL, kAsm, kExtendBlockBvh2>::type::kLdsEntries : (size_t) LdsStackW<STACK, SPILL, kExtendBlockBvh2>::kLdsEntries) *
+                               kExtendBlockBvh2 * sizeof(int) + (size_t) std::max(1u, use_asm ? sc.top_image_q_quads : sc.top_image_quads) * sizeof(f4);
         if (use_asm)
             hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST, false, kAsm, kExtendBlockBvh2>), dim3(grid), dim3(kExtendBlockBvh2), lds, s, sc, b, cur, refill, bt);
         else
@@ -877,9 +950,11 @@ void launch_finish(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &b
 
 namespace nrt {
 
-int wf_top_capacity(bool wide_nodes, bool records_32b) {
-    /* 16 stack entries per lane in LDS (+ 1: the "done" marker of the non-spilling stack), the image in what is left */
-    const size_t per_wg = kLdsPerCu / (wide_nodes ? kExtendWgsWide : kExtendWgsBvh2), stacks = (size_t) 17 * (wide_nodes ? kExtendBlockWide : kExtendBlockBvh2) * sizeof(int);
+int wf_top_capacity(bool wide_nodes, bool records_32b, bool deeper_than_lds_stack) {
+    /* 16 stack entries per lane in LDS, + 1: the "done" marker of the stacks that do not spill, + 1: the counter of the stack
+       that spills behind the hand-written loop (LdsStackHybrid); the image in what is left */
+    const size_t per_wg = kLdsPerCu / (wide_nodes ? kExtendWgsWide : kExtendWgsBvh2);
+    const size_t stacks = (size_t) (deeper_than_lds_stack && records_32b ? 18 : 17) * (wide_nodes ? kExtendBlockWide : kExtendBlockBvh2) * sizeof(int);
     const int stride = records_32b ? kTopStrideQuadsQ : kTopStrideQuads;
     int n = 0;
     while (n < kTopMaxNodes && stacks + (size_t) top_image_quads(n + 1, stride) * sizeof(f4) <= per_wg) ++n;
@@ -1036,6 +1111,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     /* 16 entries in LDS, deeper walks spill to HBM: a stack of 24 entries costs three of the eight workgroups per CU, and walks
        rarely hold more than 16 deferred subtrees however deep the tree (measured, trace ms at 16 / 24 entries: table scene,
        depth 19: 77.5 / 83.0; Cornell box with the device builders' deeper trees: 61.6 / 74.8 and 73.3 / 82.1) */
+    const bool no_asm_loop = getenv("NORI_HIP_WF_NO_ASM_LOOP") != nullptr && atoi(getenv("NORI_HIP_WF_NO_ASM_LOOP")) != 0;
     int lds_stack = 16;
     if (const char *e = getenv("NORI_HIP_WF_STACK")) lds_stack = atoi(e) <= 16 ? 16 : atoi(e) <= 24 ? 24 : 32;
     const bool spill = L.stack_depth > lds_stack || sc.wide != 0;
@@ -1044,7 +1120,10 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     const int finish_grid = finish_paths / kB;
     /* LDS per workgroup: stack entries (+1: the "done" marker of the non-spilling stack) + the top-node cache */
     const int extend_block = sc.wide ? kExtendBlockWide : kExtendBlockBvh2;
-    const size_t lds_per_wg = (size_t) (lds_stack + 1) * extend_block * sizeof(int) + (size_t) std::max(1u, std::max(sc.top_image_quads, sc.top_image_q_quads)) * sizeof(f4);
+    /* which node loop wf_extend will run (launch_extend): the hand-written one on 32-B records, or the compiler's on 64-B nodes */
+    const bool node_loop_q = NORI_ASM_NODE_LOOP && !L.count_traversal && !sc.wide && sc.nodes_q != nullptr && sc.n_triangles < (1u << 25) && !no_asm_loop;
+    const int stack_entries = node_loop_q ? lds_stack + (spill ? 2 : 1) : lds_stack + (spill ? 0 : 1);      /* kLdsEntries of the kernel's stack class */
+    const size_t lds_per_wg = (size_t) stack_entries * extend_block * sizeof(int) + (size_t) std::max(1u, node_loop_q ? sc.top_image_q_quads : sc.top_image_quads) * sizeof(f4);
     int per_cu = std::max(1, std::min(2048 / extend_block, (int) (kLdsPerCu / lds_per_wg)));      /* workgroups per CU */
     /* every workgroup of the persistent grid must be resident from the start (a workgroup that starts late owns a
        static share of the paths and works it off alone): the wide-node kernels are built for 6 waves per SIMD
@@ -1070,7 +1149,6 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
        around the triangle step compiles with 56 B of scratch and runs 50 % slower) */
     int inner_repeat = 24;
     if (const char *e = getenv("NORI_HIP_WF_INNER_REPEAT")) inner_repeat = std::min(65, std::max(1, atoi(e)));
-    const bool no_asm_loop = getenv("NORI_HIP_WF_NO_ASM_LOOP") != nullptr && atoi(getenv("NORI_HIP_WF_NO_ASM_LOOP")) != 0;
     int sync_every = 6;      /* path-loop iterations between two readbacks of the path count */
     if (const char *e = getenv("NORI_HIP_WF_SYNC_EVERY")) sync_every = std::min(64, std::max(1, atoi(e)));
     const bool census = getenv("NORI_HIP_CENSUS") != nullptr;

@@ -235,6 +235,7 @@ int emu_accel_info(const emu_ctx *c, nori_accel_info *in) {
     in->total_bytes = (uint64_t) (c->bvh.nodes.size() + c->bvh.tris.size()) * 16;
     in->build_ms = c->bvh.build_ms; in->sah_cost = c->bvh.sah_cost;
     in->node_children = c->bvh.wide ? 4u : 2u;
+    in->node_records_32b = c->dev.nodes_q != nullptr ? 1u : 0u;
     return NORI_OK;
 }
 int emu_border_size(const emu_ctx *c) { return c->host.filter.border; }
