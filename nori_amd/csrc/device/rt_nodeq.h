@@ -39,7 +39,7 @@ NORI_HD bool node_child_box(const f4 q[4], int k, double lo[3], double hi[3]) {
     const float c[3] = {k == 0 ? q[0].x : q[0].z, k == 0 ? q[0].y : q[0].w, k == 0 ? q[1].x : q[1].y};
     const float h[3] = {k == 0 ? q[2].x : q[2].z, k == 0 ? q[2].y : q[2].w, k == 0 ? q[1].z : q[1].w};
     for (int a = 0; a < 3; ++a) {
-        if (!(h[a] < 1e30f) || !(fabsf(c[a]) < 1e30f)) return false;
+        if (!(h[a] < 0.5f * kBoxHalfInf) || !(fabsf(c[a]) < 0.5f * kBoxHalfInf)) return false;      /* box_centre_half's unbounded box: c = 0, h = kBoxHalfInf */
         lo[a] = (double) c[a] - (double) h[a]; hi[a] = (double) c[a] + (double) h[a];
     }
     return true;

@@ -103,6 +103,7 @@ def emu_lib():
             "emu_accel_info": (C.c_int, [_P, C.POINTER(capi.AccelInfo)]),
             "emu_border_size": (C.c_int, [_P]),
             "emu_intersect": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
+            "emu_nodeq_check": (C.c_longlong, [_P, _P, C.c_size_t, _P]),
             "emu_packed_vs_scalar": (C.c_size_t, [C.c_size_t, C.c_uint64]),
             "emu_libm_eval": (C.c_int, [C.c_int, _P, C.c_size_t, _P]),
             "emu_sample_rays": (C.c_int, [_P, _P, C.c_size_t, _P]),
@@ -322,6 +323,14 @@ class Emu(_CpuBackend):
         info = capi.AccelInfo()
         self.lib.emu_accel_info(self._h, C.byref(info))
         return info.as_dict()
+
+    def nodeq_check(self, rays):
+        """rt_nodeq.h: (ray, child box) pairs the exact slab test accepts and the 32-B record rejects (must be 0), and how many
+        pairs the exact test / the record accept; None if the tree has no 32-B records."""
+        rays = np.ascontiguousarray(rays, dtype=capi.RAY_DTYPE)
+        counts = np.zeros(2, np.uint64)
+        bad = self.lib.emu_nodeq_check(self._h, ptr(rays), rays.shape[0], ptr(counts))
+        return None if bad < 0 else (int(bad), int(counts[0]), int(counts[1]))
 
     def render_host(self, spp_count=None, spp_begin=0, tile_mod=1, tile_rem=0, count_traversal=False):
         p = self._params(spp_count, spp_begin, tile_mod, tile_rem, count_traversal)

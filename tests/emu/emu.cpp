@@ -240,6 +240,44 @@ int emu_accel_info(const emu_ctx *c, nori_accel_info *in) {
 }
 int emu_border_size(const emu_ctx *c) { return c->host.filter.border; }
 
+/* rt_nodeq.h: every ray against every node of the tree, the 32-B record's verdict per child against the exact one.
+   Exact = the slab test of the stored 64-B box [c - h, c + h] in binary64 with the ray's own (binary32) reciprocal
+   direction, clipped to [0, maxt] (trav_inner_step's rule).  Returns the number of (ray, child) pairs the exact test
+   accepts and the record rejects -- must be 0 -- and writes how many pairs each accepts into counts[0..1].
+   -1: the tree has no 32-B records. */
+long long emu_nodeq_check(emu_ctx *c, const nori_ray *rays, size_t n, unsigned long long *counts) {
+    const DevScene &sc = c->dev;
+    if (sc.nodes_q == nullptr) return -1;
+    const size_t n_nodes = c->nodes_q.size() / kNodeqQuads;
+    unsigned long long bad = 0, acc_exact = 0, acc_q = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const nori_ray &r = rays[i];
+        const f3 o = mk3(r.o[0], r.o[1], r.o[2]);
+        const f3 rcp = mk3(slab_rcp(r.d[0]), slab_rcp(r.d[1]), slab_rcp(r.d[2]));
+        NodeqRay R; nodeq_ray(sc.grid, o, rcp, R);
+        const double oo[3] = {o.x, o.y, o.z}, rr[3] = {rcp.x, rcp.y, rcp.z};
+        for (size_t k = 0; k < n_nodes; ++k) {
+            float nl, fl, nr, fr;
+            nodeq_slabs(sc.nodes_q[k * kNodeqQuads], sc.nodes_q[k * kNodeqQuads + 1], R, nl, fl, nr, fr);
+            const bool hq[2] = {nl <= fl && fl >= 0.0f && nl <= r.maxt, nr <= fr && fr >= 0.0f && nr <= r.maxt};
+            for (int ch = 0; ch < 2; ++ch) {
+                double lo[3], hi[3];
+                if (!node_child_box(sc.nodes + k * kNodeQuads, ch, lo, hi)) continue;
+                double tn = -1e300, tf = 1e300;
+                for (int a = 0; a < 3; ++a) {
+                    const double t0 = (lo[a] - oo[a]) * rr[a], t1 = (hi[a] - oo[a]) * rr[a];
+                    tn = std::max(tn, std::min(t0, t1)); tf = std::min(tf, std::max(t0, t1));
+                }
+                const bool he = tn <= tf && tf >= 0.0 && tn <= (double) r.maxt;
+                acc_exact += he; acc_q += hq[ch];
+                if (he && !hq[ch]) ++bad;
+            }
+        }
+    }
+    if (counts) { counts[0] = acc_exact; counts[1] = acc_q; }
+    return (long long) bad;
+}
+
 int emu_intersect(emu_ctx *c, const nori_ray *rays, nori_intersection *out, size_t n, int shadow) {
     const DevScene &sc = c->dev;
     unsigned nt = std::max(1u, std::thread::hardware_concurrency());

@@ -1,6 +1,8 @@
 """CPU checks of the DEVICE code's per-lane logic (tests/emu: the same rt_*.h
 headers the HIP kernels are built from, compiled with g++) against the oracle.
 The real kernels are checked by tests/test_gpu_parity.py on the GPU box."""
+import os
+
 import numpy as np
 import pytest
 
@@ -406,3 +408,63 @@ def test_treelet_sweeps_improve_the_ploc_tree():
     sah = st["n_node_tests"] / (st["n_closest_rays"] + st["n_shadow_rays"])
     assert nodes[1] < 0.95 * nodes[0] and nodes[2] <= nodes[1] * 1.01, nodes
     assert nodes[2] < 1.02 * sah, (nodes, sah)
+
+
+# ---------------------------------------------------------------- 32-B node records (rt_nodeq.h) and wf_extend's leaf step
+
+@pytest.mark.parametrize("scene", ["soup", "cornell", "far_and_flat"])
+def test_node_records_32b_never_reject_a_box_the_ray_crosses(scene):
+    """The 16-bit planes + per-axis slack of the 32-B record against the exact slab test of the stored boxes, every ray against
+    every node -- including rays that start far outside the grid, axis-parallel rays and rays lying in the planes of flat boxes."""
+    if scene == "soup":
+        sc = scenes.soup_scene(3000, 11)
+        rays = scenes.random_rays(300, seed=5)
+    elif scene == "cornell":
+        sc = scenes.cornell_box(16, 16, 1)
+        rays = scenes.random_rays(300, seed=6, extent=0.9)
+        rays["o"] += np.float32([0, 1, 0])
+        rays["d"][:40] = np.float32([0, -1, 0]); rays["d"][40:80] = np.float32([1, 0, 0]); rays["d"][80:120] = np.float32([0, 0, -1])
+        rays["o"][120:160, 1] = 0.0; rays["d"][120:160, 1] = 0.0      # in the floor's plane
+        rays["d"][120:160] /= np.linalg.norm(rays["d"][120:160], axis=1, keepdims=True)
+    else:
+        sc = scenes.soup_scene(500, 12)
+        rays = scenes.random_rays(300, seed=7, extent=4000.0, target_extent=1.0)      # origins thousands of scene sizes away
+        rays["maxt"][:100] = 1e30
+    e = Emu(sc)
+    assert e.accel_info()["node_records_32b"] == 1
+    res = e.nodeq_check(rays)
+    assert res is not None
+    bad, exact, rec = res
+    assert bad == 0, f"{bad} boxes rejected by the 32-B record that the ray crosses"
+    assert exact > 0 and rec >= exact
+    assert rec <= 1.25 * exact + 50, "the records accept far more boxes than the exact test: planes or slack too loose"
+
+
+def test_trees_with_unbounded_boxes_have_no_32b_records():
+    """Numerically collinear triangles hang under the root in boxes of +-3e38 (rt_types.h): such a tree keeps its 64-B nodes only."""
+    from nori_amd.scene import Mesh
+    sc = scenes.soup_scene(200, 13)
+    v = np.float32([[0, 0, 0], [1, 1, 1], [2, 2, 2.0000002], [0.5, 0.2, 0.1]])
+    sc.meshes = list(sc.meshes) + [Mesh(v, np.uint32([[0, 1, 2], [0, 1, 3]]))]
+    e, o = Emu(sc), Oracle(sc)
+    assert e.accel_info()["node_records_32b"] == 0
+    rays = scenes.random_rays(3000, seed=9)
+    _assert_its_equal(o.intersect(rays), e.intersect(rays))
+
+
+def test_leaf_step_with_selects_equals_the_branching_one(monkeypatch):
+    """wf_extend's form of the leaf step (hit update as selects, no mesh id kept) is what the harness walks by default; the
+    branching form (batch twins, megakernel) must find the same intersections."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, '.'); import numpy as np\n"
+            "from tests import scenes\nfrom tests.backends import Emu\n"
+            "sc = scenes.cornell_box(16, 16, 1); rays = scenes.random_rays(20000, seed=3, extent=0.9); rays['o'] += np.float32([0, 1, 0])\n"
+            "e = Emu(sc); a = e.intersect(rays); b = e.intersect(rays, True)\n"
+            "np.save(sys.argv[1], np.concatenate([a['t'], a['uv'].ravel(), a['tri'].astype(np.float32), a['mesh'].astype(np.float32), b['mesh'].astype(np.float32)]))\n")
+    outs = []
+    for sel in ("1", "0"):
+        path = os.path.join(os.environ.get("TMPDIR", "/tmp"), f"leaf_select_{sel}_{os.getpid()}.npy")
+        env = dict(os.environ, NORI_EMU_LEAF_SELECT=sel)
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        outs.append(np.load(path)); os.remove(path)
+    assert np.array_equal(outs[0], outs[1])

@@ -311,3 +311,56 @@ def test_lds_image_of_hot_records_changes_nothing(builder, layout):
     (a, sa), (b, sb) = frames
     assert np.array_equal(a, b)
     assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
+
+
+@pytest.mark.parametrize("builder,deep", [(0, False), (1, True), (3, True)])
+def test_hand_written_node_loop_equals_the_compilers(builder, deep):
+    """wf_extend's default node loop walks the tree's 32-B records (rt_nodeq.h: 16-bit planes on one grid, conservative) in a block
+    of gfx950 assembly; NORI_HIP_WF_NO_ASM_LOOP=1 walks the 64-B nodes with the compiler's loop.  The two visit different sets of
+    nodes, but the triangles a ray hits -- and with them every path, the ray counts and the frame -- must be the same bits.  Shallow
+    tree (stack in LDS), deep trees of the device builders (LDS stack + global column), with and without the LDS image, and with a
+    tiny image (most nodes from memory)."""
+    from nori_amd.render import Renderer
+    if deep:
+        sc = scenes.soup_scene(30000, seed=3, width=80, height=56, integrator="path_mis")
+        sc.sample_count = 4
+        from nori_amd.scene import Mesh
+        v, f = scenes.quad((-3, 3, -3), (3, 3, -3), (3, 3, 3), (-3, 3, 3))
+        sc.meshes.append(Mesh(v, f, bsdf=Bsdf("diffuse", (0, 0, 0)), radiance=(5.0, 5.0, 5.0), name="light"))
+    else:
+        sc = scenes.cornell_box(96, 64, 6, "path_mis", sphere_bsdfs=[Bsdf("microfacet", (0.2, 0.3, 0.1), 0.2), Bsdf("dielectric")])
+    frames = {}
+    for name, env in (("asm", {}), ("compiler", {"NORI_HIP_WF_NO_ASM_LOOP": 1}), ("asm, no image", {"NORI_HIP_NO_TOP_IMAGE": 1}),
+                      ("asm, 3 cached nodes", {"NORI_HIP_TOP_NODES": 3})):
+        def run():
+            r = Renderer(0); r.set_option("accel_layout", "bvh2"); r.upload(sc, builder=builder); r.set_option("engine", "wavefront")
+            info = r.accel_info()
+            out = r.render_host()
+            r.close()
+            return info, out
+        info, frames[name] = _with_env(env, run)
+        assert info["node_records_32b"] == 1 and info["node_children"] == 2
+        assert (info["max_depth"] + 1 > 16) == deep
+    ref, sr = frames["compiler"]
+    for name, (f, s) in frames.items():
+        assert s["n_closest_rays"] == sr["n_closest_rays"] and s["n_shadow_rays"] == sr["n_shadow_rays"], name
+        assert np.array_equal(f, ref), name
+
+
+def test_tree_with_unbounded_boxes_takes_the_64_byte_nodes():
+    """A numerically collinear triangle hangs under the root in an unbounded box: no 32-B records for that tree, and the frame
+    equals the megakernel's."""
+    from nori_amd.render import Renderer
+    from nori_amd.scene import Mesh
+    sc = scenes.cornell_box(64, 48, 4, "path_mis")
+    a, b = np.float32([0.1, 0.2, 0.3]), np.float32([0.7, 0.9, -0.2])
+    sc.meshes = list(sc.meshes) + [Mesh(np.float32([a, b, 0.5 * (a + b)]), np.uint32([[0, 1, 2]]))]
+    out = {}
+    for engine in ("megakernel", "wavefront"):
+        r = Renderer(0); r.upload(sc); r.set_option("engine", engine)
+        assert r.accel_info()["node_records_32b"] == 0
+        out[engine] = r.render_host()
+        r.close()
+    np.testing.assert_allclose(out["wavefront"][0], out["megakernel"][0], rtol=1e-4, atol=1e-5)      # (the engines add a pixel's samples in different orders)
+    for k in ("n_closest_rays", "n_shadow_rays"):
+        assert out["megakernel"][1][k] == out["wavefront"][1][k]
