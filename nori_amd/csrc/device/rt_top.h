@@ -18,12 +18,15 @@
  *   (<= 5 quads of padding)      so that the pair records start at a multiple of kPairQuads
  *   n_pairs x kPairQuads         leaf pair records as in memory
  *
- * How many nodes: what the LDS of a CU leaves to a workgroup of wf_extend next to its traversal stacks (wavefront.hip,
- * wf_top_capacity) -- 143 for BVH2 trees (workgroups of 1024 threads, two per CU), 126 for wide nodes.
+ * Two forms: with the 64-B node records (n_nodes x kTopStrideQuads, as drawn) for the kernels that walk those, and with the
+ * 32-B records of rt_nodeq.h (n_nodes x kTopStrideQuadsQ, links in the record's last two dwords) for wf_extend's hand-written
+ * node loop.  How many nodes: what the LDS of a CU leaves to a workgroup of wf_extend next to its traversal stacks
+ * (wavefront.hip, wf_top_capacity) -- BVH2 trees (workgroups of 1024 threads, two per CU): 359 records of 32 B (230 if the tree
+ * is deeper than the LDS stack) or 143 of 64 B; wide nodes (workgroups of 256, six per CU): 113.
  *
  * Which records: greedy by the surface area of the (child) box -- the probability that a ray crossing the parent's box
  * visits the child -- starting from the root: the inner node of largest area among the children of the nodes chosen so
- * far, kTopNodes times; then the leaves hanging off the chosen nodes, largest area first, while their pairs fit.
+ * far, as many times as nodes fit; then the leaves hanging off the chosen nodes, largest area first, while their pairs fit.
  */
 #pragma once
 #include "rt_types.h"

@@ -248,15 +248,19 @@ __device__ __forceinline__ bool first_vertex(const DevScene &sc, const WfBatch &
  *
  *     do { if (trav_at_inner(tv)) trav_inner_step_q(sc, stack, tv, tc, top); } while (lanes at inner nodes >= repeat);
  *
- * (rt_trace.h; BoundingBox::rayIntersect of include/nori/bbox.h:323-350 for both children).  What bounds wf_extend is the number
- * of vector-memory instructions a CU issues -- each occupies its address path for ~16 cycles however few lanes take part, and the
- * arithmetic and scalar pipes are half idle (measured by adding instructions of each kind to this loop: one more
- * global_load_dwordx4 per node step costs 6.3 ms per frame, a dwordx2 5.2, a dword 2.8, sixteen v_mov 1.7, sixteen s_mov 0.4, the
- * LDS reads over again 0.8) -- so the loop reads a node in TWO loads where the 64-B record takes four, and pays for it in arithmetic:
- * per plane one v_cvt_f32_u32 (SDWA: a 16-bit half of a dword) and one v_fma, per axis two v_bfi that pick the dword with the near
- * planes by the sign of the ray's direction.  Written as assembly because the child selection is four v_cndmask and two
- * exec-masked LDS operations (push where both children are hit, pop where none is) where the compiler builds three nested
- * regions with their save / restore / skip-branch triples, and because the loads must not be widened, merged or re-ordered.
+ * (rt_trace.h; BoundingBox::rayIntersect of include/nori/bbox.h:323-350 for both children).  With 64-B nodes wf_extend was bound by
+ * the number of vector-memory instructions a CU issues -- each occupies its address path for ~16 cycles however few lanes take
+ * part, while the arithmetic and scalar pipes were half idle.  Measured by adding instructions of each kind to the node step
+ * (-DNORI_EXP_SENS=n, ms per frame): one more global_load_dwordx4 +6.3, a dwordx2 +5.2, a dword +2.8 -- the same with four lanes
+ * active as with all of them --, sixteen v_mov +1.7, sixteen s_mov +0.4, the LDS reads over again +0.8.  So the loop reads a node
+ * in TWO loads where the 64-B record takes four, and pays for it in arithmetic: per plane one v_cvt_f32_u32 (SDWA: a 16-bit half of
+ * a dword) and one v_fma, per axis two v_bfi that pick the dword with the near planes by the sign of the ray's direction.  On this
+ * loop the same experiment reads: one more dwordx4 +0.8, sixteen v_mov +1.8, 64 idle cycles +1.2 -- the kernel now sits against the
+ * vector ALU (~80 % busy), which is where a ray tracer without ray-tracing hardware belongs.
+ * Written as assembly because the child selection is two v_cndmask on a scalar-side mask and two exec-masked LDS operations (push
+ * where both children are hit, pop where none is) where the compiler builds three nested regions with their save / restore /
+ * skip-branch triples, because the loads must not be widened, merged or re-ordered, and because the loop's exit test can then look
+ * ahead: it stays inside while the trip around the outer loop would run neither a triangle step nor a refill.
  * Same operations in the same order as trav_inner_step_q -- the CPU harness walks that one, against the linear scan.
  * gfx950 hazards honoured by hand: a VALU-written vcc is read by v_cndmask two instructions later at the earliest.
  * Records are addressed as base + (node << 5) in 32 bits: the caller takes this path for trees below 2^25 nodes only. */
@@ -264,6 +268,9 @@ __device__ __forceinline__ bool first_vertex(const DevScene &sc, const WfBatch &
 #define NORI_ASM_NODE_LOOP 1
 #endif
 #define NORI_SDWA(dst, src, half) "v_cvt_f32_u32_sdwa " dst ", " src " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_" half "\n\t"
+/* -DNORI_EXP_SENS=n (experiments, tools/build_variant.sh + tools/ab.sh): what the node step is sensitive to -- n = 1: one more
+   global_load_dwordx4, 2: the LDS reads over again, 3: sixteen v_mov, 4: sixteen s_mov, 5: 64 idle cycles (see above) */
+#define NORI_X16(s) s s s s s s s s s s s s s s s s
 #if NORI_EXP_SENS == 1
 #define NORI_EXP_Q_GLOBAL "\n\tglobal_load_dwordx4 v[36:39], v40, %[nodes] offset:16\n"
 #else
@@ -275,9 +282,9 @@ __device__ __forceinline__ bool first_vertex(const DevScene &sc, const WfBatch &
 #define NORI_EXP_Q_LDS
 #endif
 #if NORI_EXP_SENS == 3
-#define NORI_EXP_Q_ALU "v_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\tv_mov_b32 v41, v40\n\t"
+#define NORI_EXP_Q_ALU NORI_X16("v_mov_b32 v41, v40\n\t")
 #elif NORI_EXP_SENS == 4
-#define NORI_EXP_Q_ALU "s_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\ts_mov_b64 %[u], %[t]\n\t"
+#define NORI_EXP_Q_ALU NORI_X16("s_mov_b64 %[u], %[t]\n\t")
 #elif NORI_EXP_SENS == 5
 #define NORI_EXP_Q_ALU "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
 #else
@@ -888,8 +895,11 @@ std::string ensure_pool(Pool &pool, size_t records) {
 }
 
 /* threads per wf_extend workgroup and workgroups per CU the LDS image is sized for, per node layout (see wf_extend) */
-constexpr int kExtendBlockBvh2 = 1024, kExtendBlockWide = kB;
-constexpr int kExtendWgsBvh2 = 2, kExtendWgsWide = 6;
+#ifndef NORI_EXTEND_BLOCK
+#define NORI_EXTEND_BLOCK 1024
+#endif
+constexpr int kExtendBlockBvh2 = NORI_EXTEND_BLOCK, kExtendBlockWide = kB;
+constexpr int kExtendWgsBvh2 = 2048 / NORI_EXTEND_BLOCK, kExtendWgsWide = 6;
 constexpr size_t kLdsPerCu = 160 * 1024;
 template <int STACK, bool SPILL, bool COUNT, bool FIRST>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, const WfBatch &bt, hipStream_t s) {

@@ -76,12 +76,12 @@ static void bind(emu_ctx *c) {
         /* as many node records as the device keeps (wavefront.hip, wf_top_capacity) unless told otherwise */
         const char *tn = std::getenv("NORI_EMU_TOP_NODES");
         c->top_image.assign(kTopImageMaxQuads, f4());
-        top_image_build(d.nodes, d.nodes, top_layout(false), d.tris, d.root, d.wide != 0u, d.n_triangles, tn ? atoi(tn) : (d.wide ? 126 : 143), c->top_image.data());
+        top_image_build(d.nodes, d.nodes, top_layout(false), d.tris, d.root, d.wide != 0u, d.n_triangles, tn ? atoi(tn) : (d.wide ? 113 : 143), c->top_image.data());
         d.top_image = c->top_image.data();
         d.top_image_quads = f2u(c->top_image[0].w);
         if (d.nodes_q) {
             c->top_image_q.assign(kTopImageMaxQuads, f4());
-            top_image_build(d.nodes, d.nodes_q, top_layout(true), d.tris, d.root, false, d.n_triangles, tn ? atoi(tn) : 358, c->top_image_q.data());
+            top_image_build(d.nodes, d.nodes_q, top_layout(true), d.tris, d.root, false, d.n_triangles, tn ? atoi(tn) : 359, c->top_image_q.data());
             d.top_image_q = c->top_image_q.data();
             d.top_image_q_quads = f2u(c->top_image_q[0].w);
         }

@@ -1,8 +1,9 @@
 """Static VALU instruction mix of the render kernels -> profiles/<tag>_valu_mix.json.
 
 SQ_ACTIVE_INST_VALU counts ONE unit per VALU instruction (two per transcendental), not the cycles the instruction keeps
-its SIMD busy (profiles/r3_valu_counter_calibration.txt: ~2.4 cycles for v_mov / v_add / v_mul / v_fma / v_and, ~4.2 for
-v_min / v_max / v_cmp / v_cndmask / v_mul_lo / v_pk_*, ~8.2 for v_rcp / v_sqrt).  How busy the VALU is therefore needs
+its SIMD busy (profiles/r3_valu_counter_calibration.txt: 2.4 cycles for v_fma, 2.5 - 3.2 for v_mov / v_add / v_mul / v_and, ~4.3 for
+v_min / v_max / v_cmp / v_cndmask / v_mul_lo / v_pk_* / v_cvt_* / v_bfi / v_perm / shifts / three-operand integer ops, ~8.2 for
+v_rcp / v_sqrt; the fast class is priced at its lower end, 2.4, so the busy fraction is a lower bound).  How busy the VALU is therefore needs
 the kernel's instruction mix; this script takes it from the compiler's own assembly of the kernel (all instructions of
 the kernel weighted equally -- the hot loops are most of the text) and tools/summarize_profile.py multiplies:
     valu_busy_frac = SQ_INSTS_VALU x cycles_per_instr / (SIMDs x elapsed cycles)          (<= 1 by construction of the table)
@@ -12,7 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 FAST, SLOW, TRANS = 2.4, 4.2, 8.2
-SLOW_RE = re.compile(r"^v_(min|max|med3|cmp|cmpx|cndmask|mul_lo|mul_hi|pk_|mad_u64|lshl_add_u64|lshlrev_b64|lshrrev_b64|ashrrev_i64|add_f64|mul_f64|fma_f64)")
+SLOW_RE = re.compile(r"^v_(min|max|med3|cmp|cmpx|cndmask|mul_lo|mul_hi|pk_|mad_u64|lshl_add_u64|lshlrev_b64|lshrrev_b64|ashrrev_i64|add_f64|mul_f64|fma_f64|"
+                     r"cvt_|perm_|bfi_|and_or_|lshl_add_|lshl_or_|bfe_|lshlrev_|lshrrev_|ashrrev_|sad_|fma_mix|mad_mix|mad_u32|mad_i32|add3_|xad_|or3_|alignbit)")
 TRANS_RE = re.compile(r"^v_(rcp|sqrt|rsq|exp|log|sin|cos)")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 out = {}
