@@ -300,8 +300,9 @@ int nori_hip_debug_excursions(nori_hip_ctx *ctx, unsigned long long out[4], int 
  *                     else megakernel) | "megakernel" | "wavefront"
  *   "wavefront_paths" paths in flight per wavefront batch (default 2^28, ~180 B of HBM each)
  *   "accel_layout"    node layout of the NEXT nori_hip_build_accel: "bvh2" (64-B node = two full-precision child
- *                     boxes) | "bvh4q" (64-B node = four child boxes quantised to 8 bits: half the node fetches,
- *                     for trees that do not fit the caches) | "auto" (default: bvh4q from 2^18 triangles)
+ *                     boxes; the wavefront engine walks a second, 32-B form of them, see nori_accel_info) | "bvh4q"
+ *                     (64-B node = four child boxes quantised to 8 bits: half the node fetches, for trees that do
+ *                     not fit the caches) | "auto" (default: bvh4q from 2^20 triangles)
  *   "film_order"      "fast" (default: the film adds a pixel's samples round by round in LDS tiles) | "reference" (the
  *                     samples are added in the order of renderBlock / ImageBlock::put / BlockGenerator,
  *                     src/main.cpp:33-53, src/block.cpp:62-152: whole frames only, slower -- the frame is then

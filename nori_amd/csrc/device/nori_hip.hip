@@ -408,7 +408,7 @@ struct nori_hip_ctx {
     int stack_depth = 32;
     uint64_t lbvh_bytes = 0;
     int engine = -1;                /* -1 auto, 0 megakernel, 1 wavefront */
-    int accel_layout = -1;          /* -1 auto (wide from 2^18 triangles), 0 bvh2, 1 bvh4q (wide nodes) */
+    int accel_layout = -1;          /* -1 auto (wide from 2^20 triangles), 0 bvh2, 1 bvh4q (wide nodes) */
     bool film_reference = false;    /* film_order = reference: samples added in the reference's own order (film.h) */
     size_t wavefront_paths = (size_t) 1 << 28;     /* 240 B of state each (two copies) + film: ~80 GB of the 288 GB */
     /* render-time resources of THIS context (never shared, freed in nori_hip_destroy): the wavefront
@@ -569,7 +569,9 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     ctx->have_accel = false;
     int layout = ctx->accel_layout;
     if (const char *e = getenv("NORI_HIP_ACCEL_LAYOUT")) layout = std::string(e) == "bvh4q" ? 1 : (std::string(e) == "bvh2" ? 0 : -1);
-    const bool want_wide = layout == 1 || (layout < 0 && ctx->dev.n_triangles >= (1u << 18));      /* measured: 22 k triangles BVH2 +3 %, 328 k wide +10 %, 10 M wide +50 % */
+    /* measured (wf_extend, BVH2 walked as 32-B records by the hand-written loop against wide nodes): 328 k triangles 9.7 against
+       11.7 ms, 10 M triangles 32.2 against 28.9 ms */
+    const bool want_wide = layout == 1 || (layout < 0 && ctx->dev.n_triangles >= (1u << 20));
     if (builder != NORI_ACCEL_HOST_SAH && ctx->dev.n_triangles > 0) {
         LbvhDeviceResult res;
         uint32_t ploc_radius = builder == NORI_ACCEL_GPU_PLOC ? 8u : 0u;      /* 8, 16, 32 give the same trees within 1 % (tools/builder_probe.py); 8 builds fastest */
