@@ -1,6 +1,12 @@
 """Which nodes and which leaf pair records do the rays of a workload visit?  CPU harness (emulated device code built with
 -DNORI_TRAV_HISTOGRAM, see rt_trace.h); prints how much of the traffic the hottest records carry -- the sizing argument
-for what wf_extend keeps in LDS.   python tools/trav_histogram.py <libnori_emu_hist.so> [workload] [width] [spp]"""
+for what wf_extend keeps in LDS.
+    g++ -O2 -std=c++17 -fPIC -ffp-contract=off -pthread -shared -DNORI_TRAV_HISTOGRAM=1 -o /tmp/libnori_emu_hist.so \
+        tests/emu/emu.cpp nori_amd/csrc/device/scene_prep.cpp tools/trav_hist_impl.cpp
+    python tools/trav_histogram.py /tmp/libnori_emu_hist.so [workload] [width] [spp]
+Visits of records that are cached in the harness's LDS image (links with kTopBit) are not counted: with NORI_EMU_TOP_IMAGE=0 the
+histogram is of all visits, with NORI_EMU_TOP_NODES=n of what an image of n nodes leaves to memory; NORI_EMU_NODEQ=0 walks the 64-B
+nodes instead of the 32-B records."""
 import ctypes as C, os, sys
 sys.path.insert(0, ".")
 import numpy as np
