@@ -250,7 +250,10 @@ def main():
         if t_ms <= 0.0:
             t_ms = k_ms
         rays_c = counted["n_closest_rays"] + counted["n_shadow_rays"]
-        trav_bytes = counted["n_node_tests"] * info["node_bytes"] + counted["n_tri_tests"] * info["tri_bytes"]
+        # (the wavefront engine walks a BVH2 tree that has 32-B node records with its hand-written loop, whatever the tree's depth)
+        node_loop_32b = engine == "wavefront" and info.get("node_children", 2) == 2 and info.get("node_records_32b", 0) == 1
+        node_record_bytes = 32 if node_loop_32b else int(info["node_bytes"])
+        trav_bytes = counted["n_node_tests"] * node_record_bytes + counted["n_tri_tests"] * info["tri_bytes"]
         if engine == "wavefront":
             dom_name = "wf_extend (all launches of one render pass)"
             # per closest-hit ray 36 B read (flags, origin, direction) + 16 B hit written, +16 B per shadow ray,
@@ -291,18 +294,16 @@ def main():
             roof.update({"achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fr_hbm, 5),
                          "algorithmic_bytes": int(trav_bytes + rec_bytes),
                          "note": "algorithmic bytes per SURVEY 8(d): N_node x %d + N_tri x %d + ray / hit records; the BVH (%.0f MB) "
-                                 "exceeds L2 + Infinity Cache" % (info["node_bytes"], info["tri_bytes"], info["total_bytes"] / 1e6)})
+                                 "exceeds L2 + Infinity Cache" % (node_record_bytes, info["tri_bytes"], info["total_bytes"] / 1e6)})
         roof["valu_frac"], roof["hbm_algorithmic_frac"] = round(fr_valu, 5), round(fr_hbm, 5)
         # the three ways to price the same traversal work (all <= 1): `valu_frac` = textbook operation count (52 / 54 / 9) against
         # one lane-operation per lane per clock; `flop_frac` = the same count against the f32 FLOP peak (packed FMA: 4 flops
         # per lane per clock -- reachable only by v_pk_fma); `issued_frac` = the VALU instructions the shipped code issues
         # per unit (30 / 37.5 / 9; 40 per node test in the loop over 32-B records), as lane-instructions, against the issue rate
         # of the fastest instructions
-        # (the wavefront engine walks a BVH2 tree that has 32-B node records and fits the LDS stack with its hand-written loop)
-        node_loop_32b = engine == "wavefront" and not wide and info.get("node_records_32b", 0) == 1 and info["max_depth"] + 1 <= 16
         issued_node = ISSUED_NODE_WIDE if wide else ISSUED_NODE_32B if node_loop_32b else ISSUED_NODE
         issued = counted["n_node_tests"] * issued_node + counted["n_tri_tests"] * ISSUED_TRI + rays_c * ISSUED_RAY
-        roof["node_record_bytes"] = 32 if node_loop_32b else int(info["node_bytes"])
+        roof["node_record_bytes"] = node_record_bytes
         roof["flop_frac"] = round(ops / (t_ms * 1e-3) / 1e12 / FLOP_PEAK_TFLOPS, 5)
         roof["issued_valu_instr"] = int(issued)
         roof["issued_frac"] = round(issued / (t_ms * 1e-3) / VALU_ISSUE_SLOTS, 5)
