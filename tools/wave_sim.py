@@ -11,7 +11,7 @@ nl = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 sc = workloads.load("pa4-cbox-path_mis", width=w, height=w, spp=spp).scene
 e = Emu(sc); lib = emu_lib()
 lib.emu_wave_sim.restype = C.c_int
-COST = dict(node=47, leaf=85, refill=130, trip=35, pend=60)      # VALU instructions per wave-level event (ISA of the shipped kernel)
+COST = dict(node=51, leaf=100, refill=130, trip=50, pend=60)      # VALU instructions per wave-level event (ISA of the shipped kernel: the hand-written node loop on 32-B records; a trip includes the 24 of the ray's plane coefficients)
 def run(name, refill=32, leaf=16, inner=24, postpone=0, chunk=1024, sort=0, pend=0):
     pol = (C.c_int * 7)(refill, leaf, inner, postpone, chunk, sort, pend)
     out = np.zeros((nl, 14), np.uint64)
