@@ -104,6 +104,7 @@ def emu_lib():
             "emu_border_size": (C.c_int, [_P]),
             "emu_intersect": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
             "emu_nodeq_check": (C.c_longlong, [_P, _P, C.c_size_t, _P]),
+            "emu_node_records": (C.c_longlong, [_P, _P, _P, _P, C.c_size_t]),
             "emu_packed_vs_scalar": (C.c_size_t, [C.c_size_t, C.c_uint64]),
             "emu_libm_eval": (C.c_int, [C.c_int, _P, C.c_size_t, _P]),
             "emu_sample_rays": (C.c_int, [_P, _P, C.c_size_t, _P]),
@@ -323,6 +324,14 @@ class Emu(_CpuBackend):
         info = capi.AccelInfo()
         self.lib.emu_accel_info(self._h, C.byref(info))
         return info.as_dict()
+
+    def node_records(self):
+        """(nodes as [n, 16] float32 in the 64-B layout, as [n, 8] uint32 in the 32-B layout, grid mn[3], grid scale[3]); None if the
+        tree has no 32-B records"""
+        cap = max(1, self.accel_info()["n_nodes"])
+        n64 = np.zeros((cap, 16), np.float32); n32 = np.zeros((cap, 8), np.uint32); grid = np.zeros(6, np.float32)
+        n = self.lib.emu_node_records(self._h, ptr(n64), ptr(n32), ptr(grid), cap)
+        return None if n < 0 else (n64[:n], n32[:n], grid[:3].copy(), grid[3:].copy())
 
     def nodeq_check(self, rays):
         """rt_nodeq.h: (ray, child box) pairs the exact slab test accepts and the 32-B record rejects (must be 0), and how many

@@ -240,6 +240,20 @@ int emu_accel_info(const emu_ctx *c, nori_accel_info *in) {
 }
 int emu_border_size(const emu_ctx *c) { return c->host.filter.border; }
 
+/* raw records for an independent look at the 32-B form (tests/test_device_logic_cpu.py): copies up to `cap` nodes as 16 floats
+   (64-B form) and 8 dwords (32-B form) each, the grid as (mn[3], scale[3]); returns the number of nodes, -1 without 32-B records */
+long long emu_node_records(emu_ctx *c, float *nodes64, uint32_t *nodes32, float *grid, size_t cap) {
+    const DevScene &sc = c->dev;
+    if (sc.nodes_q == nullptr) return -1;
+    const size_t n = c->nodes_q.size() / kNodeqQuads;
+    for (size_t i = 0; i < n && i < cap; ++i) {
+        std::memcpy(nodes64 + 16 * i, sc.nodes + i * kNodeQuads, 64);
+        std::memcpy(nodes32 + 8 * i, sc.nodes_q + i * kNodeqQuads, 32);
+    }
+    for (int a = 0; a < 3; ++a) { grid[a] = sc.grid.mn[a]; grid[3 + a] = sc.grid.scale[a]; }
+    return (long long) n;
+}
+
 /* rt_nodeq.h: every ray against every node of the tree, the 32-B record's verdict per child against the exact one.
    Exact = the slab test of the stored 64-B box [c - h, c + h] in binary64 with the ray's own (binary32) reciprocal
    direction, clipped to [0, maxt] (trav_inner_step's rule).  Returns the number of (ray, child) pairs the exact test

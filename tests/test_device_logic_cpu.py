@@ -468,3 +468,29 @@ def test_leaf_step_with_selects_equals_the_branching_one(monkeypatch):
         subprocess.run([sys.executable, "-c", code, path], check=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         outs.append(np.load(path)); os.remove(path)
     assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("scene", ["soup", "cornell"])
+def test_node_records_32b_enclose_the_64b_boxes_read_independently(scene):
+    """The record layout decoded here in numpy, from its description alone (rt_nodeq.h: dwords 0 / 1 = x low / high planes, left child
+    in bits 0-15, right child in bits 16-31; 2 / 3 = y; 4 / 5 = z; 6 / 7 = the links; plane = mn + q scale) against the 64-B node
+    (rt_types.h: q0 = left centre x y, right centre x y; q1 = centres z, half extents z; q2 = half extents x y; q3 = links): every
+    box of the 32-B form contains the 64-B box, is no more than a grid step (plus float rounding) wider per side, and the links agree."""
+    sc = scenes.soup_scene(4000, 21) if scene == "soup" else scenes.cornell_box(16, 16, 1)
+    rec = Emu(sc).node_records()
+    assert rec is not None
+    n64, n32, mn, scale = rec
+    n64 = n64.astype(np.float64); mn = mn.astype(np.float64); scale = scale.astype(np.float64)
+    cx = np.stack([n64[:, 0], n64[:, 2]], 1); cy = np.stack([n64[:, 1], n64[:, 3]], 1); cz = n64[:, 4:6]
+    hx = np.stack([n64[:, 8], n64[:, 10]], 1); hy = np.stack([n64[:, 9], n64[:, 11]], 1); hz = n64[:, 6:8]
+    assert np.array_equal(n32[:, 6:8], rec[0][:, 12:14].view(np.uint32))                   # links
+    for a, (c, h) in enumerate(((cx, hx), (cy, hy), (cz, hz))):
+        lo_q = np.stack([n32[:, 2 * a] & 0xffff, n32[:, 2 * a] >> 16], 1).astype(np.float64)
+        hi_q = np.stack([n32[:, 2 * a + 1] & 0xffff, n32[:, 2 * a + 1] >> 16], 1).astype(np.float64)
+        p_lo, p_hi = mn[a] + lo_q * scale[a], mn[a] + hi_q * scale[a]
+        box_lo, box_hi = c - h, c + h
+        inside_grid_lo, inside_grid_hi = box_lo >= mn[a], box_hi <= mn[a] + 65535.0 * scale[a]
+        assert (p_lo[inside_grid_lo] <= box_lo[inside_grid_lo]).all() and (p_hi[inside_grid_hi] >= box_hi[inside_grid_hi]).all()
+        slack = scale[a] * (1.0 + 1e-6) + 1e-6 * np.abs(c)
+        assert (box_lo - p_lo <= slack).all() and (p_hi - box_hi <= slack).all(), "planes more than a grid step off the box"
+        assert (lo_q <= hi_q).all()
