@@ -70,6 +70,30 @@ static void bind(emu_ctx *c) {
         bool ok = true;
         for (size_t i = 0; i < n_nodes; ++i) ok &= nodeq_from_node(d.nodes + i * kNodeQuads, d.grid, c->nodes_q.data() + i * kNodeqQuads);
         if (ok) d.nodes_q = c->nodes_q.data();
+        /* experiment: what the planes would be worth as fp16 -- every plane moved outward to the next value
+           binary16 represents in coordinates normalised to [-1, 1] around the grid's centre (11 bits of mantissa: finest at the
+           centre, 2^-11 of the half extent at the faces); NORI_EMU_NODEQ_FP16=1, tools/trav_histogram.py counts the tests */
+        if (ok && std::getenv("NORI_EMU_NODEQ_FP16") && atoi(std::getenv("NORI_EMU_NODEQ_FP16")) != 0) {
+            auto snap = [](uint32_t q, bool up) {
+                const double u = (double) q / 65535.0 * 2.0 - 1.0, a = fabs(u);
+                if (a == 0.0) return q;
+                int e; (void) frexp(a, &e);                               /* a = m 2^e, m in [0.5, 1) */
+                if (e < -13) e = -13;                                      /* binary16 denormal range: fixed spacing 2^-24 */
+                const double ulp = ldexp(1.0, e - 11);
+                const bool away = (u > 0.0) == up;                         /* away from zero? */
+                const double r = away ? ceil(a / ulp) * ulp : floor(a / ulp) * ulp;
+                const double v = ((u > 0.0 ? r : -r) + 1.0) * 0.5 * 65535.0;
+                const double qq = up ? ceil(v - 1e-9) : floor(v + 1e-9);
+                return (uint32_t) (qq < 0.0 ? 0.0 : qq > 65535.0 ? 65535.0 : qq);
+            };
+            for (size_t i = 0; i < n_nodes; ++i) {
+                uint32_t *w = reinterpret_cast<uint32_t *>(c->nodes_q.data() + i * kNodeqQuads);
+                for (int a = 0; a < 3; ++a) {
+                    w[2 * a] = snap(w[2 * a] & 0xffffu, false) | (snap(w[2 * a] >> 16, false) << 16);
+                    w[2 * a + 1] = snap(w[2 * a + 1] & 0xffffu, true) | (snap(w[2 * a + 1] >> 16, true) << 16);
+                }
+            }
+        }
     }
     const char *ti = std::getenv("NORI_EMU_TOP_IMAGE");
     if (d.n_triangles > 0 && !(ti && atoi(ti) == 0)) {
