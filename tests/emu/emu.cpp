@@ -208,7 +208,7 @@ int emu_wave_sim(emu_ctx *c, uint32_t spp, uint32_t max_levels, const int *polic
                 RayIn cam; camera_sample_ray(sc.camera, mk2((float) px + j.x, (float) py + j.y), cam);
                 sim_capture_path<6>(sc, cam, rng.state, rng.inc, stack, levels, max_levels);
             }
-    SimPolicy P; P.refill_threshold = policy[0]; P.leaf_threshold = policy[1]; P.inner_repeat = policy[2]; P.postpone = policy[3]; P.chunk = policy[4]; P.sort_octant = policy[5]; P.pend_threshold = policy[6];
+    SimPolicy P; P.refill_threshold = policy[0]; P.leaf_threshold = policy[1]; P.inner_repeat = policy[2]; P.postpone = policy[3]; P.chunk = policy[4]; P.sort_octant = policy[5]; P.pend_threshold = policy[6]; P.pretest = policy[7];
     for (size_t k = 0; k < levels.size() && k < max_levels; ++k) {
         std::vector<SimEntry> &e = levels[k];
         if (P.sort_octant)
@@ -216,7 +216,7 @@ int emu_wave_sim(emu_ctx *c, uint32_t spp, uint32_t max_levels, const int *polic
                 std::stable_sort(e.begin() + b, e.begin() + std::min(e.size(), b + 256), [](const SimEntry &x, const SimEntry &y) { return sim_octant(x) < sim_octant(y); });
         SimCounts C; std::memset(&C, 0, sizeof(C));
         for (size_t b = 0; b < e.size(); b += (size_t) P.chunk) sim_wave(sc, e.data() + b, std::min((size_t) P.chunk, e.size() - b), P, C);
-        std::memcpy(counts + k * 14, &C, sizeof(C));
+        std::memcpy(counts + k * 16, &C, sizeof(C));
     }
     return (int) levels.size();
 }
@@ -226,7 +226,7 @@ int emu_create(const nori_scene_desc *scene, emu_ctx **out) {
     std::string err = prepare_scene(*scene, c->host);
     /* node layout as the library picks it (nori_hip_build_accel): NORI_HIP_ACCEL_LAYOUT=bvh4q forces wide nodes */
     const char *lay = std::getenv("NORI_HIP_ACCEL_LAYOUT");
-    const bool wide = lay ? std::string(lay) == "bvh4q" : c->host.tri_mesh.size() >= ((size_t) 1 << 18);
+    const bool wide = lay ? std::string(lay) == "bvh4q" : c->host.tri_mesh.size() >= ((size_t) 1 << 20);
     /* NORI_EMU_BUILDER=lbvh | ploc: the DEVICE builders' steps run on the CPU (emu_builder.h) instead of the host SAH builder */
     const char *bld = std::getenv("NORI_EMU_BUILDER");
     const std::string builder = bld ? bld : "sah";

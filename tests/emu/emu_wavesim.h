@@ -22,10 +22,13 @@ struct SimPolicy {
     int chunk;               /* paths per wave */
     int sort_octant;         /* 1: within blocks of 256 paths, order by the direction octant of the first ray */
     int pend_threshold;      /* > 0: lanes whose shadow ray is answered start their continuation ray as soon as this many wait (no new paths) */
+    int pretest;             /* 1: every ray tests the image's cached leaf pairs (the walls) when it starts -- dense, at the lanes of the refill --
+                                and the walk skips those leaves (experiment: DESIGN.md section 9) */
 };
 
 struct SimCounts {
     uint64_t rays, trips, node_steps, node_lanes, leaf_steps, leaf_lanes, refills, refill_lanes, lane_node_steps, lane_leaf_steps, node_idle_lanes, node_leaf_lanes, pend_restarts, pend_lanes;
+    uint64_t pre_steps, pre_lanes;
 };
 
 struct SimLeafStack {        /* the leaf step's pop when it works on a parked leaf: nothing to pop, the leaf is done */
@@ -49,10 +52,25 @@ static inline bool sim_wants_leaf(const SimLane &l, bool postpone) {
 }
 static inline bool sim_active(const SimLane &l) { return trav_active(l.tv) || l.leaf2 != kTravDone; }
 
-static void sim_begin(const DevScene &sc, SimLane &l, const RayIn &ray, bool any, TopNodesP top) {
+static inline bool sim_cached_leaf(const SimLane &l) { return trav_at_leaf(l.tv) && ((~(uint32_t) l.tv.node) & (uint32_t) kTopBit) != 0u; }
+/* pretest: a lane never works on a cached leaf -- it was tested when the ray started */
+static inline void sim_skip_cached(SimLane &l, bool pretest) { if (pretest) while (sim_cached_leaf(l)) trav_pop(l.stack, l.tv); }
+
+static void sim_begin(const DevScene &sc, SimLane &l, const RayIn &ray, bool any, TopNodesP top, bool pretest = false) {
     trav_begin<kLayoutAny>(sc, ray, any, l.stack, l.tv);
-    if (top != nullptr && trav_active(l.tv)) l.tv.node = (int) f2u(top[0].x);
     l.leaf2 = kTravDone;
+    if (top == nullptr || !trav_active(l.tv)) return;
+    if (pretest) {
+        const uint32_t n_pairs = f2u(top[0].z), first = f2u(top[0].w) / kPairQuads - n_pairs;      /* the pair records close the image */
+        TraversalCounters tc; tc.nodes = tc.tris = 0;
+        for (uint32_t p = 0; p < n_pairs && trav_active(l.tv); ++p) {
+            l.tv.node = (int) ~(((kTopPairBase + first + p) << 3) | 0u);
+            SimLeafStack ls;
+            trav_leaf_step<false>(sc, ls, l.tv, tc, top);
+        }
+        if (l.tv.node == kTravDone) return;      /* an any-hit ray stopped by a wall */
+    }
+    l.tv.node = (int) f2u(top[0].x);
 }
 
 static void sim_wave(const DevScene &sc, const SimEntry *e, size_t n, const SimPolicy &P, SimCounts &C) {
@@ -67,13 +85,14 @@ static void sim_wave(const DevScene &sc, const SimEntry *e, size_t n, const SimP
         const bool exhausted = pos >= n;
         if ((!exhausted || anyPend) && (nIdle >= P.refill_threshold || nIdle == 64)) {
             C.refills++; C.refill_lanes += (uint64_t) nIdle;
+            if (P.pretest && top != nullptr) { C.pre_steps += f2u(top[0].z); C.pre_lanes += (uint64_t) nIdle * f2u(top[0].z); }
             for (auto &l : L) {
                 if (sim_active(l)) continue;
-                if (l.pendA) { sim_begin(sc, l, l.nextA, false, top); l.pendA = false; C.rays++; continue; }
+                if (l.pendA) { sim_begin(sc, l, l.nextA, false, top, P.pretest != 0); l.pendA = false; C.rays++; continue; }
                 if (pos >= n) continue;
                 const SimEntry &en = e[pos++];
-                if (en.hasB) { sim_begin(sc, l, en.B, true, top); C.rays++; l.pendA = en.hasA; l.nextA = en.A; }
-                else if (en.hasA) { sim_begin(sc, l, en.A, false, top); C.rays++; }
+                if (en.hasB) { sim_begin(sc, l, en.B, true, top, P.pretest != 0); C.rays++; l.pendA = en.hasA; l.nextA = en.A; }
+                else if (en.hasA) { sim_begin(sc, l, en.A, false, top, P.pretest != 0); C.rays++; }
             }
         }
         else if (P.pend_threshold > 0) {
@@ -81,7 +100,7 @@ static void sim_wave(const DevScene &sc, const SimEntry *e, size_t n, const SimP
             for (auto &l : L) if (!sim_active(l) && l.pendA) ++np;
             if (np >= P.pend_threshold) {
                 C.pend_restarts++; C.pend_lanes += (uint64_t) np;
-                for (auto &l : L) if (!sim_active(l) && l.pendA) { sim_begin(sc, l, l.nextA, false, top); l.pendA = false; C.rays++; }
+                for (auto &l : L) if (!sim_active(l) && l.pendA) { sim_begin(sc, l, l.nextA, false, top, P.pretest != 0); l.pendA = false; C.rays++; }
             }
         }
         bool anyActive = false;
@@ -104,6 +123,7 @@ static void sim_wave(const DevScene &sc, const SimEntry *e, size_t n, const SimP
                 if (!trav_at_inner(l.tv)) continue;
                 if (sc.wide) trav_wide_step<false>(sc, l.stack, l.tv, tc, top);
                 else trav_inner_step<false>(sc, l.stack, l.tv, tc, top);
+                sim_skip_cached(l, P.pretest != 0);
                 if (P.postpone && trav_at_leaf(l.tv) && l.leaf2 == kTravDone) { l.leaf2 = l.tv.node; trav_pop(l.stack, l.tv); }
             }
             int left = 0;
@@ -130,6 +150,7 @@ static void sim_wave(const DevScene &sc, const SimEntry *e, size_t n, const SimP
                     }
                 } else {
                     trav_leaf_step<false>(sc, l.stack, l.tv, tc, top);
+                    sim_skip_cached(l, P.pretest != 0);
                 }
             }
         }
