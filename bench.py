@@ -206,11 +206,13 @@ def main():
         if not args.emulate:
             torch.cuda.synchronize(dev)
 
-    def step(want_stats=False, count=False, time_kernels=False):
+    merge_ms = []      # per step: this rank's time in the exchange (its wait for the slowest rank included)
+
+    def step(want_stats=False, count=False, time_kernels=False, spp_count=None):
         # this rank's share of the frame, then ONE exchange: ImageBlock::put(ImageBlock&) across GPUs
-        return ndist.render_distributed(r.render_into, frame, split, spp, rank, world, merge=args.merge, tiles_x=tiles_x,
-                                        border=r.border, stream=stream, want_stats=want_stats, count_traversal=count,
-                                        time_kernels=time_kernels)
+        return ndist.render_distributed(r.render_into, frame, split, spp if spp_count is None else spp_count, rank, world, merge=args.merge,
+                                        tiles_x=tiles_x, border=r.border, merge_ms=merge_ms, stream=stream, want_stats=want_stats,
+                                        count_traversal=count, time_kernels=time_kernels)
 
     # one instrumented pass: traversal counters for the roofline (untimed)
     counted = step(want_stats=True, count=True)
@@ -221,6 +223,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    del merge_ms[:]
     t0 = time.perf_counter()
     kernel_ms, trace_ms, shade_ms, film_ms, trace_launches = [], [], [], [], 0
     last = None
@@ -234,10 +237,17 @@ def main():
 
     rays_local = float(last["n_closest_rays"] + last["n_shadow_rays"])
     t = torch.tensor([dt, rays_local], dtype=torch.float64, device=dev)
+    # what every rank saw, for reading a scaling record without a re-run: its own wall clock per step, the HIP-event time of its
+    # share's kernels, and its time in the merge (which contains its wait for the slowest rank)
+    mine = torch.tensor([dt / args.steps * 1e3, float(np.mean(kernel_ms)), float(np.mean(merge_ms)) if merge_ms else 0.0, rays_local],
+                        dtype=torch.float64, device=dev)
+    per_rank = [mine]
     if world > 1:
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, rays_total = float(tmax[0]), float(tsum[1])
+        per_rank = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(per_rank, mine)
     else:
         rays_total = rays_local
 
@@ -331,10 +341,36 @@ def main():
                      "hbm_measured_bytes": (ctr[1].get("pass_hbm_bytes") if ctr else None)},
             "accel": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in info.items()},
         }
-        if not args.no_cpu_baseline and world == 1:
-            cpu, parity = cpu_baseline_and_parity(wl, r, frame, args)
+        if world > 1 or merge_ms:
+            out["ranks"] = [{"rank": k, "ms_per_step": round(float(v[0]), 3), "kernel_ms": round(float(v[1]), 3), "merge_ms": round(float(v[2]), 3),
+                             "rays_per_step": int(v[3])} for k, v in enumerate(per_rank)]
+    # the CPU leg runs on rank 0 (the other ranks wait); the parity render that follows is the distributed one -- every rank its
+    # share of the sample the CPU rendered, merged on rank 0 -- so the verdict is about the frame a multi-GPU run produces
+    if not args.no_cpu_baseline:
+        sample = torch.zeros(3, dtype=torch.int64, device=dev)
+        if rank == 0:
+            cpu, A, mod, s_cpu = cpu_baseline(wl, args, whole_tiles=world > 1, min_spp=world if (world > 1 and split == "sample") else 1)
+            sample = torch.tensor([mod, s_cpu, 1], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.broadcast(sample, src=0)
+        mod, s_cpu = int(sample[0]), int(sample[1])
+        if world > 1:
+            gst = step(want_stats=True, spp_count=s_cpu)
+            g = torch.tensor([float(gst["n_closest_rays"] + gst["n_shadow_rays"])], dtype=torch.float64, device=dev)
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            rays_gpu = int(g[0])
+        else:
+            frame.zero_()
+            gst = r.render_into(frame, spp_count=s_cpu, spp_begin=0, tile_mod=mod, tile_rem=0)
+            rays_gpu = int(gst["n_closest_rays"] + gst["n_shadow_rays"])
+        if rank == 0:
+            if frame.is_cuda:
+                torch.cuda.synchronize()
             out["cpu_baseline"] = cpu
-            out["parity"] = parity
+            out["parity"] = parity_block(wl, A, frame.cpu().numpy(), r.border, cpu["rays"], rays_gpu)
+            if world > 1:
+                out["parity"]["frame"] = f"merged on rank 0 from {world} ranks ({split} split, {args.merge} merge)"
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.barrier()
@@ -359,15 +395,13 @@ def usable_cores() -> int:
     return n
 
 
-def cpu_baseline_and_parity(wl, r, frame, args):
+def cpu_baseline(wl, args, whole_tiles=False, min_spp=1):
     """The oracle (kind 'port': the CPU restatement of the path, compiled for THIS host with -O3 -march=native
     -ffp-contract=off, SAH BVH, std::thread workers pulling 32x32 blocks as src/main.cpp:85-113 does) on all
     host cores, on a bounded sample: every k-th tile of the frame at s samples per pixel, sized for
-    ~cpu_seconds.  The GPU then renders exactly that sample (same tiles, same sample indices, same per-sample
-    seeds) and the two images are compared: the parity verdict of this timed run."""
-    import numpy as np
-    import torch
-    from nori_amd.render import develop_host
+    ~cpu_seconds (whole_tiles: every tile -- the sample a multi-GPU run can share out like the frame itself -- at s >= min_spp).
+    Returns (block, RGBW frame of the sample, k, s): the GPU then renders exactly that sample (same tiles, same sample
+    indices, same per-sample seeds) and the two images are compared: the parity verdict of this timed run."""
     from tests.backends import Oracle, use_native_oracle
     native = use_native_oracle()          # builds oracle/_native/liboracle_native_<cpu>.so on this host if it can
     sc = wl.scene
@@ -384,36 +418,39 @@ def cpu_baseline_and_parity(wl, r, frame, args):
     budget = args.cpu_seconds / per_tile_spp                  # (tile x spp) units we can afford
     if budget >= tiles * spp:
         mod, s = 1, spp
-    elif budget >= tiles:
-        mod, s = 1, int(budget // tiles)
+    elif budget >= tiles or whole_tiles:
+        mod, s = 1, max(1, int(budget // tiles))
     else:
         mod, s = int(min(tiles, -(-tiles // max(1.0, budget)))), 1
+    s = min(spp, max(s, min_spp))
     A, st = o.render_host(spp_count=s, tile_mod=mod, tile_rem=0, threads=cores)
     rays = st["n_closest_rays"] + st["n_shadow_rays"]
     sec = st["kernel_ms"] * 1e-3
     cpu = {"value": round(rays / sec / 1e6, 3), "unit": "Mrays/s", "cores": cores, "kind": "port",
            "flags": "-O3 -march=native -ffp-contract=off" if native else "-O2 -ffp-contract=off (native build unavailable)",
            "accel": "binned-SAH BVH" if wl.name != "c1-bunny-normals" else "brute force over all triangles (the reference's Accel, src/accel.cpp:30-40)",
-           "accel_build_s": round(build_s, 2),
+           "accel_build_s": round(build_s, 2), "rays": int(rays), "seconds": round(sec, 2),
            "sample": f"{sc.camera.width}x{sc.camera.height}, every {mod}. tile, {s} spp of {spp} ({rays} rays in {sec:.1f} s, "
                      f"std::thread x{cores}, per-sample seeding)"}
-    frame.zero_()
-    gst = r.render_into(frame, spp_count=s, spp_begin=0, tile_mod=mod, tile_rem=0)
-    if frame.is_cuda:
-        torch.cuda.synchronize()
-    B = frame.cpu().numpy()
-    a, b = develop_host(A, r.border), develop_host(B, r.border)
-    covered = A[r.border:A.shape[0] - r.border, r.border:A.shape[1] - r.border, 3] > 0
+    return cpu, A, mod, s
+
+
+def parity_block(wl, A, B, border, rays_cpu, rays_gpu):
+    """CPU frame A against device frame B of the same sample."""
+    import numpy as np
+    from nori_amd.render import develop_host
+    a, b = develop_host(A, border), develop_host(B, border)
+    covered = A[border:A.shape[0] - border, border:A.shape[1] - border, 3] > 0
     rel = (np.abs(a - b) / np.maximum(np.abs(a), 1e-2)).max(axis=-1)[covered]
     parity = {"frac_within_1e-3": round(float((rel <= 1e-3).mean()), 6), "mean_rel": float(f"{rel.mean():.3e}"),
               "tolerance": ">= 0.999 of pixels within 1e-3 relative, mean relative error <= 1e-4 (SURVEY 8(d), per-sample seeding)",
-              "pixels": int(covered.sum()), "rays_cpu": int(rays), "rays_gpu": int(gst["n_closest_rays"] + gst["n_shadow_rays"]),
+              "pixels": int(covered.sum()), "rays_cpu": int(rays_cpu), "rays_gpu": int(rays_gpu),
               "w_channel_max_abs_diff": float(np.abs(A[..., 3] - B[..., 3]).max())}
-    parity["ok"] = bool(parity["frac_within_1e-3"] >= 0.999 and parity["mean_rel"] <= 1e-4)
+    parity["ok"] = bool(parity["frac_within_1e-3"] >= 0.999 and parity["mean_rel"] <= 1e-4 and parity["rays_cpu"] == parity["rays_gpu"])
     bsdfs = {m.bsdf.type for m in wl.scene.meshes}
     if "dielectric" in bsdfs:      # what the comparison cannot vouch for: nothing in the reference pins this plugin (SURVEY 8c)
         parity["unpinned_by_reference"] = "Dielectric::sample (src/dielectric.cpp:31-33 is a stub; no reference test touches it): oracle and device share the documented choice -- Fresnel-weighted reflect / refract, weight 1"
-    return cpu, parity
+    return parity
 
 
 if __name__ == "__main__":

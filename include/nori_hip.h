@@ -309,6 +309,9 @@ int nori_hip_debug_excursions(nori_hip_ctx *ctx, unsigned long long out[4], int 
  *                     bit-identical to a single-threaded render of the same samples by the reference's loops)
  * Unknown keys return NORI_ERR_INVALID_ARGUMENT. */
 int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value);
+/* The current value of an option as set_option would take it ("engine", "wavefront_paths", "film_order", "accel_layout"),
+ * NUL-terminated into value[capacity]; NORI_ERR_INVALID_ARGUMENT for unknown keys or a buffer too small. */
+int nori_hip_get_option(const nori_hip_ctx *ctx, const char *key, char *value, size_t capacity);
 
 /* ImageBlock::m_borderSize for the uploaded filter (src/block.cpp:20). */
 int nori_hip_border_size(const nori_hip_ctx *ctx);
@@ -404,7 +407,10 @@ int nori_hip_develop(nori_hip_ctx *ctx, const void *d_rgbw, void *d_rgb,
  * Shares: NORI_SPLIT_TILE = 16x16 tiles round-robin over the devices, NORI_SPLIT_SAMPLE = a range of the per-pixel
  * sample indices each.  Merges: NORI_MERGE_REDUCE = ncclReduce(sum) of the whole frames, NORI_MERGE_GATHER (tile split,
  * tile columns divisible by the device count) = every device sends only the column strips its tiles touched.
- * A device list that names a device more than once is served without RCCL (peer copies) -- for tests on one GPU. */
+ * A device list that names a device more than once is served without RCCL (peer copies) -- for tests on one GPU; so is a
+ * node whose librccl cannot be loaded (nori_hip_group_warning says so).  A fresh RCCL group proves its communicators with
+ * a small reduce of a known pattern before nori_hip_group_create returns.  film_order = reference and NORI_SEED_NORI_BLOCK
+ * render whole frames on one device: a group of more than one refuses them. */
 typedef struct nori_hip_group nori_hip_group;
 typedef enum nori_group_split { NORI_SPLIT_TILE = 0, NORI_SPLIT_SAMPLE = 1 } nori_group_split;
 typedef enum nori_group_merge { NORI_MERGE_REDUCE = 0, NORI_MERGE_GATHER = 1 } nori_group_merge;
@@ -418,6 +424,11 @@ nori_hip_ctx *nori_hip_group_ctx(nori_hip_group *group, int i);
 const char *nori_hip_group_last_error(const nori_hip_group *group);
 /* "rccl" or "copy" */
 const char *nori_hip_group_transport(const nori_hip_group *group);
+/* "" or why the group merges over peer copies although RCCL was wanted (librccl not loadable on this box) */
+const char *nori_hip_group_warning(const nori_hip_group *group);
+/* nori_render_stats::engine of every device's share of the last frame ("auto" picks by the size of a share, so the devices
+ * may differ); returns the number of entries written (<= capacity) or a negative nori_status */
+int nori_hip_group_engines(const nori_hip_group *group, uint32_t *engines, int capacity);
 /* nori_hip_upload_scene + nori_hip_build_accel on every device, side by side (Scene::activate per device) */
 int nori_hip_group_upload_scene(nori_hip_group *group, const nori_scene_desc *scene, int builder /* nori_accel_builder */);
 /* The render loop of src/main.cpp:78-119 over the group: samples [spp_begin, spp_begin + spp_count) of every pixel of the

@@ -120,6 +120,7 @@ HIP_PROTOTYPES = {
     "nori_hip_accel_info": (C.c_int, [_P, C.POINTER(AccelInfo)]),
     "nori_hip_debug_excursions": (C.c_int, [_P, _P, C.c_int]),
     "nori_hip_set_option": (C.c_int, [_P, C.c_char_p, C.c_char_p]),
+    "nori_hip_get_option": (C.c_int, [_P, C.c_char_p, C.c_char_p, C.c_size_t]),
     "nori_hip_border_size": (C.c_int, [_P]),
     "nori_hip_intersect": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
     "nori_hip_intersect_device": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int, _P]),
@@ -142,6 +143,8 @@ HIP_PROTOTYPES = {
     "nori_hip_group_ctx": (_P, [_P, C.c_int]),
     "nori_hip_group_last_error": (C.c_char_p, [_P]),
     "nori_hip_group_transport": (C.c_char_p, [_P]),
+    "nori_hip_group_warning": (C.c_char_p, [_P]),
+    "nori_hip_group_engines": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int]),
     "nori_hip_group_upload_scene": (C.c_int, [_P, C.POINTER(SceneDesc), C.c_int]),
     "nori_hip_group_render_host": (C.c_int, [_P, C.POINTER(RenderParams), C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(RenderStats), C.POINTER(C.c_float)]),
 }

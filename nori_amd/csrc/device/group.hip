@@ -19,9 +19,9 @@
  */
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
-#include <rccl/rccl.h>      /* types and prototypes only: the library is dlopen'ed */
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -35,24 +35,41 @@ using namespace nrt;
 
 namespace {
 
+/* The handful of RCCL types and entry points the group uses, declared here (the library itself is dlopen'ed at the first
+   group of more than one device): a one-GPU build needs neither the RCCL headers nor the library.  Values as in rccl.h /
+   nccl.h 2.x (ncclSuccess = 0, ncclFloat32 = 7, ncclSum = 0) -- checked at load time against ncclGetVersion. */
+typedef struct ncclComm *ncclComm_t;
+typedef int ncclResult_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr int ncclFloat = 7, ncclSum = 0;
+
 struct Rccl {
     void *lib = nullptr;
-    decltype(&ncclCommInitAll) CommInitAll = nullptr;
-    decltype(&ncclCommDestroy) CommDestroy = nullptr;
-    decltype(&ncclGetErrorString) GetErrorString = nullptr;
-    decltype(&ncclReduce) Reduce = nullptr;
-    decltype(&ncclSend) Send = nullptr;
-    decltype(&ncclRecv) Recv = nullptr;
-    decltype(&ncclGroupStart) GroupStart = nullptr;
-    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     std::string load() {
         if (lib) return std::string();
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { lib = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
-        if (!lib) return std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
-#define SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); if (!field) return std::string("librccl lacks ") + name
-        SYM(CommInitAll, "ncclCommInitAll"); SYM(CommDestroy, "ncclCommDestroy"); SYM(GetErrorString, "ncclGetErrorString");
-        SYM(Reduce, "ncclReduce"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv"); SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd");
+        std::string why;
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+            const char *e = dlerror();      /* ONE call: dlerror() clears the state it returns */
+            if (e && why.empty()) why = e;
+        }
+        if (!lib) return "librccl not found: " + why;
+#define SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(lib, name)); if (!field) { const std::string m = std::string("librccl lacks ") + name; dlclose(lib); lib = nullptr; return m; }
+        SYM(CommInitAll, "ncclCommInitAll") SYM(CommDestroy, "ncclCommDestroy") SYM(GetErrorString, "ncclGetErrorString") SYM(GetVersion, "ncclGetVersion")
+        SYM(Reduce, "ncclReduce") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
 #undef SYM
+        int version = 0;
+        if (GetVersion(&version) != ncclSuccess || version < 20000) { dlclose(lib); lib = nullptr; return "librccl: version " + std::to_string(version) + " (the enum values used here are those of 2.x)"; }
         return std::string();
     }
 };
@@ -98,7 +115,8 @@ struct nori_hip_group {
     std::vector<ncclComm_t> comms;
     size_t frame_floats = 0, pack_floats = 0, x_ints = 0, recv_floats = 0;      /* what the buffers are sized for */
     bool rccl = false;
-    std::string error;
+    std::string error, warning;
+    std::vector<uint32_t> engines;         /* what rendered each device's share of the last frame (nori_render_stats::engine) */
     void free_buffers() {
         for (size_t k = 0; k < devices.size(); ++k) {
             (void) hipSetDevice(devices[k]);
@@ -118,6 +136,44 @@ struct nori_hip_group {
 #define GRP_NCCL(expr) do { ncclResult_t r__ = (expr); if (r__ != ncclSuccess) { g->error = std::string(#expr) + ": " + g_rccl.GetErrorString(r__); return NORI_ERR_INTERNAL; } } while (0)
 
 static std::string g_group_create_error;
+
+/* ncclReduce(sum) of kCheckFloats floats per rank, rank k contributing (k + 1) * (i % 251 + 1): exact in binary32 for <= 64
+   ranks, so rank 0 must read n (n + 1) / 2 * (i % 251 + 1) bit for bit.  Returns "" or what went wrong. */
+constexpr size_t kCheckFloats = 4096;
+__global__ void check_fill_kernel(float *p, size_t n, float scale) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = scale * (float) (i % 251 + 1);
+}
+static std::string rccl_self_check(nori_hip_group *g) {
+    const int n = (int) g->devices.size();
+    std::vector<float *> buf((size_t) n, nullptr);
+    std::string err;
+    auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && err.empty()) err = std::string(what) + ": " + hipGetErrorString(e); return e == hipSuccess; };
+    for (int k = 0; k < n && err.empty(); ++k) {
+        if (!hip_ok(hipSetDevice(g->devices[(size_t) k]), "hipSetDevice") || !hip_ok(hipMalloc((void **) &buf[(size_t) k], kCheckFloats * sizeof(float)), "hipMalloc")) break;
+        hipLaunchKernelGGL(check_fill_kernel, dim3((unsigned) (kCheckFloats / 256)), dim3(256), 0, g->streams[(size_t) k], buf[(size_t) k], kCheckFloats, (float) (k + 1));
+        hip_ok(hipGetLastError(), "check_fill_kernel");
+    }
+    if (err.empty()) {
+        ncclResult_t r = g_rccl.GroupStart();
+        for (int k = 0; k < n && r == ncclSuccess; ++k) r = g_rccl.Reduce(buf[(size_t) k], buf[(size_t) k], kCheckFloats, ncclFloat, ncclSum, 0, g->comms[(size_t) k], g->streams[(size_t) k]);
+        const ncclResult_t e = g_rccl.GroupEnd();      /* always closed, whatever happened inside */
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) err = std::string("ncclReduce: ") + g_rccl.GetErrorString(r);
+    }
+    for (int k = 0; k < n && err.empty(); ++k) { hip_ok(hipSetDevice(g->devices[(size_t) k]), "hipSetDevice"); hip_ok(hipStreamSynchronize(g->streams[(size_t) k]), "hipStreamSynchronize"); }
+    if (err.empty()) {
+        std::vector<float> h(kCheckFloats);
+        if (hip_ok(hipSetDevice(g->devices[0]), "hipSetDevice") && hip_ok(hipMemcpy(h.data(), buf[0], kCheckFloats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy")) {
+            const float total = (float) (n * (n + 1) / 2);
+            for (size_t i = 0; i < kCheckFloats; ++i)
+                if (h[i] != total * (float) (i % 251 + 1)) { err = "rank 0 holds " + std::to_string(h[i]) + " at element " + std::to_string(i) + ", expected " + std::to_string(total * (float) (i % 251 + 1)); break; }
+        }
+    }
+    for (int k = 0; k < n; ++k) if (buf[(size_t) k]) { (void) hipSetDevice(g->devices[(size_t) k]); (void) hipFree(buf[(size_t) k]); }
+    (void) hipSetDevice(g->devices[0]);
+    return err;
+}
 
 extern "C" {
 
@@ -149,10 +205,22 @@ int nori_hip_group_create(const int *devices, int n_devices, nori_hip_group **ou
     }
     if (g->rccl) {
         std::string e = g_rccl.load();
-        if (!e.empty()) { g_group_create_error = e; nori_hip_group_destroy(g); return NORI_ERR_UNSUPPORTED; }
+        if (!e.empty()) {
+            /* no RCCL on this box: the merge still works over peer copies (hipMemcpyPeerAsync + the same kernels), only slower --
+               unless the caller insisted on RCCL */
+            if (tr && std::string(tr) == "rccl") { g_group_create_error = e; nori_hip_group_destroy(g); return NORI_ERR_UNSUPPORTED; }
+            g->rccl = false; g->warning = e + " -- merging over peer copies";
+            fprintf(stderr, "[nori_hip_group] %s\n", g->warning.c_str());
+        }
+    }
+    if (g->rccl) {
         g->comms.assign((size_t) n_devices, nullptr);
         const ncclResult_t r = g_rccl.CommInitAll(g->comms.data(), n_devices, g->devices.data());
         if (r != ncclSuccess) { g_group_create_error = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r); g->comms.clear(); nori_hip_group_destroy(g); return NORI_ERR_INTERNAL; }
+        /* RCCL with more than one rank runs for the first time on the user's node: prove the communicators before a frame
+           depends on them -- every rank contributes a known pattern, rank 0 must hold the sum */
+        const std::string check = rccl_self_check(g);
+        if (!check.empty()) { g_group_create_error = "RCCL self-check: " + check; nori_hip_group_destroy(g); return NORI_ERR_INTERNAL; }
     }
     (void) hipSetDevice(devices[0]);
     *out = g;
@@ -172,6 +240,13 @@ int nori_hip_group_size(const nori_hip_group *g) { return g ? (int) g->ctx.size(
 nori_hip_ctx *nori_hip_group_ctx(nori_hip_group *g, int i) { return (g && i >= 0 && i < (int) g->ctx.size()) ? g->ctx[(size_t) i] : nullptr; }
 const char *nori_hip_group_last_error(const nori_hip_group *g) { return g ? g->error.c_str() : g_group_create_error.c_str(); }
 const char *nori_hip_group_transport(const nori_hip_group *g) { return !g ? "" : g->rccl ? "rccl" : "copy"; }
+const char *nori_hip_group_warning(const nori_hip_group *g) { return g ? g->warning.c_str() : ""; }
+int nori_hip_group_engines(const nori_hip_group *g, uint32_t *engines, int capacity) {
+    if (!g || !engines || capacity < 0) return NORI_ERR_INVALID_ARGUMENT;
+    const int n = (int) std::min<size_t>(g->engines.size(), (size_t) capacity);
+    for (int k = 0; k < n; ++k) engines[k] = g->engines[(size_t) k];
+    return n;
+}
 
 int nori_hip_group_upload_scene(nori_hip_group *g, const nori_scene_desc *scene, int builder) {
     if (!g || !scene) return NORI_ERR_INVALID_ARGUMENT;
@@ -203,6 +278,16 @@ int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *para
         g->error = "group_render: the gather merge needs the tile split and a tile-column count (" + std::to_string(tiles_x) + ") divisible by the number of devices (" + std::to_string(n) + "); use the reduce merge";
         return NORI_ERR_INVALID_ARGUMENT;
     }
+    /* film_order = reference promises the reference's summation order over the WHOLE frame: a share of the tiles is rejected per
+       context (nori_hip_render); a share of the samples would be accepted there and lose the order in the sum of the frames */
+    if (n > 1)
+        for (int k = 0; k < n; ++k) {
+            char v[32] = "";
+            if (nori_hip_get_option(g->ctx[(size_t) k], "film_order", v, sizeof(v)) == NORI_OK && std::string(v) == "reference") {
+                g->error = "group_render: film_order = reference renders whole frames on one device (the frames of several devices are summed afterwards)";
+                return NORI_ERR_UNSUPPORTED;
+            }
+        }
     if (params->seed_mode == NORI_SEED_NORI_BLOCK && n > 1) { g->error = "group_render: NORI_SEED_NORI_BLOCK renders whole frames on one device"; return NORI_ERR_UNSUPPORTED; }
 
     /* buffers for this frame geometry */
@@ -259,7 +344,11 @@ int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *para
         if (rc[(size_t) k] != NORI_OK) { g->error = "device " + std::to_string(g->devices[(size_t) k]) + ": " + errs[(size_t) k]; return rc[(size_t) k]; }
 
     /* merge on device 0: ImageBlock::put(ImageBlock&) across devices */
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct Events {      /* destroyed on every way out */
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void) hipEventDestroy(e0); if (e1) (void) hipEventDestroy(e1); }
+    } ev;
+    hipEvent_t &e0 = ev.e0, &e1 = ev.e1;
     GRP_HIP(hipSetDevice(g->devices[0]));
     GRP_HIP(hipEventCreate(&e0)); GRP_HIP(hipEventCreate(&e1));
     GRP_HIP(hipEventRecord(e0, g->streams[0]));
@@ -267,8 +356,10 @@ int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *para
     if ((n > 1 || g->rccl) && merge == kMergeReduce) {      /* (a forced one-rank RCCL group still calls ncclReduce: a smoke test of the library on one GPU) */
         if (g->rccl) {
             GRP_NCCL(g_rccl.GroupStart());
-            for (int k = 0; k < n; ++k) GRP_NCCL(g_rccl.Reduce(g->d_frame[(size_t) k], g->d_frame[(size_t) k], frame_floats, ncclFloat, ncclSum, 0, g->comms[(size_t) k], g->streams[(size_t) k]));
-            GRP_NCCL(g_rccl.GroupEnd());
+            ncclResult_t r = ncclSuccess;      /* a failure inside leaves through GroupEnd: an open group would poison every later RCCL call of the process */
+            for (int k = 0; k < n && r == ncclSuccess; ++k) r = g_rccl.Reduce(g->d_frame[(size_t) k], g->d_frame[(size_t) k], frame_floats, ncclFloat, ncclSum, 0, g->comms[(size_t) k], g->streams[(size_t) k]);
+            const ncclResult_t closed = g_rccl.GroupEnd();
+            GRP_NCCL(r); GRP_NCCL(closed);
         } else {
             for (int k = 1; k < n; ++k) {
                 GRP_HIP(hipMemcpyPeerAsync(g->d_recv[(size_t) k], g->devices[0], g->d_frame[(size_t) k], g->devices[(size_t) k], frame_floats * sizeof(float), g->streams[0]));
@@ -284,12 +375,14 @@ int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *para
         }
         if (g->rccl) {
             GRP_NCCL(g_rccl.GroupStart());
-            for (int k = 1; k < n; ++k) {
+            ncclResult_t r = ncclSuccess;
+            for (int k = 1; k < n && r == ncclSuccess; ++k) {
                 const size_t cnt = xs[(size_t) k].size() * (size_t) rows * 4;
-                GRP_NCCL(g_rccl.Send(g->d_pack[(size_t) k], cnt, ncclFloat, 0, g->comms[(size_t) k], g->streams[(size_t) k]));
-                GRP_NCCL(g_rccl.Recv(g->d_recv[(size_t) k], cnt, ncclFloat, k, g->comms[0], g->streams[0]));
+                r = g_rccl.Send(g->d_pack[(size_t) k], cnt, ncclFloat, 0, g->comms[(size_t) k], g->streams[(size_t) k]);
+                if (r == ncclSuccess) r = g_rccl.Recv(g->d_recv[(size_t) k], cnt, ncclFloat, k, g->comms[0], g->streams[0]);
             }
-            GRP_NCCL(g_rccl.GroupEnd());
+            const ncclResult_t closed = g_rccl.GroupEnd();
+            GRP_NCCL(r); GRP_NCCL(closed);
         } else {
             for (int k = 1; k < n; ++k) {
                 GRP_HIP(hipSetDevice(g->devices[(size_t) k]));
@@ -311,7 +404,6 @@ int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *para
     GRP_HIP(hipStreamSynchronize(g->streams[0]));
     float ms = 0.0f;
     GRP_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     if (merge_ms) *merge_ms = ms;
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
@@ -322,9 +414,14 @@ int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *para
             stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms);       /* the devices render side by side: the slowest counts */
             stats->trace_ms = std::max(stats->trace_ms, s.trace_ms); stats->shade_ms = std::max(stats->shade_ms, s.shade_ms); stats->film_ms = std::max(stats->film_ms, s.film_ms);
             stats->n_workgroups += s.n_workgroups; stats->n_trace_launches = std::max(stats->n_trace_launches, s.n_trace_launches);
-            stats->lds_bytes = s.lds_bytes; stats->engine = s.engine;
+            stats->lds_bytes = std::max(stats->lds_bytes, s.lds_bytes);
         }
+        /* "auto" picks the engine by the size of a share: the devices may differ -- the summed stats name the first device's,
+           nori_hip_group_engines() every device's */
+        stats->engine = st[0].engine;
     }
+    g->engines.resize((size_t) n);
+    for (int k = 0; k < n; ++k) g->engines[(size_t) k] = st[(size_t) k].engine;
     return NORI_OK;
 }
 

@@ -714,6 +714,20 @@ int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value) {
     return NORI_ERR_INVALID_ARGUMENT;
 }
 
+int nori_hip_get_option(const nori_hip_ctx *ctx, const char *key, char *value, size_t capacity) {
+    if (!ctx || !key || !value || capacity == 0) return NORI_ERR_INVALID_ARGUMENT;
+    const std::string k(key);
+    std::string v;
+    if (k == "engine") v = ctx->engine == 0 ? "megakernel" : ctx->engine == 1 ? "wavefront" : "auto";
+    else if (k == "wavefront_paths") v = std::to_string(ctx->wavefront_paths);
+    else if (k == "film_order") v = ctx->film_reference ? "reference" : "fast";
+    else if (k == "accel_layout") v = ctx->accel_layout == 0 ? "bvh2" : ctx->accel_layout == 1 ? "bvh4q" : "auto";
+    else return NORI_ERR_INVALID_ARGUMENT;
+    if (v.size() + 1 > capacity) return NORI_ERR_INVALID_ARGUMENT;
+    std::memcpy(value, v.c_str(), v.size() + 1);
+    return NORI_OK;
+}
+
 int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out) {
     if (!ctx || !out) return NORI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_accel) return NORI_ERR_NOT_READY;

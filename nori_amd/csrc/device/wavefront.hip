@@ -91,6 +91,8 @@ struct WfBatch {
     uint32_t flags;                     /* kBatch* */
 };
 constexpr uint32_t kBatchNoAsmLoop = 1u;       /* wf_extend: the compiler's node loop instead of the hand-written one (A/B, tests) */
+constexpr uint32_t kBatchCountQ = 2u;          /* wf_extend, COUNT builds: walk the 32-B node records (trav_inner_step_q, the C++ statement of the
+                                                  hand-written loop) -- the node / triangle tests counted are those of the tree form the timed kernel walks */
 
 /* Per-lane traversal stack in LDS ([entry][thread], bank = lane -> conflict free).
    Trees no deeper than DEPTH: one register (the address of the next free slot); entry 0 holds the
@@ -459,8 +461,9 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(D
     stack.init(smem, b.stack_spill, gridDim.x * BLOCK);
     /* the first levels of the tree in LDS (rt_trace.h, node_fetch): behind the stacks */
     f4 *top = reinterpret_cast<f4 *>(smem + (size_t) Stack::kLdsEntries * BLOCK * sizeof(int));
-    /* the kernel with the hand-written node loop walks the 32-B records: its image holds those */
-    const int root_link = ASM ? top_image_to_lds(sc, top, sc.top_image_q, sc.top_image_q_quads) : top_image_to_lds(sc, top, sc.top_image, sc.top_image_quads);
+    /* the kernel with the hand-written node loop walks the 32-B records: its image holds those (and so does the counting twin's) */
+    const bool count_q = COUNT && !WIDE && (bt.flags & kBatchCountQ) != 0u;
+    const int root_link = (ASM || count_q) ? top_image_to_lds(sc, top, sc.top_image_q, sc.top_image_q_quads) : top_image_to_lds(sc, top, sc.top_image, sc.top_image_quads);
     const TopNodesP top_lds = top_nodes_pointer(top);
     const uint32_t image_address = lds_address(smem) + (uint32_t) (Stack::kLdsEntries * BLOCK * sizeof(int));      /* of top */
     const WfState S = b.st[cur];
@@ -604,6 +607,7 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(D
             if (COUNT) { const int ni = __popcll(__ballot(trav_at_inner(tv))); if (ni) { zc[Z_INNER_TRIPS]++; zc[Z_INNER_LANES] += (uint32_t) ni; } }
             if (trav_at_inner(tv)) {
                 if (WIDE) trav_wide_step<COUNT>(sc, stack, tv, tc, top_lds);      /* BVH4, quantised boxes: scenes beyond the caches */
+                else if (COUNT && count_q) trav_inner_step_q<COUNT>(sc, stack, tv, tc, top_lds);
                 else trav_inner_step<COUNT>(sc, stack, tv, tc, top_lds);
             }
         } while (__popcll(__ballot(trav_at_inner(tv))) >= bt.inner_repeat);
@@ -914,8 +918,9 @@ void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int 
            stack in LDS; everything else takes the compiler's loop over the 64-B nodes */
         constexpr bool kAsm = NORI_ASM_NODE_LOOP && !COUNT;
         const bool use_asm = kAsm && sc.nodes_q != nullptr && sc.n_triangles < (1u << 25) && (bt.flags & kBatchNoAsmLoop) == 0u;
+        const bool image_q = use_asm || (COUNT && (bt.flags & kBatchCountQ) != 0u);
         const size_t lds = (use_asm ? (size_t) ExtendStack<STACK, SPILL, kAsm, kExtendBlockBvh2>::type::kLdsEntries : (size_t) LdsStackW<STACK, SPILL, kExtendBlockBvh2>::kLdsEntries) *
-                               kExtendBlockBvh2 * sizeof(int) + (size_t) std::max(1u, use_asm ? sc.top_image_q_quads : sc.top_image_quads) * sizeof(f4);
+                               kExtendBlockBvh2 * sizeof(int) + (size_t) std::max(1u, image_q ? sc.top_image_q_quads : sc.top_image_quads) * sizeof(f4);
         if (use_asm)
             hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST, false, kAsm, kExtendBlockBvh2>), dim3(grid), dim3(kExtendBlockBvh2), lds, s, sc, b, cur, refill, bt);
         else
@@ -1124,16 +1129,27 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     const bool no_asm_loop = getenv("NORI_HIP_WF_NO_ASM_LOOP") != nullptr && atoi(getenv("NORI_HIP_WF_NO_ASM_LOOP")) != 0;
     int lds_stack = 16;
     if (const char *e = getenv("NORI_HIP_WF_STACK")) lds_stack = atoi(e) <= 16 ? 16 : atoi(e) <= 24 ? 24 : 32;
-    const bool spill = L.stack_depth > lds_stack || sc.wide != 0;
     int finish_paths = 524288;           /* fewer live paths than this: wf_finish ends the batch */
     if (const char *e = getenv("NORI_HIP_WF_FINISH_PATHS")) finish_paths = std::max(256, atoi(e)) & ~255;
     const int finish_grid = finish_paths / kB;
     /* LDS per workgroup: stack entries (+1: the "done" marker of the non-spilling stack) + the top-node cache */
     const int extend_block = sc.wide ? kExtendBlockWide : kExtendBlockBvh2;
     /* which node loop wf_extend will run (launch_extend): the hand-written one on 32-B records, or the compiler's on 64-B nodes */
-    const bool node_loop_q = NORI_ASM_NODE_LOOP && !L.count_traversal && !sc.wide && sc.nodes_q != nullptr && sc.n_triangles < (1u << 25) && !no_asm_loop;
-    const int stack_entries = node_loop_q ? lds_stack + (spill ? 2 : 1) : lds_stack + (spill ? 0 : 1);      /* kLdsEntries of the kernel's stack class */
-    const size_t lds_per_wg = (size_t) stack_entries * extend_block * sizeof(int) + (size_t) std::max(1u, node_loop_q ? sc.top_image_q_quads : sc.top_image_quads) * sizeof(f4);
+    const bool walk_q = NORI_ASM_NODE_LOOP && !sc.wide && sc.nodes_q != nullptr && sc.n_triangles < (1u << 25) && !no_asm_loop;      /* 32-B node records */
+    const bool node_loop_q = walk_q && !L.count_traversal;         /* ... by the hand-written loop */
+    const bool count_q = walk_q && L.count_traversal;              /* ... by its C++ statement, counting (the same tree form as the timed kernel's) */
+    bool spill = false;
+    size_t lds_per_wg = 0;
+    while (true) {
+        spill = L.stack_depth > lds_stack || sc.wide != 0;
+        const int stack_entries = node_loop_q ? lds_stack + (spill ? 2 : 1) : lds_stack + (spill ? 0 : 1);      /* kLdsEntries of the kernel's stack class */
+        lds_per_wg = (size_t) stack_entries * extend_block * sizeof(int) + (size_t) std::max(1u, (node_loop_q || count_q) ? sc.top_image_q_quads : sc.top_image_quads) * sizeof(f4);
+        /* the LDS image was sized at build_accel for 16-entry stacks (wf_top_capacity): a bigger stack asked for at render time
+           (NORI_HIP_WF_STACK, an experiment knob) must not push a workgroup beyond its share of the CU's LDS -- fewer workgroups
+           per CU than the kernel is built for, or a launch that fails: back to the stack the image was sized for */
+        if (lds_stack > 16 && lds_per_wg > kLdsPerCu / (size_t) (sc.wide ? kExtendWgsWide : kExtendWgsBvh2)) { lds_stack = 16; continue; }
+        break;
+    }
     int per_cu = std::max(1, std::min(2048 / extend_block, (int) (kLdsPerCu / lds_per_wg)));      /* workgroups per CU */
     /* every workgroup of the persistent grid must be resident from the start (a workgroup that starts late owns a
        static share of the paths and works it off alone): the wide-node kernels are built for 6 waves per SIMD
@@ -1185,7 +1201,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             P.bt.tile_first = P.t0; P.bt.n_tiles = nt; P.bt.s_first = L.spp_begin + P.s0; P.bt.n_spp = ns;
             P.bt.tile_mod = L.tile_mod; P.bt.tile_rem = L.tile_rem; P.bt.tiles_x = L.tiles_x; P.bt.tile_w = L.tile_w;
             P.bt.inner_repeat = inner_repeat;
-            P.bt.flags = no_asm_loop ? kBatchNoAsmLoop : 0u;
+            P.bt.flags = (no_asm_loop ? kBatchNoAsmLoop : 0u) | (count_q ? kBatchCountQ : 0u);
             WF_TRY(hipMemsetAsync(P.b.ctr, 0, C_COUNT * sizeof(uint32_t), P.stream));
             stats.n_batches++;
             P.cur = 0; P.first = true; P.active = true; any = true; P.batch_rounds = 0;
@@ -1202,6 +1218,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 if (!P.active) continue;
                 timer.begin(KC_TRACE, P.stream);
                 launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, extend_grid, P.bt, P.stream);
+                WF_TRY(hipGetLastError());      /* a launch that did not fit (LDS, registers) must not pass for an empty pass */
                 timer.end(P.stream);
                 timer.begin(KC_SHADE, P.stream);
                 launch_shade(sc, P.b, P.cur, P.bt, P.first, sh_grid, P.stream);

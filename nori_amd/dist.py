@@ -85,15 +85,29 @@ def gather_frame(frame, rank: int, world: int, tiles_x: int, border: int, dst: i
 
 
 def render_distributed(render_fn, frame, mode: str, spp: int, rank: int, world: int, merge: str = "reduce",
-                       tiles_x: int | None = None, border: int = 0, **kw):
+                       tiles_x: int | None = None, border: int = 0, merge_ms: list | None = None, **kw):
     """render_fn(frame, **shard_kwargs, **kw) accumulates this rank's share into
-    `frame` (a torch tensor, CUDA for the product / CPU in tests); then merge on rank 0."""
+    `frame` (a torch tensor, CUDA for the product / CPU in tests); then merge on rank 0.
+    merge_ms: a list that receives this rank's time in the exchange (events on the frame's stream; it contains the wait for
+    the slowest rank) -- only when a process group exists."""
+    import time
     frame.zero_()
     stats = render_fn(frame, **shard(mode, rank, world, spp), **kw)
+    timed = merge_ms is not None and _group_up()
+    if timed and frame.is_cuda:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    t0 = time.perf_counter()
     if merge == "gather":
         if mode != "tile":
             raise ValueError("gather merge applies to the tile split only")
         gather_frame(frame, rank, world, tiles_x, border, 0)
     else:
         reduce_frame(frame, 0)
+    if timed and frame.is_cuda:
+        e1.record(); e1.synchronize()
+        merge_ms.append(float(e0.elapsed_time(e1)))
+    elif timed:
+        merge_ms.append((time.perf_counter() - t0) * 1e3)
     return stats

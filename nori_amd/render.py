@@ -263,6 +263,17 @@ class DeviceGroup:
     def transport(self) -> str:
         return self._lib.nori_hip_group_transport(self._h).decode()
 
+    @property
+    def warning(self) -> str:
+        """"" or why the merge runs over peer copies although RCCL was wanted."""
+        return self._lib.nori_hip_group_warning(self._h).decode()
+
+    def engines(self):
+        """nori_render_stats::engine of every device's share of the last frame."""
+        out = (C.c_uint32 * self.size)()
+        n = self._lib.nori_hip_group_engines(self._h, out, self.size)
+        return [int(out[k]) for k in range(max(n, 0))]
+
     def upload(self, scene: Scene, builder: int = 0):
         desc, keep = scene.c_desc()
         self._check(self._lib.nori_hip_group_upload_scene(self._h, C.byref(desc), int(builder)), "group_upload_scene")

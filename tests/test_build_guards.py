@@ -1,0 +1,75 @@
+"""Build-time guards: properties of the COMPILED kernels that no result check can see.
+
+The node loop of wf_extend is a block of hand-written gfx950 assembly on fixed registers (v32-v45, vcc; wavefront.hip,
+bvh2q_node_loop_asm).  It is correct under any register allocation of the C++ around it (clobber list), but it is only FAST
+while that C++ stays within 64 VGPRs without scratch -- 8 waves per SIMD, 2 workgroups of 1024 threads per CU, which is what
+the LDS image and the persistent grid are sized for.  A register regression would cost milliseconds silently; here it fails.
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU suite."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def wavefront_kernels(tmp_path_factory):
+    import __graft_entry__ as ge
+    from kernel_resources import kernels
+    out = tmp_path_factory.mktemp("asm") / "wavefront.s"
+    flags = [f for f in ge.HIP_FLAGS if f not in ("-shared", "-fPIC")]
+    p = subprocess.run([ge.HIPCC] + flags + ["--cuda-device-only", "-S", os.path.join(ge.DEV, "wavefront.hip"), "-o", str(out)],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rows = {r["demangled"].replace("(anonymous namespace)::", ""): r for r in kernels(str(out))}
+    return rows, open(out).read()
+
+
+def _find(rows, prefix):
+    hit = [r for name, r in rows.items() if name.startswith("void " + prefix)]
+    assert len(hit) == 1, (prefix, [n for n in rows if prefix.split("<")[0] in n][:8])
+    return hit[0]
+
+
+def test_the_production_traversal_kernels_keep_their_register_budget(wavefront_kernels):
+    rows, _ = wavefront_kernels
+    # wf_extend<STACK, SPILL, COUNT, FIRST, WIDE, ASM, BLOCK>: the hand-written loop, later passes (88 % of the kernel's time)
+    for stack in (16, 24, 32):
+        k = _find(rows, f"wf_extend<{stack}, false, false, false, false, true, 1024>")
+        assert k["vgpr"] <= 64 and k["agpr"] == 0 and k["scratch"] == 0, k
+        # trees deeper than the LDS stack (LdsStackHybrid): same budget
+        k = _find(rows, f"wf_extend<{stack}, true, false, false, false, true, 1024>")
+        assert k["vgpr"] <= 64 and k["scratch"] == 0, k
+    # every BVH2 variant must fit 8 waves per SIMD (two 1024-thread workgroups per CU), scratch or not
+    for name, k in rows.items():
+        if name.startswith("void wf_extend<") and name.split(">")[0].endswith(", 1024"):
+            assert k["vgpr"] <= 64, (name, k)
+    # wide trees: 6 waves per SIMD (5 in the first pass) -- launch_extend sizes the persistent grid for that
+    k = _find(rows, "wf_extend<16, true, false, false, true, false, 256>")
+    assert k["vgpr"] <= 80 and k["scratch"] == 0, k
+    k = _find(rows, "wf_extend<16, true, false, true, true, false, 256>")
+    assert k["vgpr"] <= 96 and k["scratch"] == 0, k
+
+
+def test_the_shading_kernels_do_not_spill(wavefront_kernels):
+    rows, _ = wavefront_kernels
+    for integ in range(7):
+        for first in ("true", "false"):
+            k = _find(rows, f"wf_shade<{integ}, {first}>")
+            assert k["vgpr"] <= 128 and k["scratch"] == 0, k
+
+
+def test_the_node_loop_reads_a_node_in_two_loads(wavefront_kernels):
+    """The point of the 32-B records: two vector-memory instructions per node step.  The loop body is
+    the text between the labels the assembly block defines; the compiler must not have widened, split or duplicated it."""
+    _, text = wavefront_kernels
+    start = text.index("_ZN12_GLOBAL__N_19wf_extendILi16ELb0ELb0ELb0ELb0ELb1ELi1024EEEvN3nrt8DevSceneENS_5WfBufEiiNS_7WfBatchE:")
+    body = text[start:text.index(".end_amdhsa_kernel", start)]
+    i = body.index("v_bfi_b32 v40")
+    loop = body[body.rindex("s_and_b64 exec", 0, i):body.index("s_cbranch_scc1", i)]
+    assert loop.count("global_load_dwordx4") == 2 and loop.count("ds_read_b128") == 2
+    assert loop.count("v_cvt_f32_u32_sdwa") == 12 and loop.count("v_fma_f32") == 12
+    assert "scratch_" not in loop and "buffer_load" not in loop

@@ -84,6 +84,25 @@ def test_bench_spawns_ranks_and_merges(tmp_path, whole, world, split, merge):
     np.testing.assert_allclose(np.load(frame), ref, rtol=2e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("world,split,merge", [(2, "tile", "gather"), (3, "sample", "reduce")])
+def test_bench_line_of_a_multi_rank_run_is_complete(world, split, merge):
+    """A line for N > 1 carries what a line for N = 1 carries -- roofline, cpu_baseline (rank 0's host cores) and a parity block,
+    here on the frame MERGED from all ranks -- plus what every rank saw (its wall clock, its kernels, its time in the merge)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, BENCH, "--gpus", str(world), "--emulate", "--steps", "1", "--warmup", "0", "--cpu-seconds", "0.5",
+           "--workload", "pa4-cbox-path_mis", "--width", "64", "--height", "32", "--spp", "4", "--split", split, "--merge", merge]
+    p = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == world and out["scaling"] == "strong"
+    assert out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1 and "every 1. tile" in out["cpu_baseline"]["sample"]
+    par = out["parity"]
+    assert par["ok"] and par["rays_cpu"] == par["rays_gpu"] and par["frac_within_1e-3"] >= 0.999 and f"{world} ranks" in par["frame"]
+    assert [r["rank"] for r in out["ranks"]] == list(range(world))
+    assert all(r["ms_per_step"] > 0 and r["merge_ms"] >= 0 and r["rays_per_step"] > 0 for r in out["ranks"])
+    assert sum(r["rays_per_step"] for r in out["ranks"]) == out["config"]["rays_per_step"]
+
+
 def test_bench_without_gpu_fails_at_no_gpu():
     """On a box without a GPU the multi-GPU entry gets as far as 'no GPU' -- not an assert, not a launcher error."""
     import torch
