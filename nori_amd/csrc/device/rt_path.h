@@ -45,16 +45,66 @@ NORI_HD void path_begin(PathState &st, const RayIn &camRay) {
     st.phase = PH_CLOSEST; st.end_after_shadow = 0;
 }
 
-/* DiscretePDF::sample, include/nori/dpdf.h:106-111 (std::lower_bound) */
-NORI_HD uint32_t cdf_sample(const float *cdf, uint32_t n, float v) {
+/* Where the small per-scene tables -- mesh records, the emitter list, the emitters' triangle CDFs -- are read from.  This one
+   goes through DevScene's own pointers (global memory; every engine and twin).  wf_shade keeps a copy of the tables in LDS and
+   reads it with LDS instructions (shade_tables.h, LdsTables): a load through a generic pointer is a FLAT instruction, which
+   counts as a vector-memory AND an LDS access and forces the wave to drain everything it has in flight -- the records wf_shade
+   requests ahead included. */
+struct SceneTables {
+    const DevScene *sc;
+    NORI_HD MeshRec mesh(uint32_t i) const { return sc->meshes[i]; }
+    NORI_HD uint32_t emitter(uint32_t i) const { return sc->emitters[i]; }
+    NORI_HD float cdf(uint32_t i) const { return sc->emitter_cdf[i]; }
+};
+
+/* DiscretePDF::sample, include/nori/dpdf.h:106-111 (std::lower_bound); the CDF is entries [first, first + n] of the table */
+template <class Tab>
+NORI_HD uint32_t cdf_sample(const Tab &tab, uint32_t first, uint32_t n, float v) {
     uint32_t lo = 0, len = n + 1;
     while (len > 0) {
         uint32_t half = len >> 1, mid = lo + half;
-        if (cdf[mid] < v) { lo = mid + 1; len -= half + 1; }
+        if (tab.cdf(first + mid) < v) { lo = mid + 1; len -= half + 1; }
         else len = half;
     }
     uint32_t index = lo > 0 ? lo - 1 : 0;
     return index < n - 1 ? index : n - 1;
+}
+
+/* What wf_shade has worked out AHEAD of a vertex's arithmetic (wavefront.hip): the surface at the hit, and the point its emitter
+   sample lands on.  The emitter triangle's address depends on the path's pcg32 state and depth only, not on what was hit
+   (emitter_pick), so the two shading records are fetched together instead of one after the other's result, and each is reduced to
+   what the vertex needs of it (six registers) as soon as it arrives.  Not ok / another triangle: the record is fetched where it
+   is needed.  (Passed by reference, never as a pointer that may be null: on this target the null of the stack's address space is
+   not address 0, the test against it survives inlining and keeps the whole struct in scratch.) */
+struct ShadeAhead {
+    Surface sf;                /* surface_fill of the hit (valid if surf_ok) */
+    f3 emit_p, emit_n;         /* emitter_point of global triangle emit_tri for this vertex's (xi.x, xi.y) */
+    uint32_t emit_tri;         /* kNoHit: nothing fetched */
+    bool surf_ok;
+};
+NORI_HD void shade_ahead_none(ShadeAhead &a) { a.surf_ok = false; a.emit_tri = kNoHit; }
+
+/* the point of an emitter triangle that the sample xi selects, and the normal there: uniform barycentrics
+   (alpha = 1 - sqrt(1 - xi1), beta = xi2 sqrt(1 - xi1)); interpolated vertex normal if the mesh has normals, else geometric */
+NORI_HD void emitter_point(f2 xi, f3 p0, f3 p1, f3 p2, bool has_normals, f3 n0, f3 n1, f3 n2, f3 &p, f3 &n) {
+    const float su = exact_sqrt(1.0f - xi.x);
+    const float alpha = 1.0f - su, beta = xi.y * su;
+    const float gamma = 1.0f - alpha - beta;
+    p = (alpha * p0 + beta * p1) + gamma * p2;
+    if (has_normals) n = normalized((alpha * n0 + beta * n1) + gamma * n2);
+    else n = normalized(cross(p1 - p0, p2 - p0));
+}
+
+/* the emitter triangle the sample (xiE, xiT) selects: uniform emitter, triangle by area (DiscretePDF::sample).
+   Returns the emitter's mesh index; tri = triangle within that mesh. */
+template <class Tab>
+NORI_HD uint32_t emitter_pick(const Tab &tab, uint32_t nE, float xiE, float xiT, MeshRec &m, uint32_t &tri) {
+    uint32_t ei = (uint32_t) (xiE * (float) nE);
+    if (ei > nE - 1) ei = nE - 1;
+    const uint32_t mi = tab.emitter(ei);
+    m = tab.mesh(mi);
+    tri = cdf_sample(tab, m.cdf_offset, m.n_triangles, xiT);
+    return mi;
 }
 
 struct NeeResult {
@@ -67,29 +117,27 @@ struct NeeResult {
 /* Emitter sampling at surface `s`: uniform emitter, triangle by area, uniform
  * barycentrics (alpha = 1 - sqrt(1 - xi1), beta = xi2 sqrt(1 - xi1)).
  * Always consumes 4 random numbers.  Returns true if a shadow ray is needed. */
-NORI_HD bool sample_direct(const DevScene &sc, Rng &rng, const Surface &s, const Frame &fr,
-                           const Bsdf &bsdf, f3 wi, NeeResult &out) {
+template <class Tab>
+NORI_HD bool sample_direct(const DevScene &sc, const Tab &tab, Rng &rng, const Surface &s, const Frame &fr,
+                           const Bsdf &bsdf, f3 wi, NeeResult &out, const ShadeAhead &ahead) {
     const float xiE = rng_next_float(rng);
     const float xiT = rng_next_float(rng);
     const f2 xi = rng_next_2d(rng);
     const uint32_t nE = sc.n_emitters;
     if (nE == 0) return false;
-    uint32_t ei = (uint32_t) (xiE * (float) nE);
-    if (ei > nE - 1) ei = nE - 1;
-    const MeshRec &m = sc.meshes[sc.emitters[ei]];
+    MeshRec m; uint32_t tri;
+    (void) emitter_pick(tab, nE, xiE, xiT, m, tri);
     const float pdfPick = exact_rcp((float) nE);
-    const uint32_t tri = cdf_sample(sc.emitter_cdf + m.cdf_offset, m.n_triangles, xiT);
-    const float su = exact_sqrt(1.0f - xi.x);
-    const float alpha = 1.0f - su, beta = xi.y * su;
-    const float gamma = 1.0f - alpha - beta;
-    const f4 *rec = sc.shade_tris + (size_t) (m.tri_offset + tri) * kShadeQuads;
-    const f3 p0 = xyz(rec[0]), p1 = xyz(rec[1]), p2 = xyz(rec[2]);
-    const f3 p = (alpha * p0 + beta * p1) + gamma * p2;
-    f3 n;
-    if (m.flags & kMeshHasNormals)
-        n = normalized((alpha * xyz(rec[3]) + beta * xyz(rec[4])) + gamma * xyz(rec[5]));
-    else
-        n = normalized(cross(p1 - p0, p2 - p0));
+    const uint32_t gtri = m.tri_offset + tri;
+    f3 p, n;
+    if (ahead.emit_tri == gtri) {      /* the point is here already */
+        p = ahead.emit_p; n = ahead.emit_n;
+    } else {
+        const f4 *rec = sc.shade_tris + (size_t) gtri * kShadeQuads;
+        const bool hn = (m.flags & kMeshHasNormals) != 0u;
+        const f3 z = mk3(0.0f);
+        emitter_point(xi, xyz(rec[0]), xyz(rec[1]), xyz(rec[2]), hn, hn ? xyz(rec[3]) : z, hn ? xyz(rec[4]) : z, hn ? xyz(rec[5]) : z, p, n);
+    }
     const f3 dvec = p - s.p;
     const float dist2 = dot(dvec, dvec);
     const float dist = exact_sqrt(dist2);
@@ -113,12 +161,27 @@ NORI_HD bool sample_direct(const DevScene &sc, Rng &rng, const Surface &s, const
 /* Consume the result of a closest-hit query.  Returns true when the path is
  * complete (st.L is the radiance estimate); otherwise st.ray / st.phase name
  * the next query. */
-template <int INTEG>
-NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, bool found, const f3 d) {
+/* src/accel.cpp:45-96 (surface_fill, rt_trace.h) from the quads of the triangle's shading record: barycentric position, and the
+   interpolated vertex normal if the mesh has normals, else the geometric one */
+NORI_HD void surface_from_record(bool has_normals, float u, float v, f3 p0, f3 p1, f3 p2, f3 n0, f3 n1, f3 n2, Surface &s) {
+    const float b0 = 1.0f - (u + v), b1 = u, b2 = v;
+    s.p = (b0 * p0 + b1 * p1) + b2 * p2;
+    if (has_normals) s.ns = normalized((b0 * n0 + b1 * n1) + b2 * n2);
+    else s.ns = normalized(cross(p1 - p0, p2 - p0));
+}
+
+template <int INTEG, class Tab>
+NORI_HD bool path_on_closest(const DevScene &sc, const Tab &tab, PathState &st, const Hit &hit, bool found, const f3 d, const ShadeAhead &ahead) {
     if (!found) return true;
+    const MeshRec m = tab.mesh(hit.mesh);
     Surface sf;
-    surface_fill(sc, hit, sf, nullptr, nullptr);
-    const MeshRec &m = sc.meshes[hit.mesh];
+    if (ahead.surf_ok) sf = ahead.sf;
+    else {
+        const f4 *rec = sc.shade_tris + (size_t) hit.tri * kShadeQuads;
+        const bool hn = (m.flags & kMeshHasNormals) != 0u;
+        const f3 z = mk3(0.0f);
+        surface_from_record(hn, hit.u, hit.v, xyz(rec[0]), xyz(rec[1]), xyz(rec[2]), hn ? xyz(rec[3]) : z, hn ? xyz(rec[4]) : z, hn ? xyz(rec[5]) : z, sf);
+    }
 
     if (INTEG == INT_NORMALS) {
         st.L = mk3(fabsf(sf.ns.x), fabsf(sf.ns.y), fabsf(sf.ns.z));
@@ -156,7 +219,7 @@ NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, 
         if (emitter && dot(sf.ns, -d) > 0.0f) st.L = st.L + st.T * rad;
         if (bsdf_is_diffuse(bsdf.type)) {
             NeeResult nee;
-            if (!sample_direct(sc, st.rng, sf, fr, bsdf, wi, nee)) return true;
+            if (!sample_direct(sc, tab, st.rng, sf, fr, bsdf, wi, nee, ahead)) return true;
             st.Ld = st.T * nee.Ld;
             st.ray.o = sf.p; st.ray.d = nee.dir; st.ray.mint = kEpsilon; st.ray.maxt = nee.maxt;
             st.phase = PH_SHADOW; st.end_after_shadow = 1;
@@ -203,7 +266,7 @@ NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, 
     bool needShadow = false;
     NeeResult nee;
     if (EMS && bsdf_is_diffuse(bsdf.type)) {
-        needShadow = sample_direct(sc, st.rng, sf, fr, bsdf, wi, nee);
+        needShadow = sample_direct(sc, tab, st.rng, sf, fr, bsdf, wi, nee, ahead);
         if (needShadow) {
             float w = 1.0f;
             if (MIS) w = (nee.pdf_em + nee.pdf_bsdf) > 0.0f ? exact_div(nee.pdf_em, nee.pdf_em + nee.pdf_bsdf) : 0.0f;
@@ -231,6 +294,14 @@ NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, 
     st.ray.d = st.cont_d; st.ray.maxt = kInf;
     st.phase = PH_CLOSEST;
     return false;
+}
+
+/* (every engine but wf_shade: the tables behind DevScene's pointers, nothing fetched ahead) */
+template <int INTEG>
+NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, bool found, const f3 d) {
+    const SceneTables tab = {&sc};
+    ShadeAhead none; shade_ahead_none(none);
+    return path_on_closest<INTEG>(sc, tab, st, hit, found, d, none);
 }
 
 /* Consume the result of a shadow query (`o` = origin of the shadow ray, which
