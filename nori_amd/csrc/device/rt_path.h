@@ -48,8 +48,7 @@ NORI_HD void path_begin(PathState &st, const RayIn &camRay) {
 /* Where the small per-scene tables -- mesh records, the emitter list, the emitters' triangle CDFs -- are read from.  This one
    goes through DevScene's own pointers (global memory; every engine and twin).  wf_shade keeps a copy of the tables in LDS and
    reads it with LDS instructions (shade_tables.h, LdsTables): a load through a generic pointer is a FLAT instruction, which
-   counts as a vector-memory AND an LDS access and forces the wave to drain everything it has in flight -- the records wf_shade
-   requests ahead included. */
+   counts as a vector-memory AND an LDS access and makes the wave wait for everything it has in flight of either kind. */
 struct SceneTables {
     const DevScene *sc;
     NORI_HD MeshRec mesh(uint32_t i) const { return sc->meshes[i]; }
@@ -69,20 +68,6 @@ NORI_HD uint32_t cdf_sample(const Tab &tab, uint32_t first, uint32_t n, float v)
     uint32_t index = lo > 0 ? lo - 1 : 0;
     return index < n - 1 ? index : n - 1;
 }
-
-/* What wf_shade has worked out AHEAD of a vertex's arithmetic (wavefront.hip): the surface at the hit, and the point its emitter
-   sample lands on.  The emitter triangle's address depends on the path's pcg32 state and depth only, not on what was hit
-   (emitter_pick), so the two shading records are fetched together instead of one after the other's result, and each is reduced to
-   what the vertex needs of it (six registers) as soon as it arrives.  Not ok / another triangle: the record is fetched where it
-   is needed.  (Passed by reference, never as a pointer that may be null: on this target the null of the stack's address space is
-   not address 0, the test against it survives inlining and keeps the whole struct in scratch.) */
-struct ShadeAhead {
-    Surface sf;                /* surface_fill of the hit (valid if surf_ok) */
-    f3 emit_p, emit_n;         /* emitter_point of global triangle emit_tri for this vertex's (xi.x, xi.y) */
-    uint32_t emit_tri;         /* kNoHit: nothing fetched */
-    bool surf_ok;
-};
-NORI_HD void shade_ahead_none(ShadeAhead &a) { a.surf_ok = false; a.emit_tri = kNoHit; }
 
 /* the point of an emitter triangle that the sample xi selects, and the normal there: uniform barycentrics
    (alpha = 1 - sqrt(1 - xi1), beta = xi2 sqrt(1 - xi1)); interpolated vertex normal if the mesh has normals, else geometric */
@@ -119,7 +104,7 @@ struct NeeResult {
  * Always consumes 4 random numbers.  Returns true if a shadow ray is needed. */
 template <class Tab>
 NORI_HD bool sample_direct(const DevScene &sc, const Tab &tab, Rng &rng, const Surface &s, const Frame &fr,
-                           const Bsdf &bsdf, f3 wi, NeeResult &out, const ShadeAhead &ahead) {
+                           const Bsdf &bsdf, f3 wi, NeeResult &out) {
     const float xiE = rng_next_float(rng);
     const float xiT = rng_next_float(rng);
     const f2 xi = rng_next_2d(rng);
@@ -128,16 +113,11 @@ NORI_HD bool sample_direct(const DevScene &sc, const Tab &tab, Rng &rng, const S
     MeshRec m; uint32_t tri;
     (void) emitter_pick(tab, nE, xiE, xiT, m, tri);
     const float pdfPick = exact_rcp((float) nE);
-    const uint32_t gtri = m.tri_offset + tri;
+    const f4 *rec = sc.shade_tris + (size_t) (m.tri_offset + tri) * kShadeQuads;
+    const bool hn = (m.flags & kMeshHasNormals) != 0u;
+    const f3 z = mk3(0.0f);
     f3 p, n;
-    if (ahead.emit_tri == gtri) {      /* the point is here already */
-        p = ahead.emit_p; n = ahead.emit_n;
-    } else {
-        const f4 *rec = sc.shade_tris + (size_t) gtri * kShadeQuads;
-        const bool hn = (m.flags & kMeshHasNormals) != 0u;
-        const f3 z = mk3(0.0f);
-        emitter_point(xi, xyz(rec[0]), xyz(rec[1]), xyz(rec[2]), hn, hn ? xyz(rec[3]) : z, hn ? xyz(rec[4]) : z, hn ? xyz(rec[5]) : z, p, n);
-    }
+    emitter_point(xi, xyz(rec[0]), xyz(rec[1]), xyz(rec[2]), hn, hn ? xyz(rec[3]) : z, hn ? xyz(rec[4]) : z, hn ? xyz(rec[5]) : z, p, n);
     const f3 dvec = p - s.p;
     const float dist2 = dot(dvec, dvec);
     const float dist = exact_sqrt(dist2);
@@ -171,12 +151,11 @@ NORI_HD void surface_from_record(bool has_normals, float u, float v, f3 p0, f3 p
 }
 
 template <int INTEG, class Tab>
-NORI_HD bool path_on_closest(const DevScene &sc, const Tab &tab, PathState &st, const Hit &hit, bool found, const f3 d, const ShadeAhead &ahead) {
+NORI_HD bool path_on_closest(const DevScene &sc, const Tab &tab, PathState &st, const Hit &hit, bool found, const f3 d) {
     if (!found) return true;
     const MeshRec m = tab.mesh(hit.mesh);
     Surface sf;
-    if (ahead.surf_ok) sf = ahead.sf;
-    else {
+    {
         const f4 *rec = sc.shade_tris + (size_t) hit.tri * kShadeQuads;
         const bool hn = (m.flags & kMeshHasNormals) != 0u;
         const f3 z = mk3(0.0f);
@@ -219,7 +198,7 @@ NORI_HD bool path_on_closest(const DevScene &sc, const Tab &tab, PathState &st, 
         if (emitter && dot(sf.ns, -d) > 0.0f) st.L = st.L + st.T * rad;
         if (bsdf_is_diffuse(bsdf.type)) {
             NeeResult nee;
-            if (!sample_direct(sc, tab, st.rng, sf, fr, bsdf, wi, nee, ahead)) return true;
+            if (!sample_direct(sc, tab, st.rng, sf, fr, bsdf, wi, nee)) return true;
             st.Ld = st.T * nee.Ld;
             st.ray.o = sf.p; st.ray.d = nee.dir; st.ray.mint = kEpsilon; st.ray.maxt = nee.maxt;
             st.phase = PH_SHADOW; st.end_after_shadow = 1;
@@ -266,7 +245,7 @@ NORI_HD bool path_on_closest(const DevScene &sc, const Tab &tab, PathState &st, 
     bool needShadow = false;
     NeeResult nee;
     if (EMS && bsdf_is_diffuse(bsdf.type)) {
-        needShadow = sample_direct(sc, tab, st.rng, sf, fr, bsdf, wi, nee, ahead);
+        needShadow = sample_direct(sc, tab, st.rng, sf, fr, bsdf, wi, nee);
         if (needShadow) {
             float w = 1.0f;
             if (MIS) w = (nee.pdf_em + nee.pdf_bsdf) > 0.0f ? exact_div(nee.pdf_em, nee.pdf_em + nee.pdf_bsdf) : 0.0f;
@@ -296,12 +275,11 @@ NORI_HD bool path_on_closest(const DevScene &sc, const Tab &tab, PathState &st, 
     return false;
 }
 
-/* (every engine but wf_shade: the tables behind DevScene's pointers, nothing fetched ahead) */
+/* (every engine but wf_shade: the tables behind DevScene's pointers) */
 template <int INTEG>
 NORI_HD bool path_on_closest(const DevScene &sc, PathState &st, const Hit &hit, bool found, const f3 d) {
     const SceneTables tab = {&sc};
-    ShadeAhead none; shade_ahead_none(none);
-    return path_on_closest<INTEG>(sc, tab, st, hit, found, d, none);
+    return path_on_closest<INTEG>(sc, tab, st, hit, found, d);
 }
 
 /* Consume the result of a shadow query (`o` = origin of the shadow ray, which

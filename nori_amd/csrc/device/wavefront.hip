@@ -60,12 +60,12 @@ constexpr uint32_t kShadeChunk = 4096u;     /* output space a wf_shade workgroup
 /* The state of the paths in flight, one record per path, structure of arrays.  Two copies: wf_shade
    reads copy `cur` at index i and writes the surviving paths COMPACTED into copy `cur ^ 1`, so every
    kernel reads and writes dense, fully coalesced ranges [0, n) however many paths have died. */
-struct WfState {
-    f4 *o;          /* (o.xyz, mint of slot A) */
-    f4 *dA;         /* (d.xyz, maxt) closest-hit ray */
-    f4 *dB;         /* (d.xyz, maxt) shadow ray, mint = epsilon, same origin */
-    f4 *T_eta, *L_pdf, *Ld;
-    uint32_t *flags;   /* F_* | prev_measure << 4 | depth << 8;  0 = no path in this slot */
+struct WfState {      /* wf_records.h: how a record lies in HBM */
+    P3 *o;          /* origin of both rays (their mint is kStoredMint) */
+    f4 *dA;         /* (d.xyz of the continuation ray -- its maxt is inf --, bits: F_* | prev_measure << 4 | depth << 8; 0 = no path in this slot) */
+    f4 *dB;         /* (d.xyz, maxt) shadow ray, same origin */
+    f4 *T_eta, *L_pdf;
+    P3 *Ld;
     uint32_t *sidx;    /* the path's camera sample: index into the film's sample store */
     unsigned long long *rng;
 };
@@ -209,6 +209,15 @@ template <int LEVEL> __device__ __forceinline__ void st_f2(f2 *p, const f2 &v) {
 }
 template <int LEVEL> __device__ __forceinline__ f4 ld_f4(const f4 *p) {
     if (NORI_EXP_NT >= LEVEL) { const v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p)); f4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r; }
+    return *p;
+}
+typedef float v3f_t __attribute__((ext_vector_type(3)));
+template <int LEVEL> __device__ __forceinline__ void st_p3(P3 *p, const P3 &v) {      /* 12 B, 4-B aligned: global_store_dwordx3 */
+    if (NORI_EXP_NT >= LEVEL) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); }
+    else *p = v;
+}
+template <int LEVEL> __device__ __forceinline__ P3 ld_p3(const P3 *p) {
+    if (NORI_EXP_NT >= LEVEL) { P3 r; r.x = __builtin_nontemporal_load(&p->x); r.y = __builtin_nontemporal_load(&p->y); r.z = __builtin_nontemporal_load(&p->z); return r; }
     return *p;
 }
 template <int LEVEL, class T> __device__ __forceinline__ void st_w(T *p, T v) { if (NORI_EXP_NT >= LEVEL) __builtin_nontemporal_store(v, p); else *p = v; }
@@ -542,25 +551,25 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(D
                 }
             } else if (pend || (!trav_active(tv) && rank < avail)) {
                 const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
-                /* a fresh path: flags, origin and both directions are requested together -- one round trip to HBM
-                   instead of two (the direction a path needs first depends on its flags).  A path whose shadow ray
-                   was just answered needs its origin and continuation direction again (32 B; its lane could not
-                   afford to keep them in registers during the shadow walk), not its flags or shadow direction. */
-                uint32_t fl0 = 0u;
+                /* a fresh path: origin and both directions (the flags ride with the continuation direction) are requested
+                   together -- one round trip to HBM instead of two (the direction a path needs first depends on its
+                   flags).  A path whose shadow ray was just answered needs its continuation direction again (16 B; its
+                   lane could not afford to keep it in registers during the shadow walk) -- the origin it still has. */
                 f4 dB0; dB0.x = dB0.y = dB0.z = dB0.w = 0.0f;
-                const f4 o = S.o[i], dA0 = S.dA[i];
-                if (!pend) { dB0 = S.dB[i]; fl0 = S.flags[i]; }
+                P3 o0; o0.x = tv.o.x; o0.y = tv.o.y; o0.z = tv.o.z;      /* a path whose shadow ray was just answered: the origin is still here */
+                const f4 dA0 = S.dA[i];
+                if (!pend) { o0 = S.o[i]; dB0 = S.dB[i]; }
 #if !NORI_EXP_NO_PIN
-                /* (the compiler sinks the loads of `o` and `dA` below the test of the flags -- a second trip to HBM per refill;
-                   naming them as inputs of an empty asm statement pins all four loads in front of it) */
-                asm volatile("" :: "v"(o.x), "v"(dA0.x), "v"(fl0), "v"(dB0.x));
+                /* (the compiler sinks loads below the test of the flags -- a second trip to HBM per refill; naming them as inputs
+                   of an empty asm statement pins all of them in front of it) */
+                asm volatile("" :: "v"(o0.x), "v"(dA0.x), "v"(dB0.x));
 #endif
-                const uint32_t fl = pend ? F_HAS_A : fl0;
+                const uint32_t fl = pend ? F_HAS_A : state_flags(dA0);
                 if (fl & (F_HAS_A | F_HAS_B)) {      /* 0: empty slot */
                     const bool any = (fl & F_HAS_B) != 0u;
                     const f4 d = any ? dB0 : dA0;
-                    RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(d.x, d.y, d.z);
-                    ray.mint = any ? kEpsilon : o.w; ray.maxt = d.w;
+                    RayIn ray; ray.o = mk3(o0.x, o0.y, o0.z); ray.d = mk3(d.x, d.y, d.z);
+                    ray.mint = kStoredMint; ray.maxt = any ? dB0.w : kInf;
                     rid = pend ? (rid & ~2u) : ((i << 2) | ((any && (fl & F_HAS_A)) ? 2u : 0u));
                     trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, any, stack, tv);
                     startedA = !any; startedB = any;
@@ -655,41 +664,14 @@ constexpr int kSB = NORI_SHADE_BLOCK;
 #ifndef NORI_EXP_SHADE
 #define NORI_EXP_SHADE 0
 #endif
-/* How a round of wf_shade gets its inputs (NORI_SHADE_PIPE; A/B: tools/build_variant_fast.sh):
- *
- * A path vertex used to be a chain of dependent trips to memory -- flags -> direction, throughput, pcg32 state -> mesh id ->
- * positions -> normals -> emitter triangle -- each behind an s_waitcnt vmcnt(0), with four waves per SIMD to hide them: the kernel's
- * time followed 18.7 ms + 30 ms / (workgroups per CU) when LDS padding took workgroups away (-DNORI_EXP_SHADE=5, 6;
- * profiles/r4_01_shade_sensitivity.txt).  NORI_SHADE_PIPE = 2 leaves a round ONE exposed trip, the gathers' to L2:
- *   1  the whole state record of round r + 1 goes straight from memory into LDS while round r computes (global_load_lds_dword /
- *      _dwordx4 of gfx950: no register waits for it) -- a wave's 64-lane slice of every field, written and read by that wave only, so
- *      no barrier guards it; round r + 1 reads it into registers at its top;
- *   2  every gather of the vertex leaves at the top of the round, together: the shading record of the triangle that was hit
- *      (positions, and normals if any mesh of the scene has them) and the record of the emitter triangle the vertex's emitter sample
- *      will land on -- that address depends on the path's pcg32 state and depth only, not on what was hit (rt_path.h, emitter_pick);
- *      each record is reduced to what the vertex needs of it (six registers) as soon as it is there;
- *   3  the requests for round r + 1 are issued BEHIND those gathers, and the wait that follows is s_waitcnt vmcnt(<number of
- *      requests>): vector-memory loads return in order, so that is "the gathers are here", whatever the requests are doing.  Gathers,
- *      requests and that wait are ONE block of assembly (shade_fetch): the compiler counts a pending LDS-direct load as reason to
- *      wait for vmcnt(0) at the next use of ANY loaded register (measured: the same kernel with the builtin waits for its requests
- *      right after issuing them), and loads hidden from it must not have their destination registers moved or spilled before
- *      their wait -- inside one statement nothing can come between;
- *   4  no other vector-memory load may sit between the requests and the end of the round (its wait would be vmcnt(0) again):
- *      the per-scene tables are read with LDS instructions (shade_tables.h, LdsTables), not through generic pointers -- a FLAT
- *      load counts as vector memory AND LDS;
- *   5  the workgroup barriers of the compaction wait for LDS only: __syncthreads() is also a fence, i.e. s_waitcnt vmcnt(0) -- a
- *      wave would sit out the trip of its own state STORES to L2, and of the requests, in every round.
- * NORI_SHADE_PIPE = 1: the head of the next round's record (flags, sample index, radiance, hit) requested into registers, the rest
- * when the flags are known (round 3's form); 0: nothing requested ahead.  Both fetch the shading records where rt_path.h needs them. */
-#ifndef NORI_SHADE_PIPE
-#define NORI_SHADE_PIPE 2
-#endif
+/* wf_shade's workgroup barriers wait for LDS only: what the compaction exchanges lives there.  (__syncthreads() is also a fence,
+   i.e. s_waitcnt vmcnt(0): a wave then sits out the trip of its own state STORES to L2 in every round.) */
 #ifndef NORI_SHADE_RAW_BARRIER
 #define NORI_SHADE_RAW_BARRIER 1    /* 0: __syncthreads() */
 #endif
 __device__ __forceinline__ void shade_barrier() {
 #if NORI_SHADE_RAW_BARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      /* the counters exchanged live in LDS: nothing else is shared */
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #else
     __syncthreads();
 #endif
@@ -699,23 +681,26 @@ __device__ __forceinline__ void shade_barrier() {
 template <bool LDSTAB> struct ShadeTab { typedef SceneTables type; static __device__ __forceinline__ type make(const DevScene &sc, uint4 *) { type t = {&sc}; return t; } };
 template <> struct ShadeTab<true> { typedef LdsTables type; static __device__ __forceinline__ type make(const DevScene &sc, uint4 *s_tab) { return shade_tables_copy(sc, s_tab); } };
 
+/* Software pipelining across rounds (NORI_EXP_SHADE_PREFETCH; 0: none): the head of the next round's record (continuation direction
+   with the flags, sample index, radiance, hit) is requested while this round computes, so that a round starts with its first
+   dependent loads already answered (round 3: wf_shade 27.1 -> 26.0 ms).  Going further does not pay -- measured in round 4
+   (profiles/r4_02_shade_pipeline_ab.txt): the WHOLE record of the next round sent straight into LDS (global_load_lds) with every
+   gather of the vertex issued at the top of the round, in one block of assembly so that the only wait of a round was "the gathers
+   are here" (s_waitcnt vmcnt(<requests>)): bit-identical, and 0.5 - 1 ms slower.  The kernel is bound by the volume it streams. */
+#ifndef NORI_EXP_SHADE_PREFETCH
+#define NORI_EXP_SHADE_PREFETCH 1
+#endif
+
 template <int INTEG, bool FIRST, bool LDSTAB>
 __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
 #if NORI_EXP_SHADE == 5 || NORI_EXP_SHADE == 6
-    __shared__ volatile char s_pad[NORI_EXP_SHADE == 5 ? 12 * 1024 : 26 * 1024];
-    s_pad[threadIdx.x * 32] = 0;
+    __shared__ volatile char s_pad[NORI_EXP_SHADE == 5 ? 36 * 1024 : 50 * 1024];
+    s_pad[threadIdx.x * 64] = 0;
 #endif
     const WfState S = b.st[cur], D = b.st[cur ^ 1];
     const uint32_t s_first = bt.s_first, n_spp = bt.n_spp;
     __shared__ uint4 s_tab[LDSTAB ? kShadeTabWords / 4 : 1];
     const typename ShadeTab<LDSTAB>::type tab = ShadeTab<LDSTAB>::make(sc, s_tab);      /* mesh / emitter tables: LDS instead of L2 round trips */
-    /* does any mesh / any emitter carry vertex normals?  (decides, for the whole workgroup, whether the gathers ahead include the
-       normals' quads; tables in global memory: assume so) */
-    bool any_normals = !LDSTAB, any_emitter_normals = !LDSTAB;
-    if (LDSTAB) {
-        for (uint32_t k = 0; k < sc.n_meshes; ++k) any_normals |= (tab.mesh(k).flags & kMeshHasNormals) != 0u;
-        for (uint32_t k = 0; k < sc.n_emitters; ++k) any_emitter_normals |= (tab.mesh(tab.emitter(k)).flags & kMeshHasNormals) != 0u;
-    }
     const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
     const uint32_t rounds_total = (n + kSB - 1) / kSB;
     const uint32_t rounds_per_block = (rounds_total + gridDim.x - 1) / gridDim.x;
@@ -725,197 +710,79 @@ __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur
     bool overflow = false;
     const int wave = (int) (threadIdx.x >> 6), lane = lane_id();
     const uint32_t per_tile = 256u * n_spp;
-    constexpr int kPipe = NORI_SHADE_PIPE;
-    constexpr bool kEmitterSampling = INTEG == INT_WHITTED || INTEG == INT_EMS || INTEG == INT_MIS;
-    const bool ahead_ok = kPipe == 2 && sc.n_triangles != 0u;      /* (an empty scene has no shading record to read) */
-
-    /* ---- the record of a round, requested one round ahead */
-    uint32_t pf_fl = 0u, pf_sidx = 0u; f4 pf_L, pf_h;      /* kPipe == 1: the head of the next round's record */
-    pf_L.x = pf_L.y = pf_L.z = pf_L.w = 0.0f; pf_h = pf_L;
-    if (kPipe == 1 && r0 < r1 && r0 * kSB + threadIdx.x < n) {
+    constexpr bool kPf = !FIRST && NORI_EXP_SHADE_PREFETCH != 0;
+    uint32_t pf_sidx = 0u; f4 pf_d, pf_L, pf_h;
+    pf_d.x = pf_d.y = pf_d.z = pf_d.w = 0.0f; pf_L = pf_h = pf_d;
+    if (kPf && r0 < r1 && r0 * kSB + threadIdx.x < n) {
         const uint32_t i0 = r0 * kSB + threadIdx.x;
-        if (!FIRST) { pf_fl = ld_w<2>(&S.flags[i0]); pf_sidx = ld_w<2>(&S.sidx[i0]); pf_L = ld_f4<2>(&S.L_pdf[i0]); }
-        pf_h = ld_f4<1>(&b.hit[i0]);
+        pf_d = ld_f4<2>(&S.dA[i0]); pf_sidx = ld_w<2>(&S.sidx[i0]); pf_L = ld_f4<2>(&S.L_pdf[i0]); pf_h = ld_f4<1>(&b.hit[i0]);
     }
-    /* kPipe == 2: the record's LDS slots, [field][thread]; a request writes the 64-lane slice of the wave that issues it */
-    enum { PQ_HIT = 0, PQ_L = 1, PQ_D = 2, PQ_T = 3, PQ_LD = 4, PQ_COUNT = 5, PW_FLAGS = 0, PW_SIDX = 1, PW_RNG_LO = 2, PW_RNG_HI = 3, PW_COUNT = 4 };
-    constexpr int kPq = kPipe == 2 ? (FIRST ? 1 : PQ_COUNT) : 1, kPw = (kPipe == 2 && !FIRST) ? PW_COUNT : 1, kPn = kPipe == 2 ? kSB : 1;
-    __shared__ v4f_t s_pq[kPq][kPn];
-    __shared__ uint32_t s_pw[kPw][kPn];
-    const uint32_t wave_first = kPipe == 2 ? (threadIdx.x & ~63u) : 0u;
-    const uint32_t lds_q = (uint32_t) __builtin_amdgcn_readfirstlane((int) lds_address(&s_pq[0][wave_first]));
-    const uint32_t lds_w = (uint32_t) __builtin_amdgcn_readfirstlane((int) lds_address(&s_pw[0][wave_first]));
-    /* requests address their records as (array + first record of this workgroup's range) + 32-bit byte offset: a workgroup's
-       range is rounds_per_block * kSB records, far below 2^32 bytes whatever the batch */
-    const size_t i_first = (size_t) r0 * kSB;
-    const f4 *g_hit = b.hit + i_first, *g_L = S.L_pdf + i_first, *g_D = S.dA + i_first, *g_T = S.T_eta + i_first, *g_LD = S.Ld + i_first;
-    const uint32_t *g_fl = S.flags + i_first, *g_sidx = S.sidx + i_first, *g_rng = reinterpret_cast<const uint32_t *>(S.rng + i_first);
-    const uint32_t n_last = n > 0u ? n - 1u : 0u;
-    const f4 *rec0 = sc.shade_tris;      /* record 0: what lanes without a vertex read (one cache line for all of them) */
-    /* shade_fetch: see the comment at NORI_SHADE_PIPE.  EMIT: also the emitter triangle's positions.  any_normals (uniform): also the
-       hit triangle's normals.  k: record of the NEXT round, relative to i_first.  Returns when the gathers are in their registers. */
-#define NORI_F_S3 "global_load_dwordx4 %[s0], %[sa], off\n\tglobal_load_dwordx4 %[s1], %[sa], off offset:16\n\tglobal_load_dwordx4 %[s2], %[sa], off offset:32\n\t"
-#define NORI_F_S6 NORI_F_S3 "global_load_dwordx4 %[s3], %[sa], off offset:48\n\tglobal_load_dwordx4 %[s4], %[sa], off offset:64\n\tglobal_load_dwordx4 %[s5], %[sa], off offset:80\n\t"
-#define NORI_F_E3 "global_load_dwordx4 %[e0], %[ea], off\n\tglobal_load_dwordx4 %[e1], %[ea], off offset:16\n\tglobal_load_dwordx4 %[e2], %[ea], off offset:32\n\t"
-#define NORI_F_STR2(x) #x
-#define NORI_F_STR(x) NORI_F_STR2(x)
-#define NORI_F_QSTEP "s_add_u32 m0, m0, " NORI_F_STR(NORI_SHADE_BLOCK) "*16\n\t"
-#define NORI_F_WSTEP "s_add_u32 m0, m0, " NORI_F_STR(NORI_SHADE_BLOCK) "*4\n\t"
-#define NORI_F_REQ_FIRST "s_mov_b32 m0, %[lq]\n\tglobal_load_lds_dwordx4 %[o16], %[bh] nt\n\t"
-#define NORI_F_REQ_STATE NORI_F_REQ_FIRST \
-        NORI_F_QSTEP "global_load_lds_dwordx4 %[o16], %[bl] nt\n\t" NORI_F_QSTEP "global_load_lds_dwordx4 %[o16], %[bd] nt\n\t" \
-        NORI_F_QSTEP "global_load_lds_dwordx4 %[o16], %[bt] nt\n\t" NORI_F_QSTEP "global_load_lds_dwordx4 %[o16], %[bld] nt\n\t" \
-        "s_mov_b32 m0, %[lw]\n\tglobal_load_lds_dword %[o4], %[bf] nt\n\t" NORI_F_WSTEP "global_load_lds_dword %[o4], %[bs] nt\n\t" \
-        NORI_F_WSTEP "global_load_lds_dword %[o8], %[br] nt\n\t" NORI_F_WSTEP "global_load_lds_dword %[o8], %[br1] nt\n\t"
-    /* (no instruction offsets: an inst_offset moves the memory address AND the LDS address; the pcg32 state's high dword has its own base) */
-#define NORI_F_OUT3 [s0] "=&v"(q[0]), [s1] "=&v"(q[1]), [s2] "=&v"(q[2]), [s3] "=&v"(q[3]), [s4] "=&v"(q[4]), [s5] "=&v"(q[5])
-#define NORI_F_OUTE , [e0] "=&v"(q[6]), [e1] "=&v"(q[7]), [e2] "=&v"(q[8])
-#define NORI_F_IN [sa] "v"(sa), [ea] "v"(ea), [o16] "v"(k * 16u), [o8] "v"(k * 8u), [o4] "v"(k * 4u), [lq] "s"(lds_q), [lw] "s"(lds_w), \
-        [bh] "s"(g_hit), [bl] "s"(g_L), [bd] "s"(g_D), [bt] "s"(g_T), [bld] "s"(g_LD), [bf] "s"(g_fl), [bs] "s"(g_sidx), [br] "s"(g_rng), [br1] "s"(g_rng + 1)
-#define NORI_F_ASM(GATHERS, REQ, N, OUTS) asm volatile("s_waitcnt lgkmcnt(0)\n\t" GATHERS REQ "s_waitcnt vmcnt(" N ")" : OUTS : NORI_F_IN : "scc", "memory")
-    auto shade_fetch = [&](v4f_t (&q)[9], const f4 *sa, const f4 *ea, uint32_t k, bool with_normals) {
-        if constexpr (kPipe == 2) {
-            if constexpr (kEmitterSampling) {
-                if constexpr (FIRST) { if (with_normals) NORI_F_ASM(NORI_F_S6 NORI_F_E3, NORI_F_REQ_FIRST, "1", NORI_F_OUT3 NORI_F_OUTE); else NORI_F_ASM(NORI_F_S3 NORI_F_E3, NORI_F_REQ_FIRST, "1", NORI_F_OUT3 NORI_F_OUTE); }
-                else { if (with_normals) NORI_F_ASM(NORI_F_S6 NORI_F_E3, NORI_F_REQ_STATE, "9", NORI_F_OUT3 NORI_F_OUTE); else NORI_F_ASM(NORI_F_S3 NORI_F_E3, NORI_F_REQ_STATE, "9", NORI_F_OUT3 NORI_F_OUTE); }
-            } else {
-                if constexpr (FIRST) { if (with_normals) NORI_F_ASM(NORI_F_S6, NORI_F_REQ_FIRST, "1", NORI_F_OUT3); else NORI_F_ASM(NORI_F_S3, NORI_F_REQ_FIRST, "1", NORI_F_OUT3); }
-                else { if (with_normals) NORI_F_ASM(NORI_F_S6, NORI_F_REQ_STATE, "9", NORI_F_OUT3); else NORI_F_ASM(NORI_F_S3, NORI_F_REQ_STATE, "9", NORI_F_OUT3); }
-            }
-        }
-    };
-    auto quad = [&](int f) { const v4f_t v = s_pq[kPipe == 2 ? f : 0][kPipe == 2 ? threadIdx.x : 0]; f4 q; q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w; return q; };
-    auto q3 = [](const v4f_t &v) { return mk3(v.x, v.y, v.z); };
-    if (kPipe == 2 && r0 < r1) {      /* the first round's record: requested like any other (the gathers of the call read record 0 and are dropped) */
-        v4f_t q[9];
-        shade_fetch(q, rec0, rec0, min(r0 * kSB + threadIdx.x, n_last) - (uint32_t) i_first, false);
-    }
-
     for (uint32_t r = r0; r < r1; ++r) {
         const uint32_t i = r * kSB + threadIdx.x;
-        const bool live = i < n;
         bool survive = false;
-        /* ---- this round's record as far as it was requested ahead */
-        uint32_t c_fl = pf_fl, c_sidx = pf_sidx; f4 c_L = pf_L, c_h = pf_h, c_d = pf_L, c_t = pf_L, c_ld = pf_L;
-        unsigned long long c_rng = 0ull;
-        if (kPipe == 1 && r + 1u < r1 && i + kSB < n) {
-            if (!FIRST) { pf_fl = ld_w<2>(&S.flags[i + kSB]); pf_sidx = ld_w<2>(&S.sidx[i + kSB]); pf_L = ld_f4<2>(&S.L_pdf[i + kSB]); }
-            pf_h = ld_f4<1>(&b.hit[i + kSB]);
+        const uint32_t c_sidx = pf_sidx; const f4 c_d = pf_d, c_L = pf_L, c_h = pf_h;
+        if (kPf && r + 1u < r1 && i + kSB < n) {
+            pf_d = ld_f4<2>(&S.dA[i + kSB]); pf_sidx = ld_w<2>(&S.sidx[i + kSB]); pf_L = ld_f4<2>(&S.L_pdf[i + kSB]); pf_h = ld_f4<1>(&b.hit[i + kSB]);
         }
-        if (kPipe == 2) {
-            /* the requests of the previous round (and, with them, its stores) have landed: nothing told the compiler about them */
-            asm volatile("s_waitcnt vmcnt(0)" :: "s"(lds_q), "s"(lds_w) : "memory");
-            c_h = quad(PQ_HIT);
-            if (!FIRST) {
-                c_fl = s_pw[PW_FLAGS][kPipe == 2 ? threadIdx.x : 0]; c_sidx = s_pw[PW_SIDX][kPipe == 2 ? threadIdx.x : 0];
-                c_rng = (unsigned long long) s_pw[PW_RNG_LO][kPipe == 2 ? threadIdx.x : 0] | ((unsigned long long) s_pw[PW_RNG_HI][kPipe == 2 ? threadIdx.x : 0] << 32);
-                c_L = quad(PQ_L); c_d = quad(PQ_D); c_t = quad(PQ_T); c_ld = quad(PQ_LD);
-            }
-        }
-        /* ---- what the vertex starts from: state from HBM, or -- first vertex -- recomputed from the sample index */
-        uint32_t fl = 0u, sidx = 0u; f4 L4, d4, t4; Rng rng0; rng0.state = 0; rng0.inc = 0;
-        L4.x = L4.y = L4.z = L4.w = 0.0f; d4 = L4; t4 = L4;
-        if (live) {
+        f4 n_o, n_dA, n_dB, n_T, n_L, n_Ld;
+        uint32_t n_fl = 0u, sidx = 0u;
+        unsigned long long n_rng = 0ull;
+        if (i < n) {
+            /* the path's state: from HBM, or -- first vertex -- recomputed from the sample index */
+            uint32_t fl; f4 L4, d4, t4; Rng rng0; rng0.state = 0; rng0.inc = 0;
             if (FIRST) {
                 f2 ps; RayIn cam;
                 fl = first_vertex(sc, bt, i, ps, cam, rng0) ? (F_HAS_A | (2u << 4)) : 0u;      /* prev_measure = discrete, depth 0 */
-                sidx = i;                                          /* L = 0, pdf_mat = 0 */
+                sidx = i;
+                L4.x = L4.y = L4.z = L4.w = 0.0f;                  /* L = 0, pdf_mat = 0 */
                 t4.x = t4.y = t4.z = t4.w = 1.0f;                  /* T = 1, eta = 1 */
-                d4.x = cam.d.x; d4.y = cam.d.y; d4.z = cam.d.z; d4.w = cam.maxt;
+                d4.x = cam.d.x; d4.y = cam.d.y; d4.z = cam.d.z; d4.w = 0.0f;
             } else {
-                fl = kPipe ? c_fl : ld_w<2>(&S.flags[i]);
+                d4 = kPf ? c_d : ld_f4<2>(&S.dA[i]);               /* the continuation direction and, in its w, the flags (wf_records.h) */
+                fl = state_flags(d4);
             }
-        }
-        const bool has = (fl & (F_HAS_A | F_HAS_B)) != 0u;
-        f4 h; h.x = h.y = h.z = 0.0f; h.w = u2f(kMissA);
-        if (has) {
-            if (!FIRST) {
-                if (kPipe) { sidx = c_sidx; L4 = c_L; }
-                else { sidx = ld_w<2>(&S.sidx[i]); L4 = ld_f4<2>(&S.L_pdf[i]); }
-            }
-            h = kPipe ? c_h : ld_f4<1>(&b.hit[i]);
-        }
-        const uint32_t hw = __float_as_uint(h.w);
-        const bool to_shade = has && (fl & F_HAS_A) != 0u;            /* the vertex at the closest hit will be evaluated (F_END_AFTER_B paths have no slot A) */
-        const bool found = to_shade && (hw & kMissA) != kMissA;
-        unsigned long long rng_state = 0ull;
-        const uint64_t rng_inc = ((uint64_t) (s_first + ((sidx % per_tile) >> 8)) << 1u) | 1u;      /* pcg32 stream of this camera sample: inc from the sample index */
-        if (to_shade) {
-            if (FIRST) rng_state = rng0.state;
-            else if (kPipe == 2) { rng_state = c_rng; d4 = c_d; t4 = c_t; }
-            else { rng_state = ld_w<2>(&S.rng[i]); d4 = ld_f4<2>(&S.dA[i]); t4 = ld_f4<2>(&S.T_eta[i]); }
-        }
-        /* ---- kPipe == 2: every gather of the vertex and the requests for the next round, now (shade_fetch) */
-        ShadeAhead ah; shade_ahead_none(ah);
-        uint32_t hit_mesh = kNoHit;
-        if (kPipe == 2) {
-            const bool peek_emitter = kEmitterSampling && sc.n_emitters != 0u;      /* workgroup-uniform */
-            const bool gather = found && ahead_ok;
-            const f4 *sa = gather ? sc.shade_tris + (size_t) (hw & kMissA) * kShadeQuads : rec0, *ea = rec0;
-            f2 e_xi = mk2(0.0f, 0.0f); uint32_t e_tri = kNoHit;
-            if (peek_emitter) {
-                /* the emitter sample of this vertex (rt_path.h: sample_direct draws xiE, xiT, xi first; path_mats / path_ems / path_mis
-                   draw the Russian-roulette number before it from depth 3 on) -- a peek: the stream itself is advanced there.
-                   Emitters with vertex normals (rare) are left to sample_direct. */
-                Rng peek; peek.state = rng_state; peek.inc = rng_inc;
-                if (INTEG != INT_WHITTED && (fl >> 8) >= 3u) (void) rng_next_float(peek);
-                const float xiE = rng_next_float(peek), xiT = rng_next_float(peek);
-                e_xi = rng_next_2d(peek);
-                MeshRec em; uint32_t etri;
-                (void) emitter_pick(tab, sc.n_emitters, xiE, xiT, em, etri);
-                if (gather && !(em.flags & kMeshHasNormals)) { e_tri = em.tri_offset + etri; ea = sc.shade_tris + (size_t) e_tri * kShadeQuads; }
-            }
-            v4f_t q[9];
-            shade_fetch(q, sa, ea, min(r + 1u < r1 ? i + kSB : i, n_last) - (uint32_t) i_first, any_normals);
-            /* each record shrinks to what the vertex needs of it */
-            if (peek_emitter) {
-                const f3 z = mk3(0.0f);
-                emitter_point(e_xi, q3(q[6]), q3(q[7]), q3(q[8]), false, z, z, z, ah.emit_p, ah.emit_n);
-                ah.emit_tri = e_tri;
-            }
-            if (gather) {
-                hit_mesh = __float_as_uint(q[0].w);      /* the mesh comes with the shading record's first quad (wf_records.h, hit_unpack) */
-                const bool hn = any_normals && (tab.mesh(hit_mesh).flags & kMeshHasNormals) != 0u;
-                surface_from_record(hn, h.y, h.z, q3(q[0]), q3(q[1]), q3(q[2]), q3(q[3]), q3(q[4]), q3(q[5]), ah.sf);
-                ah.surf_ok = true;
-            }
-        }
-        if (found && hit_mesh == kNoHit) hit_mesh = f2u(sc.shade_tris[(size_t) (hw & kMissA) * kShadeQuads].w);
-        f4 n_o, n_dA, n_dB, n_T, n_L, n_Ld;
-        uint32_t n_fl = 0u;
-        unsigned long long n_rng = 0ull;
-        if (has) {
-            bool done = false;
+            if (fl & (F_HAS_A | F_HAS_B)) {
+                if (!FIRST) {
+                    if (kPf) { sidx = c_sidx; L4 = c_L; }
+                    else { sidx = ld_w<2>(&S.sidx[i]); L4 = ld_f4<2>(&S.L_pdf[i]); }
+                }
+                const f4 h = (FIRST || !kPf) ? ld_f4<1>(&b.hit[i]) : c_h;
+                const uint32_t hw = __float_as_uint(h.w);
+                bool done = false;
 #if NORI_EXP_SHADE == 1
-            if (!FIRST) { const f4 x = ld_f4<2>(&S.o[i]); asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
+                if (!FIRST) { const f4 x = ld_f4<2>(&S.dB[i]); asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
 #elif NORI_EXP_SHADE == 3
-            { float x = h.x; asm volatile(NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") : "+v"(x)); }
+                { float x = h.x; asm volatile(NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") : "+v"(x)); }
 #elif NORI_EXP_SHADE == 4
-            if ((hw & kMissA) != kMissA) { const f4 x = sc.shade_tris[(size_t) (hw & kMissA) * kShadeQuads + 5]; asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
+                if ((hw & kMissA) != kMissA) { const f4 x = sc.shade_tris[(size_t) (hw & kMissA) * kShadeQuads + 5]; asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
 #endif
-            if (fl & F_HAS_B) {                       /* path_on_shadow: add the emitter sample if unoccluded */
-                if (!(hw & kOccludedB)) {
-                    const f4 ld = kPipe == 2 ? c_ld : ld_f4<2>(&S.Ld[i]);
-                    L4.x = L4.x + ld.x; L4.y = L4.y + ld.y; L4.z = L4.z + ld.z;
+                if (fl & F_HAS_B) {                       /* path_on_shadow: add the emitter sample if unoccluded */
+                    if (!(hw & kOccludedB)) {
+                        const P3 ld = ld_p3<2>(&S.Ld[i]);
+                        L4.x = L4.x + ld.x; L4.y = L4.y + ld.y; L4.z = L4.z + ld.z;
+                    }
+                    if (fl & F_END_AFTER_B) done = true;
                 }
-                if (fl & F_END_AFTER_B) done = true;
-            }
-            PathState st;
-            st.L = mk3(L4.x, L4.y, L4.z);
-            if (!done) {
-                Hit hit;
-                hit.t = h.x; hit.u = h.y; hit.v = h.z; hit.tri = found ? (hw & kMissA) : kNoHit; hit.mesh = hit_mesh;
-                vertex_unpack(st, fl, L4, t4, rng_state, rng_inc);
-                done = path_on_closest<INTEG>(sc, tab, st, hit, found, mk3(d4.x, d4.y, d4.z), ah);      /* (ah says itself what it holds) */
+                PathState st;
+                st.L = mk3(L4.x, L4.y, L4.z);
                 if (!done) {
-                    survive = true;
-                    vertex_pack(st, n_o, n_dA, n_dB, n_T, n_L, n_Ld, n_fl);
-                    n_rng = st.rng.state;
+                    if (!FIRST) t4 = ld_f4<2>(&S.T_eta[i]);
+                    Hit hit; bool found;
+                    hit_unpack(sc, h, hit, found);
+                    /* pcg32 stream of this camera sample: inc from the sample index, state from HBM */
+                    const uint32_t sl = (sidx % per_tile) >> 8;
+                    vertex_unpack(st, fl, L4, t4, FIRST ? rng0.state : ld_w<2>(&S.rng[i]), ((uint64_t) (s_first + sl) << 1u) | 1u);
+                    done = path_on_closest<INTEG>(sc, tab, st, hit, found, mk3(d4.x, d4.y, d4.z));
+                    if (!done) {
+                        survive = true;
+                        vertex_pack(st, n_o, n_dA, n_dB, n_T, n_L, n_Ld, n_fl);
+                        n_rng = st.rng.state;
+                    }
                 }
-            }
-            if (done) {
-                f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 0.0f;
-                st_f4<2>(&b.samp_L[sidx], out);
+                if (done) {
+                    f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 0.0f;
+                    st_f4<2>(&b.samp_L[sidx], out);
+                }
             }
         }
         /* compaction: rank of this survivor among the workgroup's survivors of the round */
@@ -938,19 +805,21 @@ __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur
             if (new_base + want > b.capacity) overflow = true;
         }
         if (survive && !overflow) {
+            /* the record as it lies in HBM (wf_records.h): 100 B; the flags ride with the continuation direction, which is
+               therefore always written */
             const uint32_t j = off < room ? out_base + out_used + off : new_base + (off - room);
-            st_f4<2>(&D.o[j], n_o); st_f4<2>(&D.T_eta[j], n_T); st_f4<2>(&D.L_pdf[j], n_L);
-            st_w<2>(&D.flags[j], n_fl); st_w<2>(&D.rng[j], n_rng); st_w<2>(&D.sidx[j], sidx);
-            if (n_fl & F_HAS_A) st_f4<2>(&D.dA[j], n_dA);
-            if (n_fl & F_HAS_B) { st_f4<2>(&D.dB[j], n_dB); st_f4<2>(&D.Ld[j], n_Ld); }
+            st_p3<2>(&D.o[j], p3_of(n_o)); st_f4<2>(&D.T_eta[j], n_T); st_f4<2>(&D.L_pdf[j], n_L);
+            st_f4<2>(&D.dA[j], state_dA(n_dA, n_fl, (n_fl & F_HAS_A) != 0u)); st_w<2>(&D.rng[j], n_rng); st_w<2>(&D.sidx[j], sidx);
+            if (n_fl & F_HAS_B) { st_f4<2>(&D.dB[j], n_dB); st_p3<2>(&D.Ld[j], p3_of(n_Ld)); }
 #if NORI_EXP_SHADE == 2
-            st_f4<2>(&S.o[j], n_o);      /* (nobody reads S.o in this kernel) */
+            st_f4<2>(&S.dB[j], n_o);      /* (nobody reads S.dB in this kernel) */
 #endif
         }
         if (c > room) { out_base = new_base; out_used = c - room; out_len = want; }
         else out_used += c;
     }
-    for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kSB) D.flags[out_base + k] = 0u;
+    /* what is left of the last chunk holds no path: flags 0 */
+    for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kSB) { f4 z; z.x = z.y = z.z = z.w = 0.0f; D.dA[out_base + k] = z; }
     if (overflow && threadIdx.x == 0) b.ctr[C_OVERFLOW] = 1u;
 }
 
@@ -971,10 +840,13 @@ __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, W
     uint32_t nClosest = 0, nShadow = 0;
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
     for (uint32_t i = blockIdx.x * kB + threadIdx.x; i < n; i += gridDim.x * kB) {
-        uint32_t fl = S.flags[i];
+        f4 dA = S.dA[i];
+        uint32_t fl = state_flags(dA);
         if (!(fl & (F_HAS_A | F_HAS_B))) continue;
         const uint32_t sidx = S.sidx[i];
-        f4 o = S.o[i], dA = S.dA[i], dB = S.dB[i], T = S.T_eta[i], L = S.L_pdf[i], Ld = S.Ld[i];
+        f4 o, dB = S.dB[i], T = S.T_eta[i], L = S.L_pdf[i], Ld;
+        { const P3 o3 = S.o[i], l3 = S.Ld[i]; o.x = o3.x; o.y = o3.y; o.z = o3.z; o.w = kStoredMint; Ld.x = l3.x; Ld.y = l3.y; Ld.z = l3.z; Ld.w = 0.0f; }
+        dA.w = kInf;      /* (the stored w was the flags: a stored continuation ray reaches to infinity, wf_records.h) */
         unsigned long long rng_state = S.rng[i];
         const uint64_t inc = ((uint64_t) (bt.s_first + ((sidx % per_tile) >> 8)) << 1u) | 1u;
         while (true) {
@@ -1050,7 +922,7 @@ template <class T> std::string pool_alloc(Pool &pool, T **out, size_t count) {
 }
 
 /* bytes of path state per record: two copies of the SoA state + the hit record */
-constexpr size_t kStateBytesPerRecord = 2 * (6 * sizeof(f4) + 2 * sizeof(uint32_t) + sizeof(unsigned long long)) + sizeof(f4);
+constexpr size_t kStateBytesPerRecord = 2 * (4 * sizeof(f4) + 2 * sizeof(P3) + sizeof(uint32_t) + sizeof(unsigned long long)) + sizeof(f4);
 
 std::string ensure_pool(Pool &pool, size_t records) {
     if (pool.capacity >= records) return std::string();
@@ -1061,7 +933,7 @@ std::string ensure_pool(Pool &pool, size_t records) {
     for (int k = 0; k < 2; ++k) {
         A(st[k].o, records); A(st[k].dA, records); A(st[k].dB, records);
         A(st[k].T_eta, records); A(st[k].L_pdf, records); A(st[k].Ld, records);
-        A(st[k].flags, records); A(st[k].sidx, records); A(st[k].rng, records);
+        A(st[k].sidx, records); A(st[k].rng, records);
     }
     A(hit, records);
     A(ctr, (size_t) 2 * C_COUNT); A(stats, (size_t) 2 * S_COUNT);
@@ -1221,7 +1093,7 @@ static WfBuf slice(const WfBuf &b, size_t off, size_t records, int k) {
     for (int c = 0; c < 2; ++c) {
         WfState &t = v.st[c];
         t.o += off; t.dA += off; t.dB += off; t.T_eta += off; t.L_pdf += off; t.Ld += off;
-        t.flags += off; t.sidx += off; t.rng += off;
+        t.sidx += off; t.rng += off;
     }
     v.hit += off;
     v.ctr += (size_t) k * C_COUNT; v.stats += (size_t) k * S_COUNT;

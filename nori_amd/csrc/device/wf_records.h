@@ -66,4 +66,22 @@ NORI_HD void vertex_pack(const PathState &st, f4 &o, f4 &dA, f4 &dB, f4 &T, f4 &
     L.x = st.L.x; L.y = st.L.y; L.z = st.L.z; L.w = st.pdf_mat;
 }
 
+/* ---- how a path's record lies in HBM (wavefront.hip, WfState).  Two facts of rt_path.h shrink it: every stored ray leaves a
+   surface with mint = kEpsilon, and every stored continuation ray has maxt = inf (only the camera ray differs, and the first
+   vertex is never stored) -- so neither is kept, the origin and the emitter sample are three floats, and the word freed next
+   to the continuation direction carries the path flags, which both kernels that read the direction need:
+       o    12 B  origin (both rays)                       dA   16 B  (continuation direction, bits: path flags) -- always written
+       dB   16 B  (shadow direction, maxt) if F_HAS_B      Ld   12 B  emitter sample added if the shadow ray is unoccluded
+       T_eta, L_pdf 16 B each, sidx 4 B, rng 8 B                      = 100 B per record and copy (round 3: 112)
+   wf_extend reads o + dA + dB = 44 B per path (+ dA again after the shadow ray: 16 B -- the origin is still in its registers;
+   round 3: 52 + 32), wf_shade reads 88 B and writes 100 (96 / 112). */
+struct P3 { float x, y, z; };
+NORI_HD P3 p3_of(const f4 &v) { P3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
+NORI_HD f4 state_dA(const f4 &dA, uint32_t fl, bool has_a) {      /* what is stored for the continuation ray: direction (or zeros) + flags */
+    f4 r; r.x = has_a ? dA.x : 0.0f; r.y = has_a ? dA.y : 0.0f; r.z = has_a ? dA.z : 0.0f; r.w = u2f(fl);
+    return r;
+}
+NORI_HD uint32_t state_flags(const f4 &stored_dA) { return f2u(stored_dA.w); }
+constexpr float kStoredMint = kEpsilon;      /* of every stored ray */
+
 } // namespace nrt

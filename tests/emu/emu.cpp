@@ -179,6 +179,11 @@ static f3 run_path_records(const DevScene &sc, const RayIn &cam, uint64_t rng_st
         if (done) break;
         vertex_pack(st, o, dA, dB, T, L, Ld, fl);
         rng_state = st.rng.state;
+        /* ... and through HBM as wf_shade stores it and wf_extend / wf_shade load it (wf_records.h): the origin and the emitter
+           sample as three floats, mint / maxt of the continuation ray not at all, the flags in the continuation direction's w */
+        { const f4 stored = state_dA(dA, fl, (fl & F_HAS_A) != 0u); const P3 o3 = p3_of(o), l3 = p3_of(Ld);
+          fl = state_flags(stored); dA = stored; dA.w = kInf;
+          o.x = o3.x; o.y = o3.y; o.z = o3.z; o.w = kStoredMint; Ld.x = l3.x; Ld.y = l3.y; Ld.z = l3.z; Ld.w = 0.0f; }
     }
     return mk3(L.x, L.y, L.z);
 }
