@@ -2,7 +2,7 @@
  * film.h -- ImageBlock on the device: sample store, filtered splat, block merge.
  *
  * Both render engines finish a camera sample by storing (pixelSample, radiance)
- * -- 24 B -- into a sample store in HBM laid out tile-major:
+ * -- 20 B -- into a sample store in HBM laid out tile-major:
  *     index = (tile_ordinal * n_spp + sample_in_launch) * 256 + pixel_in_tile
  * (pixel_in_tile uses the 8x8-quad numbering of film_tile_pixel).  Then
  *   film_gather   one workgroup per tile: ImageBlock::put(pos, value)
@@ -37,7 +37,7 @@ namespace nrt {
 
 struct FilmStore {
     f2 *pos = nullptr;          /* pixelSample */
-    f4 *L = nullptr;            /* radiance rgb, w unused */
+    P3 *L = nullptr;            /* radiance rgb, 12 B apart */
     size_t capacity = 0;        /* samples */
     float *tile_acc = nullptr;  /* n_tiles x n_parts x tile_w^2 x 4 */
     uint32_t n_parts = 1;       /* workgroups per tile in film_gather: each sums its share of the samples per pixel

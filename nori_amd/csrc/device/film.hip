@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
             float bpx = 0.0f, bpy = 0.0f;
             if (live) {
                 const f2 p = st.pos[idx];
-                L = st.L[idx];
+                { const P3 l3 = st.L[idx]; L.x = l3.x; L.y = l3.y; L.z = l3.z; }
                 ok = color_valid(mk3(L.x, L.y, L.z));
                 if (!ok) { ++invalid; L.x = L.y = L.z = 0.0f; }
                 bpx = p.x - 0.5f - (float) (bx0 - border);
@@ -104,9 +104,14 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
                 const float *wy_row = s_wy[m];
                 for (int k = k_lo[o]; k <= k_hi[o]; ++k) {
                     const int r = row - k;
-                    /* Color4f(value) * wx * wy, left to right (block.cpp:88-90): (L * wx) * wy per channel, W = (1 * wx) * wy */
-                    const float wx = s_wx[k][r], wy = wy_row[r];
-                    acc[o].x += (s_Lr[r] * wx) * wy; acc[o].y += (s_Lg[r] * wx) * wy; acc[o].z += (s_Lb[r] * wx) * wy; acc[o].w += wx * wy;
+                    /* Color4f(value) * wx * wy (block.cpp:88-90) as value * (wx * wy), multiply-add fused: 5 instructions per tap where
+                       the reference's own left-to-right product ((L * wx) * wy per channel, then the add) takes 11 -- this kernel
+                       is bound by the vector ALU.  The fast film does not reproduce the reference's summation ORDER anyway
+                       (film.h): its frames differ from a render in reference order by rounding, ~1e-7 relative either way;
+                       film_order = reference keeps order and products exactly. */
+                    const float w = s_wx[k][r] * wy_row[r];
+                    acc[o].x = __builtin_fmaf(s_Lr[r], w, acc[o].x); acc[o].y = __builtin_fmaf(s_Lg[r], w, acc[o].y);
+                    acc[o].z = __builtin_fmaf(s_Lb[r], w, acc[o].z); acc[o].w += w;
                 }
             }
         }
@@ -187,7 +192,7 @@ __global__ __launch_bounds__(kB) void film_block_reference_kernel(int width, int
                    by the isValid() guard (:63-67) is given weight 0 and radiance 0 -- adding (0 * 0) * wy = +0 leaves the
                    accumulator's bits alone (it can never be -0), exactly as skipping it does */
                 auto term = [&](size_t idx, float4 &a) {
-                    f4 L = st.L[idx];
+                    f4 L; { const P3 l3 = st.L[idx]; L.x = l3.x; L.y = l3.y; L.z = l3.z; L.w = 0.0f; }
                     const f2 p = st.pos[idx];
                     const bool ok = color_valid(mk3(L.x, L.y, L.z));
                     if (centre && !ok) ++invalid;
@@ -262,7 +267,7 @@ __global__ __launch_bounds__(kB) void film_block_reference_staged_kernel(int wid
                     const int lx = px % kTile, ly = py % kTile;
                     const uint32_t pix = (uint32_t) ((((lx >> 3) | ((ly >> 3) << 1)) << 6) | ((lx & 7) | ((ly & 7) << 3)));      /* inverse of film_tile_pixel */
                     const size_t idx = (size_t) tile * n_spp * 256u + pix + (size_t) (c0 + (uint32_t) sl) * 256u;
-                    const f4 L = st.L[idx];
+                    f4 L; { const P3 l3 = st.L[idx]; L.x = l3.x; L.y = l3.y; L.z = l3.z; L.w = 0.0f; }
                     const f2 p = st.pos[idx];
                     const bool ok = color_valid(mk3(L.x, L.y, L.z));
                     if (j == 0 && !ok) ++invalid;              /* every sample is staged once with j == 0 */
@@ -397,7 +402,7 @@ std::string film_prepare(FilmStore &g_film, size_t n_samples, size_t n_sel_tiles
         if (g_film.L) (void) hipFree(g_film.L);
         g_film.pos = nullptr; g_film.L = nullptr; g_film.capacity = 0;
         FILM_TRY(hipMalloc((void **) &g_film.pos, std::max<size_t>(n_samples, 1) * sizeof(f2)));
-        FILM_TRY(hipMalloc((void **) &g_film.L, std::max<size_t>(n_samples, 1) * sizeof(f4)));
+        FILM_TRY(hipMalloc((void **) &g_film.L, std::max<size_t>(n_samples, 1) * sizeof(P3)));
         g_film.capacity = n_samples;
     }
     /* enough workgroups to fill the chip even when this GPU owns few tiles */

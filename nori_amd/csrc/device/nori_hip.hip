@@ -153,10 +153,10 @@ __global__ __launch_bounds__(kBlock, NORI_RENDER_MIN_WAVES) void render_kernel(D
                 else done = path_on_closest<INTEG>(sc, st, tv.hit, tv.hit.tri != kNoHit, tv.d);
                 if (done) {
                     /* block.put(pixelSample, value), src/main.cpp:52: the sample goes to the film's
-                       store (24 B); film_gather applies the reconstruction filter afterwards */
+                       store (20 B); film_gather applies the reconstruction filter afterwards */
                     const size_t idx = ((size_t) sel * args.spp_count + (size_t) (s - 1u - args.spp_begin)) * 256u + (size_t) tid;
                     film.pos[idx] = pixelSample;
-                    f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 0.0f;
+                    P3 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z;
                     film.L[idx] = out;
                     gen = true;
                 }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(64) void render_block_serial_kernel(DevScene sc, ui
                     rng = st.rng;                                  /* the stream goes on where Li left it */
                     const size_t idx = ((size_t) tile * spp + i) * 256u + pix;
                     film.pos[idx] = ps;
-                    f4 L; L.x = st.L.x; L.y = st.L.y; L.z = st.L.z; L.w = 0.0f;
+                    P3 L; L.x = st.L.x; L.y = st.L.y; L.z = st.L.z;
                     film.L[idx] = L;
                     ++nCam;
                 }

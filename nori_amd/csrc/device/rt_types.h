@@ -34,6 +34,7 @@ constexpr int kFilterRes = 32;                 /* include/nori/rfilter.h:12 */
 constexpr int kTile = 16;                      /* NORI_TILE_SIZE */
 
 struct f2 { float x, y; };
+struct P3 { float x, y, z; };      /* three floats as they lie in memory, 12 B apart (f3 is the arithmetic type) */
 struct f3 { float x, y, z; };
 struct alignas(16) f4 { float x, y, z, w; };
 

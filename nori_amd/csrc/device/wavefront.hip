@@ -74,7 +74,7 @@ struct WfBuf {
     WfState st[2];
     f4 *hit;           /* (t, u, v, hit word) written by wf_extend for the paths of copy `cur` */
     f2 *samp_pos;
-    f4 *samp_L;        /* the film's sample store (film.h) */
+    P3 *samp_L;        /* the film's sample store (film.h) */
     uint32_t *ctr;
     unsigned long long *stats;
     uint32_t capacity; /* records per copy */
@@ -780,8 +780,8 @@ __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur
                     }
                 }
                 if (done) {
-                    f4 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z; out.w = 0.0f;
-                    st_f4<2>(&b.samp_L[sidx], out);
+                    P3 out; out.x = st.L.x; out.y = st.L.y; out.z = st.L.z;
+                    st_p3<2>(&b.samp_L[sidx], out);
                 }
             }
         }
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, W
             vertex_pack(st, o, dA, dB, T, L, Ld, fl);
             rng_state = st.rng.state;
         }
-        f4 out; out.x = L.x; out.y = L.y; out.z = L.z; out.w = 0.0f;
+        P3 out; out.x = L.x; out.y = L.y; out.z = L.z;
         b.samp_L[sidx] = out;
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -1065,10 +1065,10 @@ bool wavefront_excursions(unsigned long long out[4], bool reset) {
 #endif
 }
 
-size_t wavefront_bytes_per_path() { return kStateBytesPerRecord + sizeof(f2) + sizeof(f4); }
+size_t wavefront_bytes_per_path() { return kStateBytesPerRecord + sizeof(f2) + sizeof(P3); }
 
 size_t wavefront_held_bytes(const WfEngine *e, const FilmStore &film) {
-    return (e ? e->pool.bytes : 0) + film.capacity * (sizeof(f2) + sizeof(f4));
+    return (e ? e->pool.bytes : 0) + film.capacity * (sizeof(f2) + sizeof(P3));
 }
 
 /* A pipe works through its own list of batches with its own slice of the state pool, on its own
@@ -1139,7 +1139,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     FilmStore film;
     err = film_prepare(film_store, per_pipe * n_pipes, L.n_sel_tiles, L.tile_w, s, film);
     if (!err.empty()) return err;
-    stats.state_bytes = g_pool.bytes + per_pipe * n_pipes * 24;
+    stats.state_bytes = g_pool.bytes + per_pipe * n_pipes * (sizeof(f2) + sizeof(P3));
     WF_TRY(hipMemsetAsync(g_pool.buf.stats, 0, 2 * S_COUNT * sizeof(unsigned long long), s));
 
     for (int k = 0; k < 3; ++k) if (!g_events[k]) WF_TRY(hipEventCreateWithFlags(&g_events[k], hipEventDisableTiming));

@@ -75,7 +75,6 @@ NORI_HD void vertex_pack(const PathState &st, f4 &o, f4 &dA, f4 &dB, f4 &T, f4 &
        T_eta, L_pdf 16 B each, sidx 4 B, rng 8 B                      = 100 B per record and copy (round 3: 112)
    wf_extend reads o + dA + dB = 44 B per path (+ dA again after the shadow ray: 16 B -- the origin is still in its registers;
    round 3: 52 + 32), wf_shade reads 88 B and writes 100 (96 / 112). */
-struct P3 { float x, y, z; };
 NORI_HD P3 p3_of(const f4 &v) { P3 r; r.x = v.x; r.y = v.y; r.z = v.z; return r; }
 NORI_HD f4 state_dA(const f4 &dA, uint32_t fl, bool has_a) {      /* what is stored for the continuation ray: direction (or zeros) + flags */
     f4 r; r.x = has_a ? dA.x : 0.0f; r.y = has_a ? dA.y : 0.0f; r.z = has_a ? dA.z : 0.0f; r.w = u2f(fl);
