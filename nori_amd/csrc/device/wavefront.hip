@@ -826,7 +826,10 @@ __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur
 /* The long tail of a batch: once only a few thousand paths are alive, every wf_extend / wf_shade pair
    is a launch that lasts as long as ONE path vertex takes (~0.1 ms) however few paths there are.
    wf_finish ends it with one launch: each lane takes a path and walks it to its end -- shadow ray,
-   continuation ray, Li vertex, repeat -- the megakernel's loop started from stored path state. */
+   continuation ray, Li vertex, repeat -- the megakernel's loop started from stored path state.
+   (Its lanes run nearly empty -- 6.5 of 64 per instruction -- and that is not what it costs: the launch lasts as long as the
+   LONGEST path, ~1300 vertices through glass at p = 0.99, one after the other.  A kernel that re-compacts a workgroup's paths
+   after every vertex keeps the lanes dense and is no faster: profiles/r4_04_tail_per_vertex_ab.txt.) */
 template <int INTEG>
 __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, WfBatch bt, int count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
