@@ -266,9 +266,10 @@ def main():
         trav_bytes = counted["n_node_tests"] * node_record_bytes + counted["n_tri_tests"] * info["tri_bytes"]
         if engine == "wavefront":
             dom_name = "wf_extend (all launches of one render pass)"
-            # per closest-hit ray 36 B read (flags, origin, direction) + 16 B hit written, +16 B per shadow ray,
-            # first vertex recomputed (-36 B per camera sample)
-            rec_bytes = counted["n_closest_rays"] * 52 + counted["n_shadow_rays"] * 16 - counted["n_camera_samples"] * 36
+            # the path record as wf_extend sees it (wf_records.h): per closest-hit ray 12 B origin + 16 B direction-with-flags read and
+            # the 16-B hit record written; per shadow ray 16 B (its direction, maxt) + the 16-B continuation direction read again
+            # after it; the first vertex is recomputed, not read (-28 B per camera sample)
+            rec_bytes = counted["n_closest_rays"] * 44 + counted["n_shadow_rays"] * 32 - counted["n_camera_samples"] * 28
         else:
             dom_name = "render_kernel (all launches of one render pass)"
             rec_bytes = counted["n_closest_rays"] * 96 + counted["n_camera_samples"] * 24

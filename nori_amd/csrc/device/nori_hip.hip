@@ -410,7 +410,10 @@ struct nori_hip_ctx {
     int engine = -1;                /* -1 auto, 0 megakernel, 1 wavefront */
     int accel_layout = -1;          /* -1 auto (wide from 2^20 triangles), 0 bvh2, 1 bvh4q (wide nodes) */
     bool film_reference = false;    /* film_order = reference: samples added in the reference's own order (film.h) */
-    size_t wavefront_paths = (size_t) 1 << 28;     /* 240 B of state each (two copies) + film: ~80 GB of the 288 GB */
+    /* 216 B of state each (two copies of the 100-B record + the hit record) + 20 B of film: 2^29 paths = 127 GB of the 288 GB.
+       A batch ends with a tail that lasts as long as its longest path (wf_finish: ~19 ms on the pa5 table scene), so fewer,
+       bigger batches are cheaper: the table scene at 2048^2 x 1024 spp is 8 batches instead of the 16 of 2^28 */
+    size_t wavefront_paths = (size_t) 1 << 29;
     /* render-time resources of THIS context (never shared, freed in nori_hip_destroy): the wavefront
        engine's state pool / streams / events and the film's sample store + tile accumulators */
     WfEngine *wf = nullptr;

@@ -257,6 +257,10 @@ template <bool COUNT, class Stack>
 NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, TopNodesP top = nullptr) {
     f4 q0, q1, q2, q3;
     node_fetch(sc, top, tv.node, q0, q1, q2, q3);
+#if defined(__HIP_DEVICE_COMPILE__) && defined(NORI_EXP_WIDE_SENS)
+    /* (experiment: what one more / one fewer vector-memory instruction per wide node step is worth) */
+    if (!(tv.node & kTopBit)) { const f4 x = sc.nodes[(size_t) tv.node * kNodeQuads + (NORI_EXP_WIDE_SENS == 1 ? 3 : 2)]; asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
+#endif
     if (COUNT) cnt.nodes++;
     const uint32_t meta = f2u(q0.w);
     const int l0 = (int) f2u(q3.x), l1 = (int) f2u(q3.y), l2 = (int) f2u(q3.z), l3 = (int) f2u(q3.w);

@@ -5,8 +5,8 @@
  * pcg32 streams, therefore the same radiance per camera sample; what changes is
  * how work is laid out for 64-wide waves.  In the megakernel a lane owns a
  * pixel and, when its path needs shading while its neighbours still traverse,
- * it waits.  Here paths live in HBM (sized for 288 GB: 240 B per path in two
- * state copies, 2^28 paths = 70 GB in flight) and every kernel runs with all lanes doing the SAME kind
+ * it waits.  Here paths live in HBM (sized for 288 GB: 216 B per path -- two state copies of 100 B, wf_records.h, and the
+ * hit record --, up to 2^29 paths = 116 GB in flight) and every kernel runs with all lanes doing the SAME kind
  * of work:
  *
  *   loop until no path is alive (the first pass computes the camera sample of src/main.cpp:41-46

@@ -58,8 +58,9 @@ def test_the_shading_kernels_do_not_spill(wavefront_kernels):
     rows, _ = wavefront_kernels
     for integ in range(7):
         for first in ("true", "false"):
-            k = _find(rows, f"wf_shade<{integ}, {first}>")
-            assert k["vgpr"] <= 128 and k["scratch"] == 0, k
+            for lds_tables in ("true", "false"):      # wf_shade<INTEG, FIRST, LDSTAB>
+                k = _find(rows, f"wf_shade<{integ}, {first}, {lds_tables}>")
+                assert k["vgpr"] <= 128 and k["scratch"] == 0, k
 
 
 def test_the_node_loop_reads_a_node_in_two_loads(wavefront_kernels):

@@ -7,7 +7,7 @@ sc = workloads.load(os.environ.get("WORKLOAD", "pa4-cbox-path_mis"), spp=int(os.
 r = Renderer(0).upload(sc, builder=int(os.environ.get("BUILDER", 0)))
 print(r.accel_info())
 r.set_option("engine", os.environ.get("ENGINE", "wavefront"))
-r.set_option("wavefront_paths", int(os.environ.get("PATHS", 1 << 28)))
+if "PATHS" in os.environ: r.set_option("wavefront_paths", int(os.environ["PATHS"]))
 f = torch.zeros(r.frame_shape(), device="cuda")
 for i in range(int(os.environ.get("REPS", 3))):
     f.zero_(); st = r.render_into(f, tile_mod=int(os.environ.get("TILE_MOD", 1)), count_traversal=bool(int(os.environ.get("COUNT", 0))),
