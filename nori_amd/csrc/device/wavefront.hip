@@ -462,7 +462,7 @@ __device__ __forceinline__ f4 hit_pack_here(const Hit *closest, bool shadow_occl
 #define NORI_PROF_MARK(acc)
 #endif
 template <int STACK, bool SPILL, bool COUNT, bool FIRST, bool WIDE, bool ASM, int BLOCK>
-__global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 6) : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
+__global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename ExtendStack<STACK, SPILL, ASM, BLOCK>::type Stack;
@@ -951,7 +951,7 @@ std::string ensure_pool(Pool &pool, size_t records) {
 #define NORI_EXTEND_BLOCK 1024
 #endif
 constexpr int kExtendBlockBvh2 = NORI_EXTEND_BLOCK, kExtendBlockWide = kB;
-constexpr int kExtendWgsBvh2 = 2048 / NORI_EXTEND_BLOCK, kExtendWgsWide = 6;
+constexpr int kExtendWgsBvh2 = 2048 / NORI_EXTEND_BLOCK, kExtendWgsWide = 7, kExtendWgsWideFirst = 5;
 constexpr size_t kLdsPerCu = 160 * 1024;
 template <int STACK, bool SPILL, bool COUNT, bool FIRST>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, const WfBatch &bt, hipStream_t s) {
@@ -1203,11 +1203,14 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     }
     int per_cu = std::max(1, std::min(2048 / extend_block, (int) (kLdsPerCu / lds_per_wg)));      /* workgroups per CU */
     /* every workgroup of the persistent grid must be resident from the start (a workgroup that starts late owns a
-       static share of the paths and works it off alone): the wide-node kernels are built for 6 waves per SIMD
-       (their first-pass variant for 5: measured 3.47 vs 3.29 Grays/s on the terrain against 5 everywhere) */
+       static share of the paths and works it off alone): the wide-node kernels are built for 7 waves per SIMD, their
+       first-pass variant (camera rays computed in the kernel: 77 - 87 registers) for 5.  (Terrain, 10 M triangles, wf_extend ms per
+       128 spp at 4 / 5 / 6 / 7 / 8 workgroups per CU: 65.7 / 57.8 / 53.9 / 53.6 / 54.2 -- the last two with the first pass still on the
+       same grid; how many records the LDS image holds does not matter there: 113, 40 or none, profiles/r4_07_c5_occupancy.txt.) */
     if (sc.wide) per_cu = std::min(per_cu, kExtendWgsWide);
     if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(2048 / extend_block, std::max(1, atoi(e)));
+    const int extend_grid_first = eng.n_cus * (sc.wide ? std::min(per_cu, kExtendWgsWideFirst) : per_cu);
     const int extend_grid = eng.n_cus * per_cu;
     if (L.stack_depth > 16) {      /* wf_finish keeps 16 entries in LDS */
         const size_t per_pipe_ints = (size_t) (L.stack_depth - 16) * std::max(extend_grid * extend_block, finish_grid * kB), ints = per_pipe_ints * n_pipes;
@@ -1268,7 +1271,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
                 timer.begin(KC_TRACE, P.stream);
-                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, extend_grid, P.bt, P.stream);
+                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, P.first ? extend_grid_first : extend_grid, P.bt, P.stream);
                 WF_TRY(hipGetLastError());      /* a launch that did not fit (LDS, registers) must not pass for an empty pass */
                 timer.end(P.stream);
                 timer.begin(KC_SHADE, P.stream);

@@ -47,9 +47,9 @@ def test_the_production_traversal_kernels_keep_their_register_budget(wavefront_k
     for name, k in rows.items():
         if name.startswith("void wf_extend<") and name.split(">")[0].endswith(", 1024"):
             assert k["vgpr"] <= 64, (name, k)
-    # wide trees: 6 waves per SIMD (5 in the first pass) -- launch_extend sizes the persistent grid for that
+    # wide trees: 7 waves per SIMD (5 in the first pass) -- wavefront_render sizes the persistent grids for that
     k = _find(rows, "wf_extend<16, true, false, false, true, false, 256>")
-    assert k["vgpr"] <= 80 and k["scratch"] == 0, k
+    assert k["vgpr"] <= 72 and k["scratch"] == 0, k      # 7 waves per SIMD
     k = _find(rows, "wf_extend<16, true, false, true, true, false, 256>")
     assert k["vgpr"] <= 96 and k["scratch"] == 0, k
 
