@@ -111,9 +111,10 @@ typedef enum nori_accel_builder {
     NORI_ACCEL_HOST_SAH = 0,   /* binned SAH on the host, uploaded            */
     NORI_ACCEL_GPU_LBVH = 1,   /* built on the device: Morton order + radix tree (1.5 ms per million triangles)   */
     NORI_ACCEL_AUTO = 2,       /* HOST_SAH up to 2^22 triangles (best trees, ~0.25 s per million triangles on 16 cores),
-                                  GPU_PLOC above (32 ms instead of 2.6 s for 10 M triangles; traversal ~15 % slower) */
-    NORI_ACCEL_GPU_PLOC = 3    /* built on the device: Morton order + nearest-neighbour clustering (PLOC, 3-6 ms per
-                                  million triangles); never worse than the radix tree, up to 20 % faster to traverse */
+                                  GPU_PLOC above (78 ms instead of 2.4 s for 10 M triangles; traversal ~10 % slower) */
+    NORI_ACCEL_GPU_PLOC = 3    /* built on the device: Morton order + nearest-neighbour clustering (PLOC, 3 ms per million
+                                  triangles) + two sweeps of treelet restructuring (a wave per treelet, 2 - 3 ms per million
+                                  triangles and sweep); never worse than the radix tree, up to 20 % faster to traverse */
 } nori_accel_builder;
 
 /* ------------------------------------------------------ scene description */

@@ -43,7 +43,9 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cstdlib>
+#include <cstring>
 #include <string>
+#include <vector>
 
 #include "lbvh.h"
 #include "lbvh_steps.h"
@@ -124,6 +126,87 @@ __global__ void k_treelet(PlocNodes nodes, TreeletData td, const f4 *pos, const 
                           uint32_t *visits, uint32_t n) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) treelet_climb(nodes, td, pos, idx, order, pad, tp, visits, n - 2u, k);
+}
+
+/* ---- a WAVE per treelet (Karras & Aila's layout, for 64 lanes).  One thread per treelet spends a sweep in 1.1 KB of scratch per
+   lane and a dynamic programme that 63 lanes of its wave wait for: 340 ms per sweep on 10 M triangles.  Here the lanes of a wave
+   still climb from 64 triangles, but every treelet one of them arrives at as the SECOND visitor is optimised by the whole wave:
+     lane 0      treelet_form (lbvh_steps.h) into the wave's LDS
+     all lanes   the areas of the 2^k - 1 subsets, two per lane
+     all lanes   the dynamic programme, subset size by subset size: the (subset, partition) pairs of a size -- 21, 105, 245, 315, 217, 63
+                 for seven leaves -- are spread over the lanes from a table; a pair's cost goes into the subset's slot by a 64-bit LDS
+                 minimum on (cost bits, rank of the partition in the serial order, partition): 17 passes instead of 966 steps, and the
+                 same winner as the serial loop, which keeps the FIRST of equally cheap partitions
+     lane 0      treelet_rewire
+   Same steps, same arithmetic, same tie rule as treelet_optimize: the tree is the one the CPU harness builds. */
+struct TreeletPair { unsigned char S, P, rank, pad; };
+struct TreeletTable { const TreeletPair *pairs; uint32_t start[8][9]; };      /* pairs of k leaves, subset size s: [start[k][s], start[k][s + 1]) */
+struct TreeletShared {
+    TreeletWork w;
+    float area[1 << kTreeletLeaves], copt[1 << kTreeletLeaves];
+    unsigned long long best[1 << kTreeletLeaves];
+    unsigned char part[1 << kTreeletLeaves];
+    int go;
+};
+
+__device__ void treelet_optimize_wave(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
+                                      TreeletParams tp, const TreeletTable &tab, uint32_t id, TreeletShared &sh, int lane) {
+    if (lane == 0) sh.go = treelet_form(nodes, td, pos, idx, order, pad, tp, id, sh.w) ? 1 : 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (!sh.go) return;                                    /* wave-uniform */
+    const int k = sh.w.k, full = (1 << k) - 1;
+    for (int S = lane + 1; S <= full; S += 64) {
+        sh.area[S] = treelet_subset_area(sh.w, S);
+        sh.best[S] = ~0ull;
+        if ((S & (S - 1)) == 0) { int i = 0; while (i < kTreeletLeaves - 1 && !(S & (1 << i))) ++i; sh.copt[S] = sh.w.lcost[i]; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    for (int s = 2; s <= k; ++s) {
+        for (uint32_t q = tab.start[k][s] + (uint32_t) lane; q < tab.start[k][s + 1]; q += 64u) {
+            const TreeletPair pr = tab.pairs[q];
+            const float c = sh.copt[pr.P] + sh.copt[pr.S ^ pr.P];          /* >= 0: its bits order like the value */
+            atomicMin(&sh.best[pr.S], ((unsigned long long) __float_as_uint(c) << 32) | ((unsigned long long) pr.rank << 8) | pr.P);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+        for (int S = lane + 1; S <= full; S += 64)
+            if (__popc((unsigned) S) == s) {
+                const unsigned long long b = sh.best[S];
+                sh.copt[S] = tp.c_node * sh.area[S] + __uint_as_float((uint32_t) (b >> 32));
+                sh.part[S] = (unsigned char) (b & 0xffu);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0 && sh.copt[full] < coh_ld(&td.cost[id]) * 0.99999f) treelet_rewire(nodes, td, id, sh.w, sh.copt, sh.part);      /* else: leave the subtree as it is */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* by the whole wave: lane 0's (agent-scope) stores are acknowledged before any lane of it arrives at the parent */
+}
+
+constexpr int kTreeletWaves = 4;      /* per workgroup */
+__global__ __launch_bounds__(64 * kTreeletWaves) void k_treelet_wave(PlocNodes nodes, TreeletData td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
+                                                                     TreeletParams tp, TreeletTable tab, uint32_t *visits, uint32_t n) {
+    __shared__ TreeletShared s_sh[kTreeletWaves];
+    TreeletShared &sh = s_sh[threadIdx.x >> 6];
+    const int lane = (int) (threadIdx.x & 63u);
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, root_id = n - 2u;
+    bool active = k < n;
+    uint32_t p = active ? nodes.parent_prim[k] : 0u;
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {
+        /* arrive: the first of a node's two visitors stops, the second -- both subtrees below are finished -- has it optimised.
+           What the other subtree's waves wrote is read at agent scope (coh_ld, lbvh_steps.h) and this wave's own stores are
+           acknowledged before it counts itself in: no cache-wide fence */
+        bool second = false;
+        if (active) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t before = __hip_atomic_fetch_add(&visits[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("" ::: "memory");
+            if (before == 0u) active = false; else second = true;
+        }
+        for (unsigned long long pend = __ballot(second); pend != 0ull; pend &= pend - 1ull) {
+            const uint32_t id = (uint32_t) __shfl((int) p, __ffsll((long long) pend) - 1);
+            treelet_optimize_wave(nodes, td, pos, idx, order, pad, tp, tab, id, sh, lane);
+        }
+        if (active) { if (p == root_id) active = false; else p = coh_ld(&nodes.parent_node[p]); }      /* (the node's own parent is not touched by its treelet) */
+        if (__ballot(active) == 0ull) break;
+    }
 }
 __global__ void k_ploc_leaf_positions(PlocNodes nodes, uint32_t n, const uint32_t *order, uint32_t *leaf_pos, uint32_t *order_out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -318,22 +401,48 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
             if (node_base != n - 1u) return "lbvh: PLOC node count";
             out.ploc_iterations = iterations;
             {   /* treelet restructuring (lbvh_steps.h): one launch per sweep, a thread per triangle climbing the tree */
-                /* two sweeps up to 2^20 triangles, none above (NORI_HIP_TREELET_SWEEPS overrides).  Measured (MI355X, profiles/r3_06_*):
-                   328 k-triangle AO scene: build 40 ms with two sweeps (host SAH: 103 ms), wf_extend 12.0 ms against the host tree's 11.8;
-                   10 M-triangle terrain: every sweep costs 340 ms (one thread per treelet, 1.1 KB of scratch each) and brings wf_extend from
-                   33.5 to 32.6 / 32.7 / 32.2 ms after 1 / 2 / 3 sweeps (host SAH tree: 29.5) -- not worth ten times PLOC's 30 ms.
-                   CPU probe (tools/builder_probe.py), 200 k-triangle terrain, wide nodes: node tests per ray 14.98 / 14.47 / 14.32 / 14.29
-                   after 0 / 1 / 2 / 3 sweeps (host SAH: 13.72); Cornell box, BVH2: 9.31 -> 8.49 (host SAH: 8.77). */
-                int sweeps = n <= (1u << 20) ? 2 : 0;
+                /* two sweeps (NORI_HIP_TREELET_SWEEPS overrides).  Round 3 ran none above 2^20 triangles: a sweep cost 340 ms on the
+                   10 M-triangle terrain.  Round 4 (profiles/r4_09_treelet_wave.txt): a wave per treelet took that to 198 ms -- and showed
+                   that the dynamic programme had not been the cost: every arrival at a node was bracketed by __threadfence(), i.e. a
+                   write-back of the L2 and an invalidation of the L1 (15 M per sweep).  With the tree data read and written at agent
+                   scope instead (coh_ld / coh_st, lbvh_steps.h) and no cache-wide fence: **20 - 28 ms per sweep**, same trees.
+                   10 M triangles, PLOC + 0 / 1 / 2 / 3 / 5 sweeps: build 29 / 49 / 78 / 106 / 162 ms, wf_extend (64 spp) 33.4 / 33.0 / 32.5 /
+                   32.4 / 32.5 ms (host SAH tree, built in 2.4 s: 29.4).  328 k-triangle AO scene: wf_extend 12.0 ms against the host
+                   tree's 11.8; Cornell box, BVH2: node tests per ray 9.31 -> 8.49 (host SAH: 8.77). */
+                int sweeps = 2;
                 if (const char *e = getenv("NORI_HIP_TREELET_SWEEPS")) sweeps = std::max(0, atoi(e));
                 if (sweeps > 0) {
                     Buf t_mn, t_mx, t_cost, t_visits;
                     LB_TRY(t_mn.alloc((size_t) n * 16)); LB_TRY(t_mx.alloc((size_t) n * 16)); LB_TRY(t_cost.alloc((size_t) n * 4)); LB_TRY(t_visits.alloc((size_t) n * 4));
                     TreeletData td{t_mn.as<f4>(), t_mx.as<f4>(), t_cost.as<float>()};
                     TreeletParams tp; tp.c_node = 1.0f; tp.c_tri = 1.0f;
+                    /* the (subset, partition) pairs of the dynamic programme for 3 .. 7 leaves, by subset size, partitions in the serial
+                       loop's order (treelet_first_partition / treelet_next_partition): 1 388 pairs */
+                    std::vector<TreeletPair> pairs;
+                    TreeletTable tab; std::memset(&tab, 0, sizeof(tab));
+                    for (int k = 3; k <= kTreeletLeaves; ++k)
+                        for (int sz = 2; sz <= k + 1; ++sz) {
+                            tab.start[k][sz] = (uint32_t) pairs.size();
+                            if (sz > k) break;
+                            for (int S = 3; S < (1 << k); ++S) {
+                                if (__builtin_popcount((unsigned) S) != sz) continue;
+                                int rank = 0;
+                                for (int P = treelet_first_partition(S); P != 0; P = treelet_next_partition(S, P), ++rank) {
+                                    TreeletPair pr; pr.S = (unsigned char) S; pr.P = (unsigned char) P; pr.rank = (unsigned char) rank; pr.pad = 0;
+                                    pairs.push_back(pr);
+                                }
+                            }
+                        }
+                    Buf t_pairs;
+                    LB_TRY(t_pairs.alloc(pairs.size() * sizeof(TreeletPair)));
+                    LB_TRY(hipMemcpy(t_pairs.p, pairs.data(), pairs.size() * sizeof(TreeletPair), hipMemcpyHostToDevice));
+                    tab.pairs = t_pairs.as<TreeletPair>();
+                    const bool serial = getenv("NORI_HIP_TREELET_SERIAL") != nullptr && atoi(getenv("NORI_HIP_TREELET_SERIAL")) != 0;      /* one thread per treelet (A/B, tests) */
                     for (int sw = 0; sw < sweeps; ++sw) {
                         LB_TRY(hipMemsetAsync(t_visits.p, 0, (size_t) n * 4, 0));
-                        hipLaunchKernelGGL(k_treelet, dim3((n + 63) / 64), dim3(64), 0, 0, pn, td, dev.positions, dev.indices, order, pad, tp, t_visits.as<uint32_t>(), n);
+                        if (serial) hipLaunchKernelGGL(k_treelet, dim3((n + 63) / 64), dim3(64), 0, 0, pn, td, dev.positions, dev.indices, order, pad, tp, t_visits.as<uint32_t>(), n);
+                        else hipLaunchKernelGGL(k_treelet_wave, dim3((n + 64 * kTreeletWaves - 1) / (64 * kTreeletWaves)), dim3(64 * kTreeletWaves), 0, 0, pn, td, dev.positions, dev.indices, order, pad, tp,
+                                                tab, t_visits.as<uint32_t>(), n);
                     }
                     LB_TRY(hipGetLastError());
                     LB_TRY(hipDeviceSynchronize());      /* the buffers go out of scope here */

@@ -232,6 +232,34 @@ constexpr int kTreeletLeaves = 7;
 struct TreeletData { f4 *nmn, *nmx; float *cost; };
 struct TreeletParams { float c_node, c_tri; };
 
+/* How the treelet code reads and writes what OTHER waves of the same launch wrote or will read (links, counts, boxes, costs): on the
+   device as relaxed atomics of agent scope -- loads and stores that go to the level at which all CUs of the GPU agree (sc1), past
+   this CU's L1 and this XCD's L2.  A sweep hands a subtree from the waves that optimised it to the wave that optimises its parent
+   through one counter; with plain accesses that hand-over needs __threadfence() on either side of it, i.e. a write-back of the whole
+   L2 and an invalidation of the L1 per arrival (buffer_wbl2 sc1 / buffer_inv sc1: 15 M of them per sweep on 10 M triangles, most of
+   the 200 - 340 ms a sweep took).  With every shared datum accessed at agent scope there is nothing dirty to write back and nothing
+   stale to invalidate: waiting for the stores' acknowledgements (s_waitcnt vmcnt(0)) before the counter is all the order needed. */
+#if defined(__HIP_DEVICE_COMPILE__)
+template <class T> __device__ __forceinline__ T coh_ld(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T> __device__ __forceinline__ void coh_st(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ f4 coh_ld4(const f4 *p) {
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p);
+    const unsigned long long a = coh_ld(q), b = coh_ld(q + 1);
+    f4 r; r.x = __uint_as_float((uint32_t) a); r.y = __uint_as_float((uint32_t) (a >> 32)); r.z = __uint_as_float((uint32_t) b); r.w = __uint_as_float((uint32_t) (b >> 32));
+    return r;
+}
+__device__ __forceinline__ void coh_st4(f4 *p, const f4 &v) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    coh_st(q, (unsigned long long) __float_as_uint(v.x) | ((unsigned long long) __float_as_uint(v.y) << 32));
+    coh_st(q + 1, (unsigned long long) __float_as_uint(v.z) | ((unsigned long long) __float_as_uint(v.w) << 32));
+}
+#else      /* the CPU harness, and the host pass over the device code */
+template <class T> NORI_HD T coh_ld(const T *p) { return *p; }
+template <class T> NORI_HD void coh_st(T *p, T v) { *p = v; }
+NORI_HD f4 coh_ld4(const f4 *p) { return *p; }
+NORI_HD void coh_st4(f4 *p, const f4 &v) { *p = v; }
+#endif
+
 NORI_HD void treelet_child(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
                            TreeletParams tp, uint32_t child, f3 &mn, f3 &mx, float &cost, uint32_t &count) {
     if (child & kLeafBit) {
@@ -239,74 +267,79 @@ NORI_HD void treelet_child(const PlocNodes &nodes, const TreeletData &td, const 
         mn = xyz(a); mx = xyz(b); count = 1u;
         cost = tp.c_tri * half_area(mn, mx);
     } else {
-        mn = xyz(td.nmn[child]); mx = xyz(td.nmx[child]); count = nodes.count[child]; cost = td.cost[child];
+        mn = xyz(coh_ld4(&td.nmn[child])); mx = xyz(coh_ld4(&td.nmx[child])); count = coh_ld(&nodes.count[child]); cost = coh_ld(&td.cost[child]);
     }
 }
 NORI_HD void treelet_set_parent(const PlocNodes &nodes, uint32_t child, uint32_t parent) {
-    if (child & kLeafBit) nodes.parent_prim[child & ~kLeafBit] = parent; else nodes.parent_node[child] = parent;
+    if (child & kLeafBit) coh_st(&nodes.parent_prim[child & ~kLeafBit], parent); else coh_st(&nodes.parent_node[child], parent);
 }
-/* box and cost of node `id` from its children (first sweep: nothing is known yet), then the optimal treelet below it */
-NORI_HD void treelet_optimize(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
-                              TreeletParams tp, uint32_t id) {
-    uint32_t leaf[kTreeletLeaves], cnt[kTreeletLeaves], inner[kTreeletLeaves];      /* treelet leaves; the inner node ids the treelet owns (inner[0] = id) */
+/* What the optimisation of one treelet works on: its <= 7 leaves (ids, boxes, subtree costs, triangle counts) and the inner node
+   ids it owns (inner[0] = the treelet's root).  Lives on the stack of the one thread that optimises a treelet (treelet_optimize)
+   or in the LDS of the wave that shares the work (lbvh.hip, treelet_optimize_wave): the same three steps either way --
+   treelet_form, the dynamic programme over the subsets of the leaves, treelet_rewire. */
+struct TreeletWork {
+    uint32_t leaf[kTreeletLeaves], cnt[kTreeletLeaves], inner[kTreeletLeaves];
     f3 lmn[kTreeletLeaves], lmx[kTreeletLeaves]; float lcost[kTreeletLeaves];
+    int k, n_inner;
+};
+
+/* box and cost of node `id` from its children (first sweep: nothing is known yet), then its treelet: the node's two children, and
+   while fewer than seven, the inner one of largest area replaced by its children.  False: nothing to optimise (an unbounded box
+   in reach, or two leaves only). */
+NORI_HD bool treelet_form(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
+                          TreeletParams tp, uint32_t id, TreeletWork &w) {
     int k = 2, n_inner = 1;
-    inner[0] = id;
-    leaf[0] = nodes.left[id]; leaf[1] = nodes.right[id];
-    for (int i = 0; i < 2; ++i) treelet_child(nodes, td, pos, idx, order, pad, tp, leaf[i], lmn[i], lmx[i], lcost[i], cnt[i]);
-    bool bounded = lmx[0].x < kBoxInf && lmx[1].x < kBoxInf;
+    w.inner[0] = id;
+    w.leaf[0] = coh_ld(&nodes.left[id]); w.leaf[1] = coh_ld(&nodes.right[id]);
+    for (int i = 0; i < 2; ++i) treelet_child(nodes, td, pos, idx, order, pad, tp, w.leaf[i], w.lmn[i], w.lmx[i], w.lcost[i], w.cnt[i]);
+    const bool bounded = w.lmx[0].x < kBoxInf && w.lmx[1].x < kBoxInf;
     {   /* this node as it stands */
-        const f3 mn = mk3(fminf(lmn[0].x, lmn[1].x), fminf(lmn[0].y, lmn[1].y), fminf(lmn[0].z, lmn[1].z));
-        const f3 mx = mk3(fmaxf(lmx[0].x, lmx[1].x), fmaxf(lmx[0].y, lmx[1].y), fmaxf(lmx[0].z, lmx[1].z));
+        const f3 mn = mk3(fminf(w.lmn[0].x, w.lmn[1].x), fminf(w.lmn[0].y, w.lmn[1].y), fminf(w.lmn[0].z, w.lmn[1].z));
+        const f3 mx = mk3(fmaxf(w.lmx[0].x, w.lmx[1].x), fmaxf(w.lmx[0].y, w.lmx[1].y), fmaxf(w.lmx[0].z, w.lmx[1].z));
         f4 a, b; a.x = mn.x; a.y = mn.y; a.z = mn.z; a.w = 0.0f; b.x = mx.x; b.y = mx.y; b.z = mx.z; b.w = 0.0f;
-        td.nmn[id] = a; td.nmx[id] = b;
-        td.cost[id] = bounded ? tp.c_node * half_area(mn, mx) + (lcost[0] + lcost[1]) : 1e30f;
+        coh_st4(&td.nmn[id], a); coh_st4(&td.nmx[id], b);
+        coh_st(&td.cost[id], bounded ? tp.c_node * half_area(mn, mx) + (w.lcost[0] + w.lcost[1]) : 1e30f);
     }
-    if (!bounded) return;
+    w.k = k; w.n_inner = n_inner;
+    if (!bounded) return false;
     while (k < kTreeletLeaves) {      /* open the inner treelet leaf of largest area */
         int best = -1; float bestArea = -1.0f;
         for (int i = 0; i < k; ++i) {
-            if (leaf[i] & kLeafBit) continue;
-            const float a = half_area(lmn[i], lmx[i]);
+            if (w.leaf[i] & kLeafBit) continue;
+            const float a = half_area(w.lmn[i], w.lmx[i]);
             if (a > bestArea) { bestArea = a; best = i; }
         }
         if (best < 0) break;
-        const uint32_t open = leaf[best];
-        inner[n_inner++] = open;
-        const uint32_t a = nodes.left[open], b = nodes.right[open];
-        leaf[best] = a; leaf[k] = b;
-        treelet_child(nodes, td, pos, idx, order, pad, tp, a, lmn[best], lmx[best], lcost[best], cnt[best]);
-        treelet_child(nodes, td, pos, idx, order, pad, tp, b, lmn[k], lmx[k], lcost[k], cnt[k]);
-        if (!(lmx[best].x < kBoxInf) || !(lmx[k].x < kBoxInf)) return;
+        const uint32_t open = w.leaf[best];
+        w.inner[n_inner++] = open;
+        const uint32_t a = coh_ld(&nodes.left[open]), b = coh_ld(&nodes.right[open]);
+        w.leaf[best] = a; w.leaf[k] = b;
+        treelet_child(nodes, td, pos, idx, order, pad, tp, a, w.lmn[best], w.lmx[best], w.lcost[best], w.cnt[best]);
+        treelet_child(nodes, td, pos, idx, order, pad, tp, b, w.lmn[k], w.lmx[k], w.lcost[k], w.cnt[k]);
+        if (!(w.lmx[best].x < kBoxInf) || !(w.lmx[k].x < kBoxInf)) return false;
         ++k;
     }
-    if (k < 3) return;                  /* two leaves: one topology */
-    /* dynamic programming over the subsets of the k leaves */
-    const int full = (1 << k) - 1;
-    float area[1 << kTreeletLeaves], copt[1 << kTreeletLeaves];
-    unsigned char part[1 << kTreeletLeaves];
-    for (int S = 1; S <= full; ++S) {
-        f3 mn = mk3(kInf), mx = mk3(-kInf);
-        for (int i = 0; i < k; ++i)
-            if (S & (1 << i)) { mn = mk3(fminf(mn.x, lmn[i].x), fminf(mn.y, lmn[i].y), fminf(mn.z, lmn[i].z)); mx = mk3(fmaxf(mx.x, lmx[i].x), fmaxf(mx.y, lmx[i].y), fmaxf(mx.z, lmx[i].z)); }
-        area[S] = half_area(mn, mx);
-    }
-    for (int i = 0; i < k; ++i) copt[1 << i] = lcost[i];
-    for (int S = 3; S <= full; ++S) {
-        if ((S & (S - 1)) == 0) continue;                   /* a single leaf */
-        float best = kInf; int bestP = 0;
-        const int delta = (S - 1) & S;                       /* S without its lowest bit: the partitions P that keep the lowest bit out are all of them once */
-        int P = (-delta) & S;
-        do {
-            const float c = copt[P] + copt[S ^ P];
-            if (c < best) { best = c; bestP = P; }
-            P = (P - delta) & S;
-        } while (P != 0);
-        copt[S] = tp.c_node * area[S] + best;
-        part[S] = (unsigned char) bestP;
-    }
-    if (!(copt[full] < td.cost[id] * 0.99999f)) return;     /* nothing to gain: leave the subtree as PLOC built it */
-    /* rewire: the treelet's inner ids take the subsets of the optimal topology, top down */
+    w.k = k; w.n_inner = n_inner;
+    return k >= 3;                      /* two leaves: one topology */
+}
+
+/* half the surface area of the union of the leaves in subset S */
+NORI_HD float treelet_subset_area(const TreeletWork &w, int S) {
+    f3 mn = mk3(kInf), mx = mk3(-kInf);
+    for (int i = 0; i < w.k; ++i)
+        if (S & (1 << i)) { mn = mk3(fminf(mn.x, w.lmn[i].x), fminf(mn.y, w.lmn[i].y), fminf(mn.z, w.lmn[i].z)); mx = mk3(fmaxf(mx.x, w.lmx[i].x), fmaxf(mx.y, w.lmx[i].y), fmaxf(mx.z, w.lmx[i].z)); }
+    return half_area(mn, mx);
+}
+
+/* The partitions of subset S into two non-empty halves, each once: the halves P that keep S's lowest bit out, in the order
+   first_partition, next_partition, ... until 0.  THE order: among partitions of equal cost the first one wins, here and in the
+   wave's table (lbvh.hip), so that both forms build the same tree. */
+NORI_HD int treelet_first_partition(int S) { const int delta = (S - 1) & S; return (-delta) & S; }
+NORI_HD int treelet_next_partition(int S, int P) { const int delta = (S - 1) & S; return (P - delta) & S; }
+
+/* the treelet's inner ids take the subsets of the optimal topology, top down */
+NORI_HD void treelet_rewire(const PlocNodes &nodes, const TreeletData &td, uint32_t id, const TreeletWork &w, const float *copt, const unsigned char *part) {
+    const int k = w.k, full = (1 << k) - 1;
     int stack_S[kTreeletLeaves]; uint32_t stack_id[kTreeletLeaves]; int sp = 0, used = 1;
     stack_S[sp] = full; stack_id[sp] = id; ++sp;
     while (sp > 0) {
@@ -317,21 +350,48 @@ NORI_HD void treelet_optimize(const PlocNodes &nodes, const TreeletData &td, con
         for (int h = 0; h < 2; ++h) {
             const int T = halves[h];
             if ((T & (T - 1)) == 0) {                        /* one leaf of the treelet */
-                int i = 0; while (!(T & (1 << i))) ++i;
-                child_id[h] = leaf[i];
+                int i = 0; while (i < kTreeletLeaves - 1 && !(T & (1 << i))) ++i;
+                child_id[h] = w.leaf[i];
             } else {
-                child_id[h] = inner[used++];
-                stack_S[sp] = T; stack_id[sp] = child_id[h]; ++sp;
+                child_id[h] = w.inner[used < kTreeletLeaves - 1 ? used : kTreeletLeaves - 1]; ++used;
+                if (sp < kTreeletLeaves) { stack_S[sp] = T; stack_id[sp] = child_id[h]; ++sp; }
             }
             treelet_set_parent(nodes, child_id[h], me);
         }
-        nodes.left[me] = child_id[0]; nodes.right[me] = child_id[1];
+        coh_st(&nodes.left[me], child_id[0]); coh_st(&nodes.right[me], child_id[1]);
         f3 mn = mk3(kInf), mx = mk3(-kInf); uint32_t c = 0u;
         for (int i = 0; i < k; ++i)
-            if (S & (1 << i)) { mn = mk3(fminf(mn.x, lmn[i].x), fminf(mn.y, lmn[i].y), fminf(mn.z, lmn[i].z)); mx = mk3(fmaxf(mx.x, lmx[i].x), fmaxf(mx.y, lmx[i].y), fmaxf(mx.z, lmx[i].z)); c += cnt[i]; }
+            if (S & (1 << i)) { mn = mk3(fminf(mn.x, w.lmn[i].x), fminf(mn.y, w.lmn[i].y), fminf(mn.z, w.lmn[i].z)); mx = mk3(fmaxf(mx.x, w.lmx[i].x), fmaxf(mx.y, w.lmx[i].y), fmaxf(mx.z, w.lmx[i].z)); c += w.cnt[i]; }
         f4 a, b; a.x = mn.x; a.y = mn.y; a.z = mn.z; a.w = 0.0f; b.x = mx.x; b.y = mx.y; b.z = mx.z; b.w = 0.0f;
-        td.nmn[me] = a; td.nmx[me] = b; td.cost[me] = copt[S]; nodes.count[me] = c;
+        coh_st4(&td.nmn[me], a); coh_st4(&td.nmx[me], b); coh_st(&td.cost[me], copt[S]); coh_st(&nodes.count[me], c);
     }
+}
+
+/* one thread does it all: the CPU harness, and the device when NORI_HIP_TREELET_SERIAL is set */
+NORI_HD void treelet_optimize(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
+                              TreeletParams tp, uint32_t id) {
+    TreeletWork w;
+    if (!treelet_form(nodes, td, pos, idx, order, pad, tp, id, w)) return;
+    /* dynamic programming over the subsets of the k leaves */
+    const int k = w.k, full = (1 << k) - 1;
+    float area[1 << kTreeletLeaves], copt[1 << kTreeletLeaves];
+    unsigned char part[1 << kTreeletLeaves];
+    for (int S = 1; S <= full; ++S) area[S] = treelet_subset_area(w, S);
+    for (int i = 0; i < k; ++i) copt[1 << i] = w.lcost[i];
+    for (int S = 3; S <= full; ++S) {
+        if ((S & (S - 1)) == 0) continue;                   /* a single leaf */
+        float best = kInf; int bestP = 0;
+        int P = treelet_first_partition(S);
+        do {
+            const float c = copt[P] + copt[S ^ P];
+            if (c < best) { best = c; bestP = P; }
+            P = treelet_next_partition(S, P);
+        } while (P != 0);
+        copt[S] = tp.c_node * area[S] + best;
+        part[S] = (unsigned char) bestP;
+    }
+    if (!(copt[full] < coh_ld(&td.cost[id]) * 0.99999f)) return;     /* nothing to gain: leave the subtree as PLOC built it */
+    treelet_rewire(nodes, td, id, w, copt, part);
 }
 
 /* One sweep = treelet_climb for every triangle position k (visits[] zeroed before).  On the device the arrival counter is an
@@ -351,7 +411,7 @@ NORI_HD void treelet_climb(const PlocNodes &nodes, const TreeletData &td, const 
         if (before == 0u) return;
         treelet_optimize(nodes, td, pos, idx, order, pad, tp, p);
         if (p == root_id) return;
-        p = nodes.parent_node[p];
+        p = coh_ld(&nodes.parent_node[p]);
     }
 }
 

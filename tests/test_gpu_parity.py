@@ -316,6 +316,35 @@ def test_gpu_lbvh_builder_same_hits_as_brute_force(renderer_factory, n_tris, see
     assert np.array_equal(o.intersect(rays, True)["mesh"], r.intersect(rays, True)["mesh"])
 
 
+def test_treelet_wave_builds_the_tree_of_the_serial_form():
+    """Treelet restructuring on the device: a WAVE per treelet (lbvh.hip, treelet_optimize_wave: subset areas two per lane, the dynamic
+    programme's (subset, partition) pairs spread over the lanes, winners by a 64-bit LDS minimum that keeps the serial loop's tie rule)
+    against one thread per treelet (NORI_HIP_TREELET_SERIAL=1 -- the form the CPU harness runs, lbvh_steps.h): the same tree.  Checked
+    by what a tree determines: node count, depth, SAH cost, and the node / triangle tests of a render."""
+    from nori_amd.render import Renderer
+    from nori_amd.scene import Scene
+    import os
+    jobs = [scenes.soup_scene(30000, seed=11, width=96, height=64, integrator="path_mis"),
+            Scene.load_npz(os.path.join(os.path.dirname(__file__), "golden", "pa5-table_mis.npz"))]
+    jobs[0].sample_count = 2
+    jobs[1].camera.width, jobs[1].camera.height, jobs[1].sample_count = 160, 120, 2
+    for sc in jobs:
+        got = {}
+        for serial in (0, 1):
+            os.environ["NORI_HIP_TREELET_SERIAL"] = str(serial)
+            os.environ["NORI_HIP_TREELET_SWEEPS"] = "2"
+            try:
+                r = Renderer(0).upload(sc, builder=3)
+            finally:
+                del os.environ["NORI_HIP_TREELET_SERIAL"], os.environ["NORI_HIP_TREELET_SWEEPS"]
+            info = r.accel_info()
+            frame, st = r.render_host(count_traversal=True)
+            got[serial] = (info["n_nodes"], info["max_depth"], info["sah_cost"], st["n_node_tests"], st["n_tri_tests"], frame)
+            r.close()
+        assert got[0][:5] == got[1][:5], (got[0][:5], got[1][:5])
+        assert np.array_equal(got[0][5], got[1][5])
+
+
 def test_gpu_lbvh_render_equals_sah_render(renderer_factory):
     from tests import stat_harness  # noqa: F401
     from nori_amd.scene import Scene
