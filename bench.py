@@ -73,6 +73,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--engine", default="auto", choices=["auto", "megakernel", "wavefront"])
+    ap.add_argument("--builder", default="host", choices=["host", "lbvh", "auto", "ploc"],
+                    help="nori_accel_builder: binned SAH on the host (best trees; the default of every line so far), or on the device: "
+                         "radix tree, PLOC + treelet sweeps, auto = host up to 2^22 triangles, PLOC above (accel.build_ms is in the line)")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY (tests/test_distributed_cpu.py): run the same sharding / merge / reporting code on CPU "
                          "ranks (gloo) with the emulated device headers standing in for the GPU; never a fallback")
@@ -190,7 +193,7 @@ def main():
         r = _EmuRenderer(sc)
     else:
         from nori_amd.render import Renderer
-        r = Renderer(local_rank).upload(sc)
+        r = Renderer(local_rank).upload(sc, builder={"host": 0, "lbvh": 1, "auto": 2, "ploc": 3}[args.builder])
     tiles_x, tiles_y = (width + 15) // 16, (height + 15) // 16
     tiles = tiles_x * tiles_y
     shard = ndist.shard(split, rank, world, spp)
@@ -340,7 +343,7 @@ def main():
             "pass": {"kernel_ms": round(k_ms, 3), "trace_ms": round(float(np.mean(trace_ms)), 3), "shade_ms": round(float(np.mean(shade_ms)), 3),
                      "film_ms": round(float(np.mean(film_ms)), 3),
                      "hbm_measured_bytes": (ctr[1].get("pass_hbm_bytes") if ctr else None)},
-            "accel": {k: (round(v, 3) if isinstance(v, float) else v) for k, v in info.items()},
+            "accel": dict({k: (round(v, 3) if isinstance(v, float) else v) for k, v in info.items()}, builder=args.builder),
         }
         if world > 1 or merge_ms:
             out["ranks"] = [{"rank": k, "ms_per_step": round(float(v[0]), 3), "kernel_ms": round(float(v[1]), 3), "merge_ms": round(float(v[2]), 3),

@@ -15,6 +15,9 @@ constexpr int kB = 256;
 
 constexpr int kMaxBorder = 8;                  /* (16 + 2 * 8)^2 / 256 = 4 output pixels per thread */
 
+/* a workgroup barrier that waits for LDS only (what film_gather's rounds exchange lives there) */
+__device__ __forceinline__ void film_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 /* ImageBlock::put(pos, value) as a gather.  Sample round by sample round, the tile's 256 current
  * samples are staged in LDS together with their 1-D filter weights; then every pixel of the tile's
  * bordered block (tile_w^2 pixels, <= 4 per thread) adds the samples that can reach it.  Weights follow
@@ -72,15 +75,19 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
     __syncthreads();
     /* this workgroup's share of the samples per pixel */
     const uint32_t s_lo = (uint32_t) ((uint64_t) fl.n_spp * part / st.n_parts), s_hi = (uint32_t) ((uint64_t) fl.n_spp * (part + 1) / st.n_parts);
+    /* the NEXT round's sample is requested while this round's taps run (its trip to HBM used to open every round; the barriers of a
+       round wait for LDS only -- __syncthreads() would wait for the request as well) */
+    f2 p_next = mk2(0.0f, 0.0f); P3 l_next; l_next.x = l_next.y = l_next.z = 0.0f;
+    if (live && s_lo < s_hi) { const size_t i0 = first + (size_t) s_lo * 256u + (size_t) tid; p_next = st.pos[i0]; l_next = st.L[i0]; }
     for (uint32_t s = s_lo; s < s_hi; ++s) {
         {
-            const size_t idx = first + (size_t) s * 256u + (size_t) tid;
             f4 L; L.x = L.y = L.z = 0.0f;
             bool ok = false;
             float bpx = 0.0f, bpy = 0.0f;
+            const f2 p = p_next; const P3 l3 = l_next;
+            if (live && s + 1u < s_hi) { const size_t i1 = first + (size_t) (s + 1u) * 256u + (size_t) tid; p_next = st.pos[i1]; l_next = st.L[i1]; }
             if (live) {
-                const f2 p = st.pos[idx];
-                { const P3 l3 = st.L[idx]; L.x = l3.x; L.y = l3.y; L.z = l3.z; }
+                L.x = l3.x; L.y = l3.y; L.z = l3.z;
                 ok = color_valid(mk3(L.x, L.y, L.z));
                 if (!ok) { ++invalid; L.x = L.y = L.z = 0.0f; }
                 bpx = p.x - 0.5f - (float) (bx0 - border);
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
                 s_wy[k][raster] = iny ? ftab[(int) (fabsf(yb - bpy) * lookup)] : 0.0f;
             }
         }
-        __syncthreads();
+        film_barrier();
         for (int o = 0; o < kMaxOut; ++o) {
             const int oy = out_y[o], ox = out_x[o];
             if (oy < 0) break;
@@ -115,7 +122,7 @@ __global__ __launch_bounds__(kB) void film_gather_kernel(int width, int height, 
                 }
             }
         }
-        __syncthreads();                                       /* round consumed */
+        film_barrier();                                        /* round consumed */
     }
     f4 *dst = reinterpret_cast<f4 *>(st.tile_acc) + ((size_t) ord * st.n_parts + part) * n_out;
     for (int o = 0; o < kMaxOut; ++o) {

@@ -829,7 +829,10 @@ __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur
    continuation ray, Li vertex, repeat -- the megakernel's loop started from stored path state.
    (Its lanes run nearly empty -- 6.5 of 64 per instruction -- and that is not what it costs: the launch lasts as long as the
    LONGEST path, ~1300 vertices through glass at p = 0.99, one after the other.  A kernel that re-compacts a workgroup's paths
-   after every vertex keeps the lanes dense and is no faster: profiles/r4_04_tail_per_vertex_ab.txt.) */
+   after every vertex keeps the lanes dense and is no faster: profiles/r4_04_tail_per_vertex_ab.txt.  Nor does walking through
+   the LDS image of the hot records help here -- pa5 table, 64 spp: 44.9 against 42.0 ms of shade time, a 1/8 share of the Cornell
+   box 3.99 against 3.56: 2048 workgroups each copy 12 KB for a few hundred paths, and the C++ form of the 32-B node step pays 24
+   instructions per step for the ray's plane coefficients.) */
 template <int INTEG>
 __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, WfBatch bt, int count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
