@@ -222,7 +222,7 @@ def main():
     if "engine" in counted:
         engine = {0: "megakernel", 1: "wavefront", 2: "block-serial"}[int(counted["engine"])]
     else:                      # --emulate: the CPU harness walks paths one by one, sized like the library's rule would
-        engine = args.engine if args.engine != "auto" else ("wavefront" if my_tiles * 256 * shard["spp_count"] >= (1 << 24) else "megakernel")
+        engine = args.engine if args.engine != "auto" else ("wavefront" if my_tiles * 256 * shard["spp_count"] >= (1 << (24 if sc.integrator.type == "normals" else 19)) else "megakernel")
     for _ in range(args.warmup):
         step()
     barrier()

@@ -297,8 +297,8 @@ int nori_hip_accel_info(const nori_hip_ctx *ctx, nori_accel_info *out);
 int nori_hip_debug_excursions(nori_hip_ctx *ctx, unsigned long long out[4], int reset);
 
 /* Tuning / engine selection (no reference counterpart).  Keys:
- *   "engine"          "auto" (default: wavefront for >= 2^24 camera samples per call,
- *                     else megakernel) | "megakernel" | "wavefront"
+ *   "engine"          "auto" (default: wavefront for >= 2^19 camera samples per call -- 2^24 for the `normals`
+ *                     integrator --, else megakernel) | "megakernel" | "wavefront"
  *   "wavefront_paths" paths in flight per wavefront batch (default 2^29, 236 B of HBM each; bounded by 85 % of the free memory)
  *   "accel_layout"    node layout of the NEXT nori_hip_build_accel: "bvh2" (64-B node = two full-precision child
  *                     boxes; the wavefront engine walks a second, 32-B form of them, see nori_accel_info) | "bvh4q"

@@ -1039,9 +1039,15 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
     KernelTimer timer(stats && params->time_kernels != 0);
     int engine = ctx->engine;
     if (const char *e = getenv("NORI_HIP_ENGINE")) engine = std::string(e) == "wavefront" ? 1 : (std::string(e) == "megakernel" ? 0 : -1);
-    /* auto: the wavefront engine wins once there are enough paths to keep its kernels full
-       (measured on pa4 cbox: 7.3 vs 6.8 Grays/s at 2.7e8 paths); small jobs avoid its launch train */
-    if (engine < 0) engine = (size_t) a.n_sel_tiles * 256 * a.spp_count >= ((size_t) 1 << 24) ? 1 : 0;
+    /* auto: the wavefront engine wins once there are enough paths to keep its kernels full; small jobs avoid its launch train.
+       Measured on the round-4 build (tools/engine_switch_probe.py, profiles/r4_11_engine_switch.txt): with a path loop -- every
+       integrator but `normals` -- from 2^19 camera samples per call (Cornell box path_mis, megakernel / wavefront ms: 2^18 1.11 / 1.47,
+       2^19 2.00 / 1.80, 2^22 3.90 / 3.08, 2^24 9.84 / 7.86, 2^26 33.1 / 19.4; AO on 328 k triangles 2^18 0.90 / 0.66); `normals` is one
+       ray and no loop: one launch against four (2^20 samples: 0.17 / 0.44 ms), the old 2^24 stays */
+    if (engine < 0) {
+        const size_t samples = (size_t) a.n_sel_tiles * 256 * a.spp_count;
+        engine = samples >= ((size_t) 1 << (ctx->dev.integrator.type == 0 ? 24 : 19)) ? 1 : 0;
+    }
     if (ctx->dev.wide) engine = 1;      /* wide nodes are walked by the wavefront engine (and the batch twins) only */
     if (params->seed_mode == NORI_SEED_NORI_BLOCK && a.n_sel_tiles > 0 && a.spp_count > 0) {
         /* one lane per 32x32 block, the block's own pcg32 stream (render_block_serial_kernel) */
