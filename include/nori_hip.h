@@ -306,8 +306,9 @@ int nori_hip_debug_excursions(nori_hip_ctx *ctx, unsigned long long out[4], int 
  *                     not fit the caches) | "auto" (default: bvh4q from 2^20 triangles)
  *   "film_order"      "fast" (default: the film adds a pixel's samples round by round in LDS tiles) | "reference" (the
  *                     samples are added in the order of renderBlock / ImageBlock::put / BlockGenerator,
- *                     src/main.cpp:33-53, src/block.cpp:62-152: whole frames only, slower -- the frame is then
- *                     bit-identical to a single-threaded render of the same samples by the reference's loops)
+ *                     src/main.cpp:33-53, src/block.cpp:62-152: whole frames -- or whole rows of 32x32 blocks through
+ *                     nori_hip_render_block_rows --, slower; the frame is then bit-identical to a single-threaded
+ *                     render of the same samples by the reference's loops)
  * Unknown keys return NORI_ERR_INVALID_ARGUMENT. */
 int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value);
 /* The current value of an option as set_option would take it ("engine", "wavefront_paths", "film_order", "accel_layout"),
@@ -389,6 +390,21 @@ int nori_hip_splat(nori_hip_ctx *ctx, const float *positions,
 int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params,
                     void *d_rgbw, nori_render_stats *stats);
 
+/* film_order = "reference" shared out over devices or ranks.  The reference adds a 32x32 block's samples consecutively
+ * into the block's own ImageBlock (renderBlock, src/main.cpp:27-55) and the blocks into the frame in BlockGenerator's order
+ * (src/block.cpp:93-152): the smallest share that keeps the order is a block, the one handed out here is a ROW of blocks.
+ * nori_hip_render_block_rows renders block rows [row_begin, row_begin + row_count) (clipped to the frame) with samples
+ * [spp_begin, spp_begin + spp_count) and writes the bordered accumulators of THOSE blocks into d_block_acc, the array for
+ * ALL blocks of the frame: nori_hip_block_acc_floats floats, block b = by * blocks_x + bx at b * (32 + 2 border)^2 * 4,
+ * zeroed by the caller.  The arrays of disjoint shares sum exactly in any order (x + 0 = x), e.g. by one ncclReduce;
+ * nori_hip_resolve_blocks then ADDS the blocks into the RGBW frame in BlockGenerator's order -- the bits of the frame one
+ * device renders with film_order = reference, whatever the number of shares.  params: tile_mod 1, tile_rem 0,
+ * NORI_SEED_PER_SAMPLE; the context's film_order must be "reference". */
+int nori_hip_block_acc_floats(nori_hip_ctx *ctx, size_t *n_floats);
+int nori_hip_render_block_rows(nori_hip_ctx *ctx, const nori_render_params *params, uint32_t row_begin, uint32_t row_count,
+                               void *d_block_acc, nori_render_stats *stats);
+int nori_hip_resolve_blocks(nori_hip_ctx *ctx, const void *d_block_acc, void *d_rgbw, void *stream);
+
 /* Convenience: zero a host RGBW buffer, render into a scratch device buffer
  * and copy back (synchronous). */
 int nori_hip_render_host(nori_hip_ctx *ctx, const nori_render_params *params,
@@ -410,8 +426,11 @@ int nori_hip_develop(nori_hip_ctx *ctx, const void *d_rgbw, void *d_rgb,
  * tile columns divisible by the device count) = every device sends only the column strips its tiles touched.
  * A device list that names a device more than once is served without RCCL (peer copies) -- for tests on one GPU; so is a
  * node whose librccl cannot be loaded (nori_hip_group_warning says so).  A fresh RCCL group proves its communicators with
- * a small reduce of a known pattern before nori_hip_group_create returns.  film_order = reference and NORI_SEED_NORI_BLOCK
- * render whole frames on one device: a group of more than one refuses them. */
+ * a small reduce of a known pattern before nori_hip_group_create returns.  With film_order = reference on its contexts a
+ * group hands out rows of 32x32 blocks instead (whatever `split` says), merges the blocks' accumulators (a reduce of disjoint
+ * arrays: exact) and adds them into the frame in BlockGenerator's order on the first device: the frame has the bits of the
+ * one-device frame for any number of devices.  NORI_SEED_NORI_BLOCK renders whole frames on one device: a group of more
+ * than one refuses it. */
 typedef struct nori_hip_group nori_hip_group;
 typedef enum nori_group_split { NORI_SPLIT_TILE = 0, NORI_SPLIT_SAMPLE = 1 } nori_group_split;
 typedef enum nori_group_merge { NORI_MERGE_REDUCE = 0, NORI_MERGE_GATHER = 1 } nori_group_merge;

@@ -137,6 +137,9 @@ HIP_PROTOTYPES = {
     "nori_hip_render": (C.c_int, [_P, C.POINTER(RenderParams), _P, C.POINTER(RenderStats)]),
     "nori_hip_render_host": (C.c_int, [_P, C.POINTER(RenderParams), _P, C.POINTER(RenderStats)]),
     "nori_hip_develop": (C.c_int, [_P, _P, _P, _P]),
+    "nori_hip_block_acc_floats": (C.c_int, [_P, C.POINTER(C.c_size_t)]),
+    "nori_hip_render_block_rows": (C.c_int, [_P, C.POINTER(RenderParams), C.c_uint32, C.c_uint32, _P, C.POINTER(RenderStats)]),
+    "nori_hip_resolve_blocks": (C.c_int, [_P, _P, _P, _P]),
     "nori_hip_group_create": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
     "nori_hip_group_destroy": (None, [_P]),
     "nori_hip_group_size": (C.c_int, [_P]),

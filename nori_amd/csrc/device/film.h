@@ -72,11 +72,25 @@ std::string film_prepare(FilmStore &store, size_t n_samples, size_t n_sel_tiles,
 void film_gather(const DevScene &sc, const float *d_filter_table, const FilmStore &st, const FilmLaunch &fl, void *stream);
 /* add all accumulators into the caller's RGBW frame */
 void film_resolve(const DevScene &sc, const FilmStore &st, const FilmLaunch &fl, float *d_rgbw, void *stream);
-/* Reference-order film (see the header comment): the store must hold EVERY sample of the frame -- all tiles, samples
-   [0, n_spp) of every pixel, index (tile * n_spp + s) * 256 + pixel -- because a pixel's samples are added
-   consecutively.  Accumulates into d_rgbw.  "" or an error. */
+/* A share of the reference-order film for one of several devices: whole ROWS of 32x32 blocks (a block's samples are added
+   consecutively, so a block is the smallest share), i.e. the contiguous range of 16x16 tiles from
+   film_block_rows_first_tile(row_begin) on.  With block_acc set, the call stops after the blocks: it writes the accumulators of
+   its own blocks into the caller's array for ALL blocks of the frame (film_block_acc_floats; zeroed by the caller).  The shares'
+   arrays are disjoint, so their element-wise sum is exact whatever its order (x + 0 = x; an accumulator is never -0), and
+   film_resolve_blocks on the sum gives the bits of the one-device frame. */
+struct FilmBlockRows {
+    uint32_t row_begin = 0, row_count = 0xffffffffu;      /* clipped to the frame's block rows */
+    float *block_acc = nullptr;
+};
+NORI_HD uint32_t film_block_rows_first_tile(uint32_t block_row, uint32_t tiles_x) { return block_row * 2u * tiles_x; }      /* NORI_BLOCK_SIZE = 2 tiles */
+size_t film_block_acc_floats(const DevScene &sc);
+/* Reference-order film (see the header comment): the store must hold EVERY sample of the frame (of the share's block rows) --
+   all tiles, samples [0, n_spp) of every pixel, index (tile * n_spp + s) * 256 + pixel -- because a pixel's samples are added
+   consecutively.  Accumulates into d_rgbw (unless share->block_acc is set).  "" or an error. */
 std::string film_reference_order(FilmStore &store, const FilmStore &view, const DevScene &sc, const float *d_filter_table,
-                                 uint32_t n_spp, uint32_t tiles_x, float *d_rgbw, void *stream);
+                                 uint32_t n_spp, uint32_t tiles_x, const FilmBlockRows *share, float *d_rgbw, void *stream);
+/* ImageBlock::put(ImageBlock&) of every block in BlockGenerator's order (src/block.cpp:93-152) into d_rgbw */
+std::string film_resolve_blocks(FilmStore &store, const DevScene &sc, const float *d_block_acc, float *d_rgbw, void *stream);
 /* samples dropped by the isValid() guard (src/block.cpp:63-67) since film_prepare; synchronises `stream` */
 unsigned long long film_invalid_count(const FilmStore &st, void *stream);
 void film_release(FilmStore &store);

@@ -172,16 +172,18 @@ constexpr int kBlock32 = 32;          /* NORI_BLOCK_SIZE, include/nori/block.h:1
    samples that reach it in the reference's order: source pixels in raster order (renderBlock's y, x loops,
    src/main.cpp:33-34), samples in index order (:35), each as ImageBlock::put does (src/block.cpp:62-91) */
 __global__ __launch_bounds__(kB) void film_block_reference_kernel(int width, int height, FilterRec fr, const float *__restrict__ filter_table,
-                                                                  FilmStore st, uint32_t n_spp, uint32_t tiles_x, uint32_t blocks_x) {
+                                                                  FilmStore st, uint32_t n_spp, uint32_t tiles_x, uint32_t blocks_x,
+                                                                  uint32_t block_first, uint32_t tile_first) {
     __shared__ float ftab[kFilterRes + 1];
     if (threadIdx.x <= kFilterRes) ftab[threadIdx.x] = filter_table[threadIdx.x];
     __syncthreads();
-    const int bx = (int) (blockIdx.x % blocks_x), by = (int) (blockIdx.x / blocks_x);
+    const uint32_t blk = block_first + blockIdx.x;      /* a share of the frame: whole block rows from block_first on, their tiles from tile_first on in the store */
+    const int bx = (int) (blk % blocks_x), by = (int) (blk / blocks_x);
     const int offx = bx * kBlock32, offy = by * kBlock32;
     const int bw = min(kBlock32, width - offx), bh = min(kBlock32, height - offy);
     const int border = fr.border, cols = bw + 2 * border, rows = bh + 2 * border;
     const float radius = fr.radius, lookup = fr.lookup_factor;
-    float4 *dst = reinterpret_cast<float4 *>(st.block_acc) + (size_t) blockIdx.x * (kBlock32 + 2 * border) * (kBlock32 + 2 * border);
+    float4 *dst = reinterpret_cast<float4 *>(st.block_acc) + (size_t) blk * (kBlock32 + 2 * border) * (kBlock32 + 2 * border);
     unsigned long long invalid = 0;
     for (int i = (int) threadIdx.x; i < cols * rows; i += kB) {
         const int oy = i / cols, ox = i - oy * cols;
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(kB) void film_block_reference_kernel(int width, int
         for (int sy = max(0, oy - 2 * border); sy <= min(bh - 1, oy); ++sy)
             for (int sx = max(0, ox - 2 * border); sx <= min(bw - 1, ox); ++sx) {
                 const int px = offx + sx, py = offy + sy;
-                const uint32_t tile = (uint32_t) (py / kTile) * tiles_x + (uint32_t) (px / kTile);
+                const uint32_t tile = (uint32_t) (py / kTile) * tiles_x + (uint32_t) (px / kTile) - tile_first;
                 const int lx = px % kTile, ly = py % kTile;
                 const uint32_t pix = (uint32_t) ((((lx >> 3) | ((ly >> 3) << 1)) << 6) | ((lx & 7) | ((ly & 7) << 3)));      /* inverse of film_tile_pixel */
                 const bool centre = ox == sx + border && oy == sy + border;      /* one thread per source pixel counts its invalid samples */
@@ -239,18 +241,20 @@ constexpr int kRefChunk = 32;          /* samples of one source pixel staged per
 constexpr int kRefMaxSlots = 4;        /* (2 * 8 + 1) * (32 + 16) / 256 rounded up */
 
 __global__ __launch_bounds__(kB) void film_block_reference_staged_kernel(int width, int height, FilterRec fr, const float *__restrict__ filter_table,
-                                                                         FilmStore st, uint32_t n_spp, uint32_t tiles_x, uint32_t blocks_x, int chunk) {
+                                                                         FilmStore st, uint32_t n_spp, uint32_t tiles_x, uint32_t blocks_x, int chunk,
+                                                                         uint32_t block_first, uint32_t tile_first) {
     extern __shared__ __attribute__((aligned(16))) float s_ref[];      /* [chunk][32] float4 (r wx, g wx, b wx, wx), then wy[taps][chunk][32] */
     __shared__ float ftab[kFilterRes + 1];
     if (threadIdx.x <= kFilterRes) ftab[threadIdx.x] = filter_table[threadIdx.x];
     const int tid = (int) threadIdx.x;
-    const int bx = (int) (blockIdx.x % blocks_x), by = (int) (blockIdx.x / blocks_x);
+    const uint32_t blk = block_first + blockIdx.x;
+    const int bx = (int) (blk % blocks_x), by = (int) (blk / blocks_x);
     const int offx = bx * kBlock32, offy = by * kBlock32;
     const int bw = min(kBlock32, width - offx), bh = min(kBlock32, height - offy);
     const int border = fr.border, taps = 2 * border + 1, cols = bw + 2 * border;
     const int stride = kBlock32 + 2 * border;
     const float radius = fr.radius, lookup = fr.lookup_factor;
-    float4 *dst = reinterpret_cast<float4 *>(st.block_acc) + (size_t) blockIdx.x * stride * stride;
+    float4 *dst = reinterpret_cast<float4 *>(st.block_acc) + (size_t) blk * stride * stride;
     const int plane = chunk * kBlock32;
     float4 *s_lw = reinterpret_cast<float4 *>(s_ref);      /* one ds_read_b128 per term: consecutive lanes read consecutive float4s (conflict free) */
     float *s_wy = s_ref + 4 * plane;                       /* s_wy[m][s][sx] */
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(kB) void film_block_reference_staged_kernel(int wid
                 for (int e = tid; e < cs * bw; e += kB) {
                     const int sl = e / bw, sx = e - sl * bw;
                     const int px = offx + sx;
-                    const uint32_t tile = (uint32_t) (py / kTile) * tiles_x + (uint32_t) (px / kTile);
+                    const uint32_t tile = (uint32_t) (py / kTile) * tiles_x + (uint32_t) (px / kTile) - tile_first;
                     const int lx = px % kTile, ly = py % kTile;
                     const uint32_t pix = (uint32_t) ((((lx >> 3) | ((ly >> 3) << 1)) << 6) | ((lx & 7) | ((ly & 7) << 3)));      /* inverse of film_tile_pixel */
                     const size_t idx = (size_t) tile * n_spp * 256u + pix + (size_t) (c0 + (uint32_t) sl) * 256u;
@@ -442,17 +446,15 @@ void film_resolve(const DevScene &sc, const FilmStore &st, const FilmLaunch &fl,
                        (const float *) st.tile_acc, d_rgbw);
 }
 
-std::string film_reference_order(FilmStore &store, const FilmStore &view, const DevScene &sc, const float *d_filter_table,
-                                 uint32_t n_spp, uint32_t tiles_x, float *d_rgbw, void *stream) {
+size_t film_block_acc_floats(const DevScene &sc) {
+    const int border = sc.filter.border;
+    const size_t nb = (size_t) ((sc.camera.width + kBlock32 - 1) / kBlock32) * (size_t) ((sc.camera.height + kBlock32 - 1) / kBlock32);
+    return nb * (kBlock32 + 2 * border) * (kBlock32 + 2 * border) * 4;
+}
+
+std::string film_resolve_blocks(FilmStore &store, const DevScene &sc, const float *d_block_acc, float *d_rgbw, void *stream) {
     const int w = sc.camera.width, h = sc.camera.height, border = sc.filter.border;
     const uint32_t bxn = (uint32_t) ((w + kBlock32 - 1) / kBlock32), byn = (uint32_t) ((h + kBlock32 - 1) / kBlock32), nb = bxn * byn;
-    const size_t floats = (size_t) nb * (kBlock32 + 2 * border) * (kBlock32 + 2 * border) * 4;
-    if (store.block_floats < floats) {
-        if (store.block_acc) (void) hipFree(store.block_acc);
-        store.block_acc = nullptr; store.block_floats = 0;
-        FILM_TRY(hipMalloc((void **) &store.block_acc, floats * sizeof(float)));
-        store.block_floats = floats;
-    }
     if (store.n_rank != nb) {
         if (store.spiral_rank) (void) hipFree(store.spiral_rank);
         store.spiral_rank = nullptr; store.n_rank = 0;
@@ -462,20 +464,44 @@ std::string film_reference_order(FilmStore &store, const FilmStore &view, const 
     const std::vector<uint32_t> rank = spiral_ranks((int) bxn, (int) byn);       /* the frame size may have changed: cheap, recomputed per call */
     FILM_TRY(hipMemcpyAsync(store.spiral_rank, rank.data(), (size_t) nb * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t) stream));
     FILM_TRY(hipStreamSynchronize((hipStream_t) stream));                       /* `rank` is a host temporary */
-    FilmStore v = view; v.block_acc = store.block_acc; v.spiral_rank = store.spiral_rank;
+    const int cols = w + 2 * border, rows = h + 2 * border;
+    hipLaunchKernelGGL(film_resolve_reference_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, (hipStream_t) stream, w, h, border, bxn, byn,
+                       d_block_acc, (const uint32_t *) store.spiral_rank, d_rgbw);
+    FILM_TRY(hipGetLastError());
+    return std::string();
+}
+
+std::string film_reference_order(FilmStore &store, const FilmStore &view, const DevScene &sc, const float *d_filter_table,
+                                 uint32_t n_spp, uint32_t tiles_x, const FilmBlockRows *share, float *d_rgbw, void *stream) {
+    const int w = sc.camera.width, h = sc.camera.height, border = sc.filter.border;
+    const uint32_t bxn = (uint32_t) ((w + kBlock32 - 1) / kBlock32), byn = (uint32_t) ((h + kBlock32 - 1) / kBlock32);
+    const size_t floats = film_block_acc_floats(sc);
+    float *acc = share ? share->block_acc : nullptr;
+    if (!acc) {
+        if (store.block_floats < floats) {
+            if (store.block_acc) (void) hipFree(store.block_acc);
+            store.block_acc = nullptr; store.block_floats = 0;
+            FILM_TRY(hipMalloc((void **) &store.block_acc, floats * sizeof(float)));
+            store.block_floats = floats;
+        }
+        acc = store.block_acc;
+    }
+    /* the blocks of this call: all of them, or the rows of a share -- whose tiles are the store's tiles 0, 1, ... */
+    const uint32_t row0 = share ? std::min(share->row_begin, byn) : 0u, rown = share ? std::min(share->row_count, byn - row0) : byn;
+    const uint32_t nb = rown * bxn, block_first = row0 * bxn, tile_first = film_block_rows_first_tile(row0, tiles_x);
+    FilmStore v = view; v.block_acc = acc;
     static const bool unstaged = getenv("NORI_HIP_FILM_REF_UNSTAGED") != nullptr;      /* the first implementation, for A / B: one thread per output pixel reading its sources from memory */
-    if (unstaged) hipLaunchKernelGGL(film_block_reference_kernel, dim3(nb), dim3(kB), 0, (hipStream_t) stream, w, h, sc.filter, d_filter_table, v, n_spp, tiles_x, bxn);
+    if (nb == 0) { /* an empty share */ }
+    else if (unstaged) hipLaunchKernelGGL(film_block_reference_kernel, dim3(nb), dim3(kB), 0, (hipStream_t) stream, w, h, sc.filter, d_filter_table, v, n_spp, tiles_x, bxn, block_first, tile_first);
     else {
         int chunk = 2 * border + 1 > 11 ? kRefChunk / 2 : kRefChunk;
         if (const char *e = getenv("NORI_HIP_FILM_REF_CHUNK")) chunk = std::min(kRefChunk, std::max(4, atoi(e)));
         hipLaunchKernelGGL(film_block_reference_staged_kernel, dim3(nb), dim3(kB), (size_t) (4 + 2 * border + 1) * chunk * kBlock32 * sizeof(float), (hipStream_t) stream,
-                           w, h, sc.filter, d_filter_table, v, n_spp, tiles_x, bxn, chunk);
+                           w, h, sc.filter, d_filter_table, v, n_spp, tiles_x, bxn, chunk, block_first, tile_first);
     }
-    const int cols = w + 2 * border, rows = h + 2 * border;
-    hipLaunchKernelGGL(film_resolve_reference_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, (hipStream_t) stream, w, h, border, bxn, byn,
-                       (const float *) store.block_acc, (const uint32_t *) store.spiral_rank, d_rgbw);
     FILM_TRY(hipGetLastError());
-    return std::string();
+    if (share && share->block_acc) return std::string();      /* the caller merges the shares' accumulators, then film_resolve_blocks */
+    return film_resolve_blocks(store, sc, acc, d_rgbw, stream);
 }
 
 unsigned long long film_invalid_count(const FilmStore &st, void *stream) {

@@ -175,6 +175,91 @@ static std::string rccl_self_check(nori_hip_group *g) {
     return err;
 }
 
+/* stats of a frame from the devices' shares: counters summed, times = the slowest device's */
+static void group_sum_stats(nori_hip_group *g, const std::vector<nori_render_stats> &st, nori_render_stats *stats) {
+    const int n = (int) st.size();
+    group_sum_stats(g, st, stats);
+}
+
+/* film_order = reference over the group (nori_hip.h: nori_hip_render_block_rows): every device renders its rows of 32x32 blocks
+   into a zeroed array of block accumulators, the arrays -- disjoint, so their sum is exact in any order -- are reduced to the
+   first device, which adds the blocks into the frame in BlockGenerator's order */
+static int group_render_reference(nori_hip_group *g, const nori_render_params *params, int width, int height, float *rgbw,
+                                  nori_render_stats *stats, float *merge_ms) {
+    const int n = (int) g->ctx.size();
+    const int border = nori_hip_border_size(g->ctx[0]);
+    const size_t frame_floats = (size_t) (height + 2 * border) * (size_t) (width + 2 * border) * 4;
+    size_t acc_floats = 0;
+    if (nori_hip_block_acc_floats(g->ctx[0], &acc_floats) != NORI_OK) { g->error = std::string("group_render: ") + nori_hip_last_error(g->ctx[0]); return NORI_ERR_NOT_READY; }
+    const uint32_t block_rows = (uint32_t) ((height + 31) / 32);
+    struct Buffers {      /* this mode is for comparisons: its buffers live for one frame */
+        nori_hip_group *g; std::vector<float *> acc; float *recv = nullptr, *frame = nullptr;
+        ~Buffers() {
+            for (size_t k = 0; k < acc.size(); ++k) if (acc[k]) { (void) hipSetDevice(g->devices[k]); (void) hipFree(acc[k]); }
+            (void) hipSetDevice(g->devices[0]);
+            if (recv) (void) hipFree(recv);
+            if (frame) (void) hipFree(frame);
+        }
+    } buf;
+    buf.g = g; buf.acc.assign((size_t) n, nullptr);
+    for (int k = 0; k < n; ++k) { GRP_HIP(hipSetDevice(g->devices[(size_t) k])); GRP_HIP(hipMalloc((void **) &buf.acc[(size_t) k], acc_floats * sizeof(float))); }
+    GRP_HIP(hipSetDevice(g->devices[0]));
+    GRP_HIP(hipMalloc((void **) &buf.frame, frame_floats * sizeof(float)));
+    if (!g->rccl) GRP_HIP(hipMalloc((void **) &buf.recv, acc_floats * sizeof(float)));
+
+    std::vector<int> rc((size_t) n, NORI_OK);
+    std::vector<nori_render_stats> st((size_t) n);
+    std::vector<std::string> errs((size_t) n);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n; ++k) th.emplace_back([&, k] {
+        const size_t i = (size_t) k;
+        if (hipSetDevice(g->devices[i]) != hipSuccess || hipMemsetAsync(buf.acc[i], 0, acc_floats * sizeof(float), g->streams[i]) != hipSuccess) { rc[i] = NORI_ERR_INTERNAL; errs[i] = "clearing the block accumulators failed"; return; }
+        const GroupRows rows = group_block_rows(k, n, block_rows);
+        nori_render_params p = *params;
+        p.stream = g->streams[i];
+        std::memset(&st[i], 0, sizeof(st[i]));
+        rc[i] = nori_hip_render_block_rows(g->ctx[i], &p, rows.row_begin, rows.row_count, buf.acc[i], &st[i]);      /* synchronises its stream (stats requested) */
+        if (rc[i] != NORI_OK) errs[i] = nori_hip_last_error(g->ctx[i]);
+        else if (hipStreamSynchronize(g->streams[i]) != hipSuccess) { rc[i] = NORI_ERR_INTERNAL; errs[i] = "hipStreamSynchronize failed"; }      /* (an empty share launched nothing but the memset) */
+    });
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n; ++k)
+        if (rc[(size_t) k] != NORI_OK) { g->error = "device " + std::to_string(g->devices[(size_t) k]) + ": " + errs[(size_t) k]; return rc[(size_t) k]; }
+
+    struct Events {
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events() { if (e0) (void) hipEventDestroy(e0); if (e1) (void) hipEventDestroy(e1); }
+    } ev;
+    GRP_HIP(hipSetDevice(g->devices[0]));
+    GRP_HIP(hipEventCreate(&ev.e0)); GRP_HIP(hipEventCreate(&ev.e1));
+    GRP_HIP(hipEventRecord(ev.e0, g->streams[0]));
+    if (g->rccl) {
+        GRP_NCCL(g_rccl.GroupStart());
+        ncclResult_t r = ncclSuccess;
+        for (int k = 0; k < n && r == ncclSuccess; ++k) r = g_rccl.Reduce(buf.acc[(size_t) k], buf.acc[(size_t) k], acc_floats, ncclFloat, ncclSum, 0, g->comms[(size_t) k], g->streams[(size_t) k]);
+        const ncclResult_t closed = g_rccl.GroupEnd();
+        GRP_NCCL(r); GRP_NCCL(closed);
+        for (int k = 1; k < n; ++k) { GRP_HIP(hipSetDevice(g->devices[(size_t) k])); GRP_HIP(hipStreamSynchronize(g->streams[(size_t) k])); }
+        GRP_HIP(hipSetDevice(g->devices[0]));
+    } else {
+        for (int k = 1; k < n; ++k) {      /* one receive buffer, the copies and adds in stream order */
+            GRP_HIP(hipMemcpyPeerAsync(buf.recv, g->devices[0], buf.acc[(size_t) k], g->devices[(size_t) k], acc_floats * sizeof(float), g->streams[0]));
+            hipLaunchKernelGGL(add_frames_kernel, dim3((unsigned) ((acc_floats / 4 + 255) / 256)), dim3(256), 0, g->streams[0], reinterpret_cast<float4 *>(buf.acc[0]), reinterpret_cast<const float4 *>(buf.recv), acc_floats / 4);
+            GRP_HIP(hipGetLastError());
+        }
+    }
+    GRP_HIP(hipMemsetAsync(buf.frame, 0, frame_floats * sizeof(float), g->streams[0]));
+    if (nori_hip_resolve_blocks(g->ctx[0], buf.acc[0], buf.frame, g->streams[0]) != NORI_OK) { g->error = std::string("group_render: ") + nori_hip_last_error(g->ctx[0]); return NORI_ERR_INTERNAL; }
+    GRP_HIP(hipEventRecord(ev.e1, g->streams[0]));
+    GRP_HIP(hipMemcpyAsync(rgbw, buf.frame, frame_floats * sizeof(float), hipMemcpyDeviceToHost, g->streams[0]));
+    GRP_HIP(hipStreamSynchronize(g->streams[0]));
+    float ms = 0.0f;
+    GRP_HIP(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    if (merge_ms) *merge_ms = ms;
+    group_sum_stats(g, st, stats);
+    return NORI_OK;
+}
+
 extern "C" {
 
 int nori_hip_group_create(const int *devices, int n_devices, nori_hip_group **out) {
@@ -278,16 +363,20 @@ int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *para
         g->error = "group_render: the gather merge needs the tile split and a tile-column count (" + std::to_string(tiles_x) + ") divisible by the number of devices (" + std::to_string(n) + "); use the reduce merge";
         return NORI_ERR_INVALID_ARGUMENT;
     }
-    /* film_order = reference promises the reference's summation order over the WHOLE frame: a share of the tiles is rejected per
-       context (nori_hip_render); a share of the samples would be accepted there and lose the order in the sum of the frames */
-    if (n > 1)
+    /* film_order = reference promises the reference's summation order over the WHOLE frame: a sum of the devices' frames would lose
+       it, so the group hands out block rows and merges the blocks' accumulators instead (group_render_reference) */
+    if (n > 1) {
+        int n_ref = 0;
         for (int k = 0; k < n; ++k) {
             char v[32] = "";
-            if (nori_hip_get_option(g->ctx[(size_t) k], "film_order", v, sizeof(v)) == NORI_OK && std::string(v) == "reference") {
-                g->error = "group_render: film_order = reference renders whole frames on one device (the frames of several devices are summed afterwards)";
-                return NORI_ERR_UNSUPPORTED;
-            }
+            if (nori_hip_get_option(g->ctx[(size_t) k], "film_order", v, sizeof(v)) == NORI_OK && std::string(v) == "reference") ++n_ref;
         }
+        if (n_ref != 0 && n_ref != n) { g->error = "group_render: film_order = reference on some devices of the group only"; return NORI_ERR_INVALID_ARGUMENT; }
+        if (n_ref == n) {
+            if (params->seed_mode == NORI_SEED_NORI_BLOCK) { g->error = "group_render: NORI_SEED_NORI_BLOCK renders whole frames on one device"; return NORI_ERR_UNSUPPORTED; }
+            return group_render_reference(g, params, width, height, rgbw, stats, merge_ms);
+        }
+    }
     if (params->seed_mode == NORI_SEED_NORI_BLOCK && n > 1) { g->error = "group_render: NORI_SEED_NORI_BLOCK renders whole frames on one device"; return NORI_ERR_UNSUPPORTED; }
 
     /* buffers for this frame geometry */
@@ -405,23 +494,7 @@ int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *para
     float ms = 0.0f;
     GRP_HIP(hipEventElapsedTime(&ms, e0, e1));
     if (merge_ms) *merge_ms = ms;
-    if (stats) {
-        std::memset(stats, 0, sizeof(*stats));
-        for (int k = 0; k < n; ++k) {
-            const nori_render_stats &s = st[(size_t) k];
-            stats->n_camera_samples += s.n_camera_samples; stats->n_closest_rays += s.n_closest_rays; stats->n_shadow_rays += s.n_shadow_rays;
-            stats->n_node_tests += s.n_node_tests; stats->n_tri_tests += s.n_tri_tests; stats->n_invalid += s.n_invalid;
-            stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms);       /* the devices render side by side: the slowest counts */
-            stats->trace_ms = std::max(stats->trace_ms, s.trace_ms); stats->shade_ms = std::max(stats->shade_ms, s.shade_ms); stats->film_ms = std::max(stats->film_ms, s.film_ms);
-            stats->n_workgroups += s.n_workgroups; stats->n_trace_launches = std::max(stats->n_trace_launches, s.n_trace_launches);
-            stats->lds_bytes = std::max(stats->lds_bytes, s.lds_bytes);
-        }
-        /* "auto" picks the engine by the size of a share: the devices may differ -- the summed stats name the first device's,
-           nori_hip_group_engines() every device's */
-        stats->engine = st[0].engine;
-    }
-    g->engines.resize((size_t) n);
-    for (int k = 0; k < n; ++k) g->engines[(size_t) k] = st[(size_t) k].engine;
+    group_sum_stats(g, st, stats);
     return NORI_OK;
 }
 

@@ -10,6 +10,8 @@
  *   split sample  every device renders the whole frame with a contiguous share of the sample indices per pixel
  *                 (disjoint pcg32 streams)
  *   merge reduce  sum of the N whole frames into device 0's (RCCL ncclReduce; either split)
+ *   (film_order = reference: rows of 32x32 blocks per device, the blocks' accumulators merged, then added into the frame in the
+ *   reference's block order on device 0 -- group_block_rows below, nori_hip.h)
  *   merge gather  tile split with tiles_x divisible by N only: a device's tiles are whole tile COLUMNS, so what it touched
  *                 is a set of (16 + 2 border)-pixel-wide column strips; each device packs its strips, device 0 receives
  *                 them (RCCL send / receive) and adds them, overlapping halos included -- 1/N of the frame per device
@@ -42,6 +44,17 @@ inline GroupShare group_share(int split, int rank, int world, uint32_t spp_begin
     } else {
         s.spp_begin = spp_begin; s.spp_count = spp_count; s.tile_mod = (uint32_t) world; s.tile_rem = (uint32_t) rank;
     }
+    return s;
+}
+
+/* film_order = reference: the share is whole rows of 32x32 blocks (a block's samples are added consecutively, film.h) --
+   contiguous, the first (block_rows % world) devices one row more; devices beyond the rows get none */
+struct GroupRows { uint32_t row_begin, row_count; };
+inline GroupRows group_block_rows(int rank, int world, uint32_t block_rows) {
+    const uint32_t base = block_rows / (uint32_t) world, extra = block_rows % (uint32_t) world, r = (uint32_t) rank;
+    GroupRows s;
+    s.row_begin = r * base + (r < extra ? r : extra);
+    s.row_count = base + (r < extra ? 1u : 0u);
     return s;
 }
 

@@ -993,12 +993,16 @@ static hipError_t launch_render(nori_hip_ctx *ctx, const RenderArgs &a, const Fi
     }
 }
 
-extern "C" {
-
-int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d_rgbw, nori_render_stats *stats) {
+/* nori_hip_render, and nori_hip_render_block_rows (share != nullptr: the block rows of a reference-order film; the accumulators
+   of their blocks go to share->block_acc instead of a frame) */
+static int render_impl(nori_hip_ctx *ctx, const nori_render_params *params, void *d_rgbw, nori_render_stats *stats, const FilmBlockRows *share) {
     REQUIRE_ACCEL(ctx);
-    if (!params || !d_rgbw) return NORI_ERR_INVALID_ARGUMENT;
+    if (!params || (!d_rgbw && !share)) return NORI_ERR_INVALID_ARGUMENT;
     if (params->tile_mod == 0 || params->tile_rem >= params->tile_mod) { ctx->error = "render: bad tile_mod/tile_rem"; return NORI_ERR_INVALID_ARGUMENT; }
+    if (share && (!ctx->film_reference || params->tile_mod != 1 || params->seed_mode != NORI_SEED_PER_SAMPLE || !share->block_acc)) {
+        ctx->error = "render_block_rows: needs film_order = reference, tile_mod 1, NORI_SEED_PER_SAMPLE and an accumulator array";
+        return NORI_ERR_INVALID_ARGUMENT;
+    }
     if (params->seed_mode != NORI_SEED_PER_SAMPLE && params->seed_mode != NORI_SEED_NORI_BLOCK) { ctx->error = "render: unknown seed_mode"; return NORI_ERR_INVALID_ARGUMENT; }
     if (params->seed_mode == NORI_SEED_NORI_BLOCK && (params->tile_mod != 1 || params->spp_begin != 0)) {
         ctx->error = "render: NORI_SEED_NORI_BLOCK renders whole frames from sample 0 (a block's stream is serial: src/independent.cpp:36-41)";
@@ -1016,6 +1020,14 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
     a.tiles_y = (uint32_t) ((ctx->host.camera.height + kTile - 1) / kTile);
     const uint32_t n_tiles = a.tiles_x * a.tiles_y;
     a.n_sel_tiles = n_tiles > a.tile_rem ? (n_tiles - a.tile_rem + a.tile_mod - 1) / a.tile_mod : 0;
+    if (share) {
+        /* whole rows of 32x32 blocks = a contiguous range of tiles: tile_id = tile_rem + ordinal * 1 with tile_rem = the range's
+           first tile (every kernel derives a tile from its ordinal this way) */
+        const uint32_t byn = (uint32_t) ((ctx->host.camera.height + kNoriBlock - 1) / kNoriBlock);
+        const uint32_t row0 = std::min(share->row_begin, byn), row1 = row0 + std::min(share->row_count, byn - row0);
+        const uint32_t t0 = std::min(film_block_rows_first_tile(row0, a.tiles_x), n_tiles), t1 = std::min(film_block_rows_first_tile(row1, a.tiles_x), n_tiles);
+        a.tile_rem = t0; a.n_sel_tiles = t1 - t0;
+    }
     a.tile_w = kTile + 2 * ctx->host.filter.border;
     a.th_shade = 44; a.th_inner = 1; a.th_leaf = 1;
     a.debug_flags = getenv("NORI_HIP_NOSPLAT") ? 1u : 0u;
@@ -1074,7 +1086,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         fl.tiles_x = a.tiles_x; fl.tiles_y = a.tiles_y; fl.tile_w = a.tile_w; fl.n_spp = a.spp_count;
         timer.begin(KC_FILM, s);
         if (ctx->film_reference) {
-            std::string rerr = film_reference_order(ctx->film, film, ctx->dev, ctx->d_filter, a.spp_count, a.tiles_x, (float *) d_rgbw, s);
+            std::string rerr = film_reference_order(ctx->film, film, ctx->dev, ctx->d_filter, a.spp_count, a.tiles_x, nullptr, (float *) d_rgbw, s);
             if (!rerr.empty()) { ctx->error = rerr; return NORI_ERR_INTERNAL; }
         } else {
             film_gather(ctx->dev, ctx->d_filter, film, fl, s);
@@ -1095,7 +1107,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         wl.time_kernels = stats && params->time_kernels != 0;
         /* paths in flight: the option, bounded by what this GPU has free right now (state already held by
            this context counts as free) -- a second context or another process may own part of the HBM */
-        wl.film_reference = ctx->film_reference;
+        wl.film_reference = ctx->film_reference; wl.film_share = share;
         wl.max_paths = ctx->wavefront_paths;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
@@ -1144,7 +1156,7 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         }
         timer.begin(KC_FILM, s);
         if (ctx->film_reference) {
-            std::string rerr = film_reference_order(ctx->film, film, ctx->dev, ctx->d_filter, a.spp_count, a.tiles_x, (float *) d_rgbw, s);
+            std::string rerr = film_reference_order(ctx->film, film, ctx->dev, ctx->d_filter, a.spp_count, a.tiles_x, share, (float *) d_rgbw, s);
             if (!rerr.empty()) { ctx->error = rerr; return NORI_ERR_INTERNAL; }
         } else film_resolve(ctx->dev, film, fl, (float *) d_rgbw, s);
         timer.end(s);
@@ -1179,6 +1191,35 @@ int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d
         const uint32_t need = ctx->bvh.max_depth + 1;
         stats->lds_bytes = (uint32_t) (need <= 16 ? render_lds_bytes<16>(a) : need <= 24 ? render_lds_bytes<24>(a) : need <= 32 ? render_lds_bytes<32>(a) : render_lds_bytes<64>(a));
     }
+    return NORI_OK;
+}
+
+extern "C" {
+
+int nori_hip_render(nori_hip_ctx *ctx, const nori_render_params *params, void *d_rgbw, nori_render_stats *stats) {
+    return render_impl(ctx, params, d_rgbw, stats, nullptr);
+}
+
+int nori_hip_block_acc_floats(nori_hip_ctx *ctx, size_t *n_floats) {
+    if (!ctx || !ctx->have_scene) return NORI_ERR_NOT_READY;
+    if (!n_floats) return NORI_ERR_INVALID_ARGUMENT;
+    *n_floats = film_block_acc_floats(ctx->dev);
+    return NORI_OK;
+}
+
+int nori_hip_render_block_rows(nori_hip_ctx *ctx, const nori_render_params *params, uint32_t row_begin, uint32_t row_count,
+                               void *d_block_acc, nori_render_stats *stats) {
+    FilmBlockRows share;
+    share.row_begin = row_begin; share.row_count = row_count; share.block_acc = (float *) d_block_acc;
+    return render_impl(ctx, params, nullptr, stats, &share);
+}
+
+int nori_hip_resolve_blocks(nori_hip_ctx *ctx, const void *d_block_acc, void *d_rgbw, void *stream) {
+    if (!ctx || !ctx->have_scene) return NORI_ERR_NOT_READY;
+    if (!d_block_acc || !d_rgbw) return NORI_ERR_INVALID_ARGUMENT;
+    DeviceGuard g(ctx->device);
+    const std::string err = film_resolve_blocks(ctx->film, ctx->dev, (const float *) d_block_acc, (float *) d_rgbw, (hipStream_t) stream);
+    if (!err.empty()) { ctx->error = err; return NORI_ERR_INTERNAL; }
     return NORI_OK;
 }
 

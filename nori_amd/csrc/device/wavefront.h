@@ -18,6 +18,7 @@ struct WfLaunch {
     bool time_kernels;          /* HIP events around every launch (ktimer.h) */
     size_t max_paths;           /* paths in flight per batch */
     bool film_reference;        /* add the samples in the reference's order (film.h): needs the whole frame in ONE batch */
+    const FilmBlockRows *film_share = nullptr;      /* reference order: the selected tiles are these block rows (tile_mod 1, tile_rem = their first tile) */
 };
 
 struct WfStats {

@@ -1323,7 +1323,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
         }
     timer.begin(KC_FILM, s);
     if (L.film_reference) {
-        err = film_reference_order(film_store, film, sc, d_filter_table, L.spp_count, L.tiles_x, d_rgbw, s);
+        err = film_reference_order(film_store, film, sc, d_filter_table, L.spp_count, L.tiles_x, L.film_share, d_rgbw, s);
         if (!err.empty()) return err;
     } else film_resolve(sc, film, fl, d_rgbw, s);
     timer.end(s);

@@ -19,6 +19,11 @@ merge of those buffers on rank 0 -- ImageBlock::put(ImageBlock&)
                    (overlapping halos included) into the frame -- 1/N of the frame per
                    rank over the wire instead of a ring reduce of all of it.
 Both give, up to float summation order, the single-GPU image.
+
+film_order = "reference" (the reference's own summation order, bit for bit): render_distributed_reference -- every rank
+renders whole ROWS of 32x32 blocks into an array of block accumulators, ONE reduce of those (disjoint, hence exact) arrays,
+and rank 0 adds the blocks into the frame in BlockGenerator's order: the frame has the bits of the one-GPU frame for any
+number of ranks.
 """
 from __future__ import annotations
 
@@ -34,6 +39,13 @@ def shard(mode: str, rank: int, world: int, spp: int):
         begin = rank * base + min(rank, extra)
         return dict(spp_begin=begin, spp_count=base + (1 if rank < extra else 0), tile_mod=1, tile_rem=0)
     raise ValueError(f"unknown shard mode {mode!r}")
+
+
+def block_rows(rank: int, world: int, n_rows: int):
+    """(row_begin, row_count) of rank `rank`: contiguous rows of 32x32 blocks, the first n_rows % world ranks one more
+    (group_merge.h group_block_rows)."""
+    base, extra = divmod(n_rows, world)
+    return rank * base + min(rank, extra), base + (1 if rank < extra else 0)
 
 
 def _group_up() -> bool:
@@ -110,4 +122,25 @@ def render_distributed(render_fn, frame, mode: str, spp: int, rank: int, world: 
         merge_ms.append(float(e0.elapsed_time(e1)))
     elif timed:
         merge_ms.append((time.perf_counter() - t0) * 1e3)
+    return stats
+
+
+def render_distributed_reference(renderer, frame, spp: int, rank: int, world: int, merge_ms: list | None = None, **kw):
+    """film_order = reference over the ranks (module docstring).  `renderer`: nori_amd.render.Renderer with
+    set_option("film_order", "reference"); `frame`: this rank's RGBW tensor, the merged frame on rank 0."""
+    import torch
+    acc = torch.zeros(renderer.block_acc_floats(), dtype=torch.float32, device=frame.device)
+    r0, rn = block_rows(rank, world, renderer.block_rows())
+    stats = renderer.render_block_rows_into(acc, r0, rn, spp_count=spp, **kw)
+    timed = merge_ms is not None and _group_up()
+    if timed:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    reduce_frame(acc, 0)      # disjoint arrays: x + 0 = x, exact whatever order the ring adds in
+    frame.zero_()
+    if rank == 0:
+        renderer.resolve_blocks(acc, frame)
+    if timed:
+        e1.record(); e1.synchronize()
+        merge_ms.append(float(e0.elapsed_time(e1)))
     return stats

@@ -212,6 +212,35 @@ class Renderer:
                                               C.byref(st) if st is not None else None), "render")
         return st.as_dict() if st is not None else None
 
+    # -- film_order = reference shared out: rows of 32x32 blocks (include/nori_hip.h: nori_hip_render_block_rows) --
+    def block_rows(self) -> int:
+        """rows of 32x32 blocks (NORI_BLOCK_SIZE) in the frame"""
+        return (self.scene.camera.height + 31) // 32
+
+    def block_acc_floats(self) -> int:
+        n = C.c_size_t(0)
+        self._check(self._lib.nori_hip_block_acc_floats(self._h, C.byref(n)), "block_acc_floats")
+        return int(n.value)
+
+    def render_block_rows_into(self, acc_tensor, row_begin, row_count, spp_count=None, spp_begin=0, stream=None, count_traversal=False):
+        """Block rows [row_begin, row_begin + row_count) in the reference's summation order: their blocks' accumulators are written
+        into `acc_tensor` (CUDA float32, block_acc_floats() elements, zeroed by the caller; other blocks untouched)."""
+        assert acc_tensor.is_cuda and acc_tensor.is_contiguous() and acc_tensor.numel() == self.block_acc_floats()
+        spp = self.scene.sample_count if spp_count is None else spp_count
+        raw = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        p = self._params(spp_begin, spp, 1, 0, count_traversal, raw, False)
+        st = capi.RenderStats()
+        self._check(self._lib.nori_hip_render_block_rows(self._h, C.byref(p), int(row_begin), int(row_count), C.c_void_p(acc_tensor.data_ptr()), C.byref(st)), "render_block_rows")
+        return st.as_dict()
+
+    def resolve_blocks(self, acc_tensor, rgbw_tensor, stream=None):
+        """ImageBlock::put(ImageBlock&) of every block in BlockGenerator's order: adds into the RGBW frame tensor."""
+        assert acc_tensor.is_cuda and acc_tensor.numel() == self.block_acc_floats()
+        assert rgbw_tensor.is_cuda and rgbw_tensor.is_contiguous() and tuple(rgbw_tensor.shape) == tuple(self.frame_shape())
+        raw = C.c_void_p(stream.cuda_stream) if stream is not None else None
+        self._check(self._lib.nori_hip_resolve_blocks(self._h, C.c_void_p(acc_tensor.data_ptr()), C.c_void_p(rgbw_tensor.data_ptr()), raw), "resolve_blocks")
+        return rgbw_tensor
+
     def develop(self, rgbw_tensor, stream=None):
         """ImageBlock::toBitmap on the device: (H, W, 3) torch tensor."""
         import torch

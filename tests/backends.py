@@ -118,6 +118,7 @@ def emu_lib():
             "emu_pcg32_floats": (C.c_int, [_P, _P, C.c_size_t, C.c_uint32, _P]),
             "emu_render": (C.c_int, [_P, C.POINTER(capi.RenderParams), _P, C.POINTER(capi.RenderStats)]),
             "emu_group_render": (C.c_int, [_P, C.c_int, C.POINTER(capi.RenderParams), C.c_int, C.c_int, _P, C.POINTER(capi.RenderStats)]),
+            "emu_group_block_rows": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32)]),
         }
         _emu = capi.bind(lib, protos)
     return _emu

@@ -191,6 +191,7 @@ static f3 run_path_records(const DevScene &sc, const RayIn &cam, uint64_t rng_st
 
 #include "emu_wavesim.h"
 #include "../../nori_amd/csrc/device/group_merge.h"
+#include "../../nori_amd/csrc/device/film.h"      /* film_block_rows_first_tile: the tile range of a share of block rows */
 
 extern "C" {
 
@@ -635,5 +636,19 @@ extern "C" int emu_group_render(emu_ctx *c, int n_ranks, const nori_render_param
             stats->n_shadow_rays += st[(size_t) k].n_shadow_rays; stats->n_invalid += st[(size_t) k].n_invalid;
         }
     }
+    return NORI_OK;
+}
+
+
+/* film_order = reference over a group: the rows of 32x32 blocks of rank `rank` (group_merge.h) and the contiguous range of 16x16
+   tiles they are rendered as (film.h; nori_hip.hip render_impl clips it to the frame the same way): out = row_begin, row_count,
+   tile_begin, tile_count */
+extern "C" int emu_group_block_rows(int rank, int world, int width, int height, uint32_t out[4]) {
+    if (world < 1 || rank < 0 || rank >= world || !out) return NORI_ERR_INVALID_ARGUMENT;
+    const uint32_t tiles_x = (uint32_t) ((width + kTile - 1) / kTile), tiles_y = (uint32_t) ((height + kTile - 1) / kTile), n_tiles = tiles_x * tiles_y;
+    const uint32_t byn = (uint32_t) ((height + 31) / 32);
+    const GroupRows r = group_block_rows(rank, world, byn);
+    const uint32_t t0 = std::min(film_block_rows_first_tile(r.row_begin, tiles_x), n_tiles), t1 = std::min(film_block_rows_first_tile(r.row_begin + r.row_count, tiles_x), n_tiles);
+    out[0] = r.row_begin; out[1] = r.row_count; out[2] = t0; out[3] = t1 - t0;
     return NORI_OK;
 }

@@ -164,3 +164,30 @@ def test_shard_partitions():
                 pos += p["spp_count"]
             tiles = [shard("tile", r, world, spp) for r in range(world)]
             assert [t["tile_rem"] for t in tiles] == list(range(world)) and all(t["tile_mod"] == world for t in tiles)
+
+
+@pytest.mark.parametrize("size", [(1024, 1024), (112, 72), (33, 31), (16, 200), (800, 600)])
+@pytest.mark.parametrize("world", [1, 2, 3, 8, 40])
+def test_block_row_shares_of_the_reference_order_film(size, world):
+    """film_order = reference is shared out by rows of 32x32 blocks (a block's samples are added consecutively): the rows of the
+    ranks are contiguous, disjoint and cover the frame; rendered as tiles they are contiguous tile ranges that partition the frame's
+    tiles; the C++ group (group_merge.h, film.h -- through the CPU harness) and nori_amd.dist hand out the same rows."""
+    import ctypes as C
+    from nori_amd import dist as ndist
+    from tests.backends import emu_lib
+    w, h = size
+    lib = emu_lib()
+    rows_total = (h + 31) // 32
+    tiles = ((w + 15) // 16) * ((h + 15) // 16)
+    next_row, next_tile = 0, 0
+    for rank in range(world):
+        out = (C.c_uint32 * 4)()
+        assert lib.emu_group_block_rows(rank, world, w, h, out) == 0
+        r0, rn, t0, tn = (int(v) for v in out)
+        assert (r0, rn) == ndist.block_rows(rank, world, rows_total)
+        assert r0 == next_row and t0 == next_tile
+        assert rn in (rows_total // world, rows_total // world + 1)
+        # a row of blocks = two rows of tiles (one where the frame ends inside it)
+        assert tn == (min(2 * (r0 + rn), (h + 15) // 16) - min(2 * r0, (h + 15) // 16)) * ((w + 15) // 16)
+        next_row, next_tile = r0 + rn, t0 + tn
+    assert next_row == rows_total and next_tile == tiles

@@ -305,12 +305,12 @@ def test_device_group_errors_and_one_rank_rccl(tmp_path):
     np.testing.assert_allclose(got, Renderer(0).upload(sc).render_host()[0], rtol=2e-5, atol=1e-6)
     assert g.warning == "" and g.engines() in ([0], [1])      # one entry per member
     g.close()
-    # film_order = reference promises the reference's summation order over the whole frame: one device only
+    # film_order = reference on some members only is refused (the frame would have no defined order)
     g = DeviceGroup([0, 0]).upload(sc)
-    g.set_option("film_order", "reference")
-    for split in ("tile", "sample"):
-        with pytest.raises(NoriError, match="film_order = reference renders whole frames on one device"):
-            g.render_host(split, "reduce")
+    lib = _capi.load_hip()
+    assert lib.nori_hip_set_option(lib.nori_hip_group_ctx(g._h, 1), b"film_order", b"reference") == 0
+    with pytest.raises(NoriError, match="film_order = reference on some devices of the group only"):
+        g.render_host("tile", "reduce")
     g.set_option("film_order", "fast")
     g.render_host("sample", "reduce")
     assert len(g.engines()) == 2
@@ -437,3 +437,95 @@ def test_tree_with_unbounded_boxes_takes_the_64_byte_nodes():
     np.testing.assert_allclose(out["wavefront"][0], out["megakernel"][0], rtol=1e-4, atol=1e-5)      # (the engines add a pixel's samples in different orders)
     for k in ("n_closest_rays", "n_shadow_rays"):
         assert out["megakernel"][1][k] == out["wavefront"][1][k]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["megakernel", "wavefront"])
+def test_reference_order_frame_has_the_same_bits_for_any_number_of_shares(engine):
+    """film_order = reference shared out by rows of 32x32 blocks (nori_hip_render_block_rows): every share writes the
+    accumulators of its own blocks, the arrays are summed -- in any order: they are disjoint -- and the blocks added into the
+    frame in BlockGenerator's order.  The frame must have the bits of the one-device frame (which tests/test_gpu_parity.py
+    pins, bit for bit, to the single-threaded oracle) for every number of shares, more shares than rows included."""
+    import torch
+    from nori_amd import dist as ndist
+    from nori_amd.render import Renderer
+    sc = scenes.cornell_box(112, 72, 5, "path_mis")          # 4 x 3 blocks, the last column / row clipped; 7 x 5 tiles
+    r = Renderer(0).upload(sc)
+    r.set_option("film_order", "reference"); r.set_option("engine", engine)
+    whole, st_whole = r.render_host()
+    assert r.block_rows() == 3
+    for world in (1, 2, 3, 5):
+        accs, rays = [], 0
+        for rank in range(world):
+            acc = torch.zeros(r.block_acc_floats(), dtype=torch.float32, device="cuda:0")
+            r0, rn = ndist.block_rows(rank, world, r.block_rows())
+            st = r.render_block_rows_into(acc, r0, rn)
+            rays += st["n_closest_rays"] + st["n_shadow_rays"]
+            accs.append(acc)
+        total = torch.zeros_like(accs[0])
+        for k in reversed(range(world)):                      # an order of its own
+            total += accs[k]
+        frame = torch.zeros(r.frame_shape(), dtype=torch.float32, device="cuda:0")
+        r.resolve_blocks(total, frame)
+        got = frame.cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), whole.view(np.uint32)), (world, float(np.abs(got - whole).max()))
+        assert rays == st_whole["n_closest_rays"] + st_whole["n_shadow_rays"]
+    # the fast film refuses the call, and so does a tile share
+    r.set_option("film_order", "fast")
+    from nori_amd import NoriError
+    with pytest.raises(NoriError, match="needs film_order = reference"):
+        r.render_block_rows_into(torch.zeros(r.block_acc_floats(), dtype=torch.float32, device="cuda:0"), 0, 1)
+    r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("members", [2, 3, 4])
+def test_device_group_in_reference_order_gives_the_one_device_bits(members):
+    """The C++ group with film_order = reference on its contexts: block rows per member, the accumulators merged, the blocks
+    added in the reference's order on the first device -- same bits as one device, whatever `split` says."""
+    from nori_amd.render import DeviceGroup, Renderer
+    sc = scenes.cornell_box(80, 96, 3, "path_mis")           # 3 block columns (the last clipped), 3 block rows
+    r = Renderer(0).upload(sc)
+    r.set_option("film_order", "reference")
+    whole, st_whole = r.render_host()
+    r.close()
+    g = DeviceGroup([0] * members).upload(sc)
+    g.set_option("film_order", "reference")
+    for split in ("tile", "sample"):
+        got, st, ms = g.render_host(split, "reduce")
+        assert np.array_equal(got.view(np.uint32), whole.view(np.uint32)), (members, split, float(np.abs(got - whole).max()))
+        for k in ("n_camera_samples", "n_closest_rays", "n_shadow_rays", "n_invalid"):
+            assert st[k] == st_whole[k], (k, st[k], st_whole[k])
+    assert len(g.engines()) == members
+    g.close()
+
+
+@pytest.mark.gpu
+def test_reference_order_over_torch_distributed_ranks():
+    """nori_amd.dist.render_distributed_reference through a launcher-started one-rank RCCL group (what a rank of an N-GPU run
+    executes): the merged frame has the one-device bits."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path.insert(0, os.getcwd())
+        import numpy as np, torch, torch.distributed as dist
+        from nori_amd import dist as ndist
+        from nori_amd.render import Renderer
+        from tests import scenes
+        dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
+        sc = scenes.cornell_box(96, 64, 4, "path_mis")
+        r = Renderer(0).upload(sc)
+        r.set_option("film_order", "reference")
+        whole, _ = r.render_host()
+        frame = torch.zeros(r.frame_shape(), dtype=torch.float32, device="cuda:0")
+        ms = []
+        ndist.render_distributed_reference(r, frame, sc.sample_count, dist.get_rank(), dist.get_world_size(), merge_ms=ms)
+        torch.cuda.synchronize()
+        assert np.array_equal(frame.cpu().numpy().view(np.uint32), whole.view(np.uint32))
+        assert len(ms) == 1
+        dist.destroy_process_group()
+        print("REFERENCE-ORDER-RANKS-OK")
+    """)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "REFERENCE-ORDER-RANKS-OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
