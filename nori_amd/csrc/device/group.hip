@@ -178,7 +178,23 @@ static std::string rccl_self_check(nori_hip_group *g) {
 /* stats of a frame from the devices' shares: counters summed, times = the slowest device's */
 static void group_sum_stats(nori_hip_group *g, const std::vector<nori_render_stats> &st, nori_render_stats *stats) {
     const int n = (int) st.size();
-    group_sum_stats(g, st, stats);
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        for (int k = 0; k < n; ++k) {
+            const nori_render_stats &s = st[(size_t) k];
+            stats->n_camera_samples += s.n_camera_samples; stats->n_closest_rays += s.n_closest_rays; stats->n_shadow_rays += s.n_shadow_rays;
+            stats->n_node_tests += s.n_node_tests; stats->n_tri_tests += s.n_tri_tests; stats->n_invalid += s.n_invalid;
+            stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms);       /* the devices render side by side: the slowest counts */
+            stats->trace_ms = std::max(stats->trace_ms, s.trace_ms); stats->shade_ms = std::max(stats->shade_ms, s.shade_ms); stats->film_ms = std::max(stats->film_ms, s.film_ms);
+            stats->n_workgroups += s.n_workgroups; stats->n_trace_launches = std::max(stats->n_trace_launches, s.n_trace_launches);
+            stats->lds_bytes = std::max(stats->lds_bytes, s.lds_bytes);
+        }
+        /* "auto" picks the engine by the size of a share: the devices may differ -- the summed stats name the first device's,
+           nori_hip_group_engines() every device's */
+        stats->engine = st[0].engine;
+    }
+    g->engines.resize((size_t) n);
+    for (int k = 0; k < n; ++k) g->engines[(size_t) k] = st[(size_t) k].engine;
 }
 
 /* film_order = reference over the group (nori_hip.h: nori_hip_render_block_rows): every device renders its rows of 32x32 blocks

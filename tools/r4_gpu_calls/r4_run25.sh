@@ -2,7 +2,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r4_26; mkdir -p $O
 ( time timeout 600 python -c "import torch; torch.zeros(1).cuda(); print('torch ok')" ) 2>&1 | tail -3
-timeout 400 python -m pytest tests/test_gpu_wavefront.py -m gpu -x -q --durations=5 -k "reference_order or device_group or native_library" > $O/pytest_new.log 2>&1; echo "pytest rc $?" >> $O/pytest_new.log; tail -12 $O/pytest_new.log
+timeout 400 python -m pytest tests/test_gpu_wavefront.py -m gpu -q --durations=5 -k "reference_order or device_group or native_library" > $O/pytest_new.log 2>&1; echo "pytest rc $?" >> $O/pytest_new.log; tail -12 $O/pytest_new.log
 echo "t = $SECONDS s"
 timeout 420 bash tools/profile_round.sh r4_13 pa4-cbox-path_mis > gpurun_out/prof_r4_13.log 2>&1; tail -1 gpurun_out/prof_r4_13.log | cut -c1-300
 echo "t = $SECONDS s"
