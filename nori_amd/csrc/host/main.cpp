@@ -1,5 +1,5 @@
 /*
- * main.cpp -- `nori <scene.xml> [--no-gui] [--threads N] [--seed sample|block] [--gpus N] [--split tile|sample] [--merge reduce|gather]`
+ * main.cpp -- `nori <scene.xml> [--no-gui] [--threads N] [--seed sample|block] [--gpus N] [--split tile|sample] [--merge reduce|gather] [--film-order fast|reference]`
  * Command line of the reference (src/main.cpp:150-246).  There is no GUI on a
  * compute node: --no-gui is accepted and implied; --threads is accepted for
  * compatibility (the work runs on the GPU).  --seed block renders with the
@@ -17,7 +17,7 @@ using namespace nori;
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        cerr << "Syntax: " << argv[0] << " <scene.xml> [--no-gui] [--threads N] [--seed sample|block] [--gpus N] [--split tile|sample] [--merge reduce|gather]" << endl;
+        cerr << "Syntax: " << argv[0] << " <scene.xml> [--no-gui] [--threads N] [--seed sample|block] [--gpus N] [--split tile|sample] [--merge reduce|gather] [--film-order fast|reference]" << endl;
         return -1;
     }
     std::string sceneName;
@@ -46,12 +46,12 @@ int main(int argc, char **argv) {
             }
             setenv("NORI_GPUS", argv[++i], 1);
             continue;
-        } else if (token == "--split" || token == "--merge") {
+        } else if (token == "--split" || token == "--merge" || token == "--film-order") {
             if (i + 1 >= argc) {
                 cerr << "\"" << token << "\" expects a value." << endl;
                 return -1;
             }
-            setenv(token == "--split" ? "NORI_SPLIT" : "NORI_MERGE", argv[++i], 1);
+            setenv(token == "--split" ? "NORI_SPLIT" : token == "--merge" ? "NORI_MERGE" : "NORI_FILM_ORDER", argv[++i], 1);
             continue;
         }
         if (endsWith(token, ".xml")) {

@@ -340,6 +340,16 @@ def test_device_group_errors_and_one_rank_rccl(tmp_path):
     assert p.returncode != 0 and f"device {n_dev} not found" in p.stdout + p.stderr
     p = subprocess.run([exe, str(tmp_path / "scene.xml"), "--gpus", "1", "--split", "sample"], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "1 GPUs, sample split" in p.stdout, p.stdout + p.stderr
+    # --film-order reaches every context: one device or a group, the frame in reference order has the same bits
+    from nori_amd import host
+    frames = []
+    for extra in ([], ["--gpus", "1"]):
+        p = subprocess.run([exe, str(tmp_path / "scene.xml"), "--film-order", "reference"] + extra, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        frames.append(host.load_exr(str(tmp_path / "scene.exr")).copy())
+    assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32))
+    p = subprocess.run([exe, str(tmp_path / "scene.xml"), "--film-order", "sideways"], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "--film-order expects" in p.stdout + p.stderr
 
 
 @pytest.mark.parametrize("split,merge", [("tile", "reduce"), ("tile", "gather"), ("sample", "reduce")])
