@@ -302,7 +302,8 @@ def main():
                          "note": "VALU-issue bound (%s); ops = %d per node test + %d per triangle test + %d per ray (f32 vector operations as "
                                  "written in rt_trace.h), peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"
                                  % ("BVH of %.1f MB is L2 / Infinity-Cache resident" % (info["total_bytes"] / 1e6) if cache_resident
-                                    else "counters: VALU busier than HBM" if cd else "algorithmic bytes exceed what HBM can deliver: cache-served",
+                                    else "counters: VALU busy %.2f of its cycles, HBM at %.2f of its peak" % (cd["valu_busy_frac"], fr_hbm_measured) if cd.get("valu_busy_frac") is not None and fr_hbm_measured is not None
+                                    else "algorithmic bytes exceed what HBM can deliver: part of them is cache-served" + (" (measured HBM traffic: %.2f of the peak -- about %.2f of what a copy reaches; this walk sits close to both roofs)" % (fr_hbm_measured, fr_hbm_measured / 0.79) if fr_hbm_measured is not None else ""),
                                     ops_node, OPS_TRI, OPS_RAY)})
         else:
             roof.update({"achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fr_hbm, 5),
