@@ -1168,7 +1168,10 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
 
     int refill = 32;
     if (const char *e = getenv("NORI_HIP_WF_REFILL")) refill = std::min(64, std::max(1, atoi(e)));
-    int leaf_th = 16;
+    /* lanes at a leaf before a triangle step runs: 16 on BVH2 trees; 8 on wide trees, whose node steps are twice as long and whose
+       waves hold fewer lanes per step (terrain, trace ms at 16 / 8 / 4: 54.2 / 53.3 / 53.2; the AO scene's BVH2 walk: 62.1 / 62.6 at 8;
+       profiles/r4_05_sweeps.txt) */
+    int leaf_th = sc.wide ? 8 : 16;
     if (const char *e = getenv("NORI_HIP_WF_LEAF")) leaf_th = std::min(64, std::max(1, atoi(e)));
     int static_per_wave = 1024, dyn_div = 8;      /* chunking of wf_extend: all-static below static_per_wave paths per wave, else n / (waves * dyn_div) per claim */
     if (const char *e = getenv("NORI_HIP_WF_STATIC")) static_per_wave = std::min(4095, std::max(0, atoi(e)));
