@@ -127,20 +127,25 @@ def render_distributed(render_fn, frame, mode: str, spp: int, rank: int, world: 
 
 def render_distributed_reference(renderer, frame, spp: int, rank: int, world: int, merge_ms: list | None = None, **kw):
     """film_order = reference over the ranks (module docstring).  `renderer`: nori_amd.render.Renderer with
-    set_option("film_order", "reference"); `frame`: this rank's RGBW tensor, the merged frame on rank 0."""
+    set_option("film_order", "reference") (anything with its block_rows / block_acc_floats / render_block_rows_into /
+    resolve_blocks: the CPU tests pass a stand-in); `frame`: this rank's RGBW tensor, the merged frame on rank 0."""
+    import time
     import torch
     acc = torch.zeros(renderer.block_acc_floats(), dtype=torch.float32, device=frame.device)
     r0, rn = block_rows(rank, world, renderer.block_rows())
     stats = renderer.render_block_rows_into(acc, r0, rn, spp_count=spp, **kw)
     timed = merge_ms is not None and _group_up()
-    if timed:
+    if timed and frame.is_cuda:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+    t0 = time.perf_counter()
     reduce_frame(acc, 0)      # disjoint arrays: x + 0 = x, exact whatever order the ring adds in
     frame.zero_()
     if rank == 0:
         renderer.resolve_blocks(acc, frame)
-    if timed:
+    if timed and frame.is_cuda:
         e1.record(); e1.synchronize()
         merge_ms.append(float(e0.elapsed_time(e1)))
+    elif timed:
+        merge_ms.append((time.perf_counter() - t0) * 1e3)
     return stats

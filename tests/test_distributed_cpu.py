@@ -191,3 +191,70 @@ def test_block_row_shares_of_the_reference_order_film(size, world):
         assert tn == (min(2 * (r0 + rn), (h + 15) // 16) - min(2 * r0, (h + 15) // 16)) * ((w + 15) // 16)
         next_row, next_tile = r0 + rn, t0 + tn
     assert next_row == rows_total and next_tile == tiles
+
+
+_REFERENCE_RANK = r'''
+import os, sys
+sys.path.insert(0, os.environ["NORI_REPO"])
+import numpy as np, torch, torch.distributed as dist
+from nori_amd import dist as ndist
+
+class BlockFilm:
+    """Stand-in for a Renderer in reference order: a block's accumulator is a fixed pseudo-random array (what it holds does not matter
+    here, that every rank computes the SAME array for a block does), resolve_blocks adds the blocks covering a pixel in a fixed order."""
+    def __init__(self, w, h, border):
+        self.w, self.h, self.b = w, h, border
+        self.bx, self.by = (w + 31) // 32, (h + 31) // 32
+        self.side = 32 + 2 * border
+    def block_rows(self): return self.by
+    def block_acc_floats(self): return self.bx * self.by * self.side * self.side * 4
+    def frame_shape(self): return (self.h + 2 * self.b, self.w + 2 * self.b, 4)
+    def render_block_rows_into(self, acc, r0, rn, spp_count=None):
+        a = acc.view(self.by, self.bx, self.side, self.side, 4)
+        for by in range(r0, r0 + rn):
+            for bx in range(self.bx):
+                g = torch.Generator().manual_seed(1000 * by + bx)
+                a[by, bx] = torch.rand(self.side, self.side, 4, generator=g) * (10.0 ** ((by + bx) % 5 - 2))      # magnitudes differ: order matters
+        return {"rows": rn}
+    def resolve_blocks(self, acc, frame):
+        a = acc.view(self.by, self.bx, self.side, self.side, 4)
+        order = sorted(((by, bx) for by in range(self.by) for bx in range(self.bx)), key=lambda t: (t[0] * 7 + t[1] * 3) % 11 * 100 + t[0] * 10 + t[1])
+        for by, bx in order:                              # a fixed order that is not raster order
+            hh, ww = min(32, self.h - 32 * by) + 2 * self.b, min(32, self.w - 32 * bx) + 2 * self.b
+            frame[32 * by:32 * by + hh, 32 * bx:32 * bx + ww] += a[by, bx, :hh, :ww]
+        return frame
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="file://" + os.environ["NORI_STORE"], rank=rank, world_size=world)
+film = BlockFilm(100, 150, 2)                            # 4 x 5 blocks, clipped at both ends; 5 rows over 2 or 3 ranks
+frame = torch.zeros(film.frame_shape())
+ms = []
+st = ndist.render_distributed_reference(film, frame, 4, rank, world, merge_ms=ms)
+assert st["rows"] == ndist.block_rows(rank, world, film.block_rows())[1] and len(ms) == 1
+if rank == 0:
+    whole_acc = torch.zeros(film.block_acc_floats())
+    film.render_block_rows_into(whole_acc, 0, film.block_rows())
+    whole = film.resolve_blocks(whole_acc, torch.zeros(film.frame_shape()))
+    assert torch.equal(frame.view(torch.int32), whole.view(torch.int32)), float((frame - whole).abs().max())
+    assert float(whole.abs().sum()) > 0
+    print("REFERENCE-ORDER-GLOO-OK")
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_reference_order_merge_over_gloo_ranks(tmp_path, world):
+    """nori_amd.dist.render_distributed_reference with world_size 2 and 3 (gloo, CPU tensors, a stand-in film): every rank fills the
+    accumulators of its block rows, one reduce of the disjoint arrays, rank 0 adds the blocks in its fixed order -- the merged frame has
+    the bits of the frame one rank computes alone, although the blocks' magnitudes differ by 10^4 (a sum of per-rank FRAMES would not)."""
+    script = tmp_path / "rank.py"
+    script.write_text(_REFERENCE_RANK)
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), NORI_STORE=str(tmp_path / "store"), NORI_REPO=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, o + e
+    assert "REFERENCE-ORDER-GLOO-OK" in outs[0][0]
