@@ -249,6 +249,9 @@ typedef struct nori_render_stats {
     uint32_t engine;         /* what rendered this call: 0 = megakernel (render_kernel), 1 = wavefront (wf_extend / wf_shade),
                                 2 = the block-serial kernel of NORI_SEED_NORI_BLOCK.  The option "engine" is a request: "auto"
                                 picks by job size, and trees with wide nodes are walked by the wavefront engine only */
+    uint32_t trace_cus;      /* CUs the ray-query kernels ran on: all of the device's, or -- wavefront engine, big jobs -- all but
+                                the CUs set aside for the shading and film kernels, which then run BESIDE the ray queries of
+                                the other half of the tiles (trace_ms, shade_ms and film_ms overlap in that case) */
 } nori_render_stats;
 
 typedef struct nori_accel_info {

@@ -555,6 +555,7 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
     d.tri_mesh = ctx->d_tri_mesh;
     d.n_emitters = (uint32_t) h.emitters.size();
     d.n_meshes = (uint32_t) h.meshes.size();
+    d.bsdf_mask = 0u; for (const MeshRec &m : h.meshes) d.bsdf_mask |= 1u << (uint32_t) m.bsdf_type;
     d.n_triangles = (uint32_t) h.tri_mesh.size();
     d.n_cdf = (uint32_t) h.emitter_cdf.size();
     d.camera = h.camera; d.filter = h.filter; d.integrator = h.integrator;
@@ -1186,6 +1187,7 @@ static int render_impl(nori_hip_ctx *ctx, const nori_render_params *params, void
             stats->n_camera_samples = wst.n_camera; stats->n_closest_rays = wst.n_closest; stats->n_shadow_rays = wst.n_shadow;
             stats->n_node_tests = wst.n_nodes; stats->n_tri_tests = wst.n_tris; stats->n_invalid = wst.n_invalid;
             stats->n_workgroups = wst.n_launches;
+            stats->trace_cus = wst.trace_cus;
             if (getenv("NORI_HIP_CENSUS")) fprintf(stderr, "[wavefront] batches %u iterations %u launches %u state %.1f MB\n", wst.n_batches, wst.n_iterations, wst.n_launches, wst.state_bytes / 1048576.0);
         }
         const uint32_t need = ctx->bvh.max_depth + 1;

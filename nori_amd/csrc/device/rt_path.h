@@ -150,7 +150,18 @@ NORI_HD void surface_from_record(bool has_normals, float u, float v, f3 p0, f3 p
     else s.ns = normalized(cross(p1 - p0, p2 - p0));
 }
 
-template <int INTEG, class Tab>
+/* MATSET: the BSDF types the scene contains, bit t = nori_bsdf_type t (DevScene::bsdf_mask).  A kernel instantiated for a
+   subset never compiles the other BSDFs' sample / eval / pdf (include/nori/bsdf.h:59-87): wf_shade of an all-diffuse scene
+   (src/diffuse.cpp:23-71) is a smaller kernel with more waves per SIMD.  kAnyBsdf: every type. */
+constexpr int kAnyBsdf = 0xf;
+template <int MATSET> NORI_HD int32_t bsdf_type_in_set(int32_t type) {
+    if (MATSET == 1) return 0;                                      /* diffuse only: a constant */
+    if (MATSET == 8) return 3;
+    if (!(MATSET & 8) && type == 3) type = 0;                         /* (never taken: the type is in the set; tells the compiler) */
+    if (!(MATSET & 6) && type != 0 && type != 3) type = 0;
+    return type;
+}
+template <int INTEG, class Tab, int MATSET = kAnyBsdf>
 NORI_HD bool path_on_closest(const DevScene &sc, const Tab &tab, PathState &st, const Hit &hit, bool found, const f3 d) {
     if (!found) return true;
     const MeshRec m = tab.mesh(hit.mesh);
@@ -191,7 +202,8 @@ NORI_HD bool path_on_closest(const DevScene &sc, const Tab &tab, PathState &st, 
 
     const bool emitter = (m.flags & kMeshEmitter) != 0;
     const f3 rad = mk3(m.radiance[0], m.radiance[1], m.radiance[2]);
-    const Bsdf bsdf = bsdf_from_mesh(m);
+    Bsdf bsdf = bsdf_from_mesh(m);
+    bsdf.type = bsdf_type_in_set<MATSET>(bsdf.type);
     const f3 wi = to_local(fr, -d);
 
     if (INTEG == INT_WHITTED) {

@@ -357,6 +357,7 @@ struct DevScene {
     uint32_t wide;              /* nodes are WIDE nodes (BVH4, quantised boxes) instead of BVH2 nodes */
     uint32_t top_image_quads;   /* quads of top_image in use (its header's .w) */
     uint32_t top_image_q_quads;
+    uint32_t bsdf_mask;         /* bit t: some mesh has a BSDF of nori_bsdf_type t (wf_shade is instantiated per material set) */
     NodeqGrid grid;             /* of nodes_q */
     CameraRec camera;
     FilterRec filter;

@@ -27,6 +27,7 @@ struct WfStats {
     size_t state_bytes = 0;
     float class_ms[3] = {0.0f, 0.0f, 0.0f};      /* KernelClass: trace, shade, film */
     uint32_t class_launches[3] = {0, 0, 0};
+    uint32_t trace_cus = 0;                      /* CUs wf_extend's stream owned (fewer than the device has: shading ran beside it) */
 };
 
 /* The engine's per-context resources (path-state pool, pipe streams / events, device properties);

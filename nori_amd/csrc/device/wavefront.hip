@@ -657,6 +657,10 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
 #define NORI_SHADE_BLOCK 256
 #endif
 constexpr int kSB = NORI_SHADE_BLOCK;
+/* workgroups per CU the all-diffuse wf_shade is compiled for (4: as the general kernel) */
+#ifndef NORI_SHADE_WGS_DIFFUSE
+#define NORI_SHADE_WGS_DIFFUSE 4
+#endif
 
 /* -DNORI_EXP_SHADE=n (experiments, tools/build_variant_fast.sh + tools/ab.sh): what wf_shade is sensitive to, one resource at a time --
    1: one more dense 16-B load per path, 2: one more 16-B store per survivor, 3: 64 more VALU instructions per path, 4: one more
@@ -691,8 +695,11 @@ template <> struct ShadeTab<true> { typedef LdsTables type; static __device__ __
 #define NORI_EXP_SHADE_PREFETCH 1
 #endif
 
-template <int INTEG, bool FIRST, bool LDSTAB>
-__global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
+/* MATSET (rt_path.h): the BSDF types the scene contains -- the kernel of an all-diffuse scene carries no mirror, dielectric or
+   microfacet code; kShadeWgs: the workgroups per CU its register budget is held to */
+template <int MATSET> struct ShadeBudget { static constexpr int kWgs = MATSET == 1 ? NORI_SHADE_WGS_DIFFUSE : 4; };
+template <int INTEG, bool FIRST, bool LDSTAB, int MATSET>
+__global__ __launch_bounds__(kSB, ShadeBudget<MATSET>::kWgs) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
 #if NORI_EXP_SHADE == 5 || NORI_EXP_SHADE == 6
     __shared__ volatile char s_pad[NORI_EXP_SHADE == 5 ? 36 * 1024 : 50 * 1024];
     s_pad[threadIdx.x * 64] = 0;
@@ -772,7 +779,7 @@ __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur
                     /* pcg32 stream of this camera sample: inc from the sample index, state from HBM */
                     const uint32_t sl = (sidx % per_tile) >> 8;
                     vertex_unpack(st, fl, L4, t4, FIRST ? rng0.state : ld_w<2>(&S.rng[i]), ((uint64_t) (s_first + sl) << 1u) | 1u);
-                    done = path_on_closest<INTEG>(sc, tab, st, hit, found, mk3(d4.x, d4.y, d4.z));
+                    done = path_on_closest<INTEG, typename ShadeTab<LDSTAB>::type, MATSET>(sc, tab, st, hit, found, mk3(d4.x, d4.y, d4.z));
                     if (!done) {
                         survive = true;
                         vertex_pack(st, n_o, n_dA, n_dB, n_T, n_L, n_Ld, n_fl);
@@ -891,6 +898,12 @@ __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, W
 
 /* ----------------------------------------------------------- host driver */
 constexpr int kShadeGridMax = 4096;
+/* CUs of the shading side when the device is split (wavefront_render), and the job size from which it is */
+#ifndef NORI_SPLIT_CUS_DEFAULT
+#define NORI_SPLIT_CUS_DEFAULT 0
+#endif
+constexpr int kSplitCusDefault = NORI_SPLIT_CUS_DEFAULT;
+constexpr size_t kSplitMinSamples = (size_t) 1 << 24;
 
 int shade_grid(size_t paths) { return (int) std::min<size_t>(kShadeGridMax, std::max<size_t>(64, (paths + kShadeChunk - 1) / kShadeChunk)); }
 
@@ -995,13 +1008,20 @@ void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, 
 void launch_shade(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &bt, bool first, int grid_, hipStream_t s) {
     const dim3 grid(grid_ * (kB / kSB)), block(kSB);
     const bool lds_tables = shade_tables_fit(sc);
+    /* the material set the kernel is compiled for: all-diffuse scenes (the Cornell box of the headline), scenes without a
+       microfacet BSDF, any scene; integrators that never ask a BSDF (normals, ao, simple) have one kernel */
+    const int matset = sc.integrator.type < INT_WHITTED ? kAnyBsdf : sc.bsdf_mask == 1u ? 1 : (sc.bsdf_mask & 8u) == 0u ? 7 : kAnyBsdf;
     switch (sc.integrator.type) {
-#define SH2(I, F) if (lds_tables) hipLaunchKernelGGL((wf_shade<I, F, true>), grid, block, 0, s, sc, b, cur, bt); \
-                  else hipLaunchKernelGGL((wf_shade<I, F, false>), grid, block, 0, s, sc, b, cur, bt)
-#define SH(I) case I: if (first) { SH2(I, true); } else { SH2(I, false); } break;
-        SH(0) SH(1) SH(2) SH(3) SH(4) SH(5) SH(6)
+#define SH3(I, F, M) if (lds_tables) hipLaunchKernelGGL((wf_shade<I, F, true, M>), grid, block, 0, s, sc, b, cur, bt); \
+                     else hipLaunchKernelGGL((wf_shade<I, F, false, M>), grid, block, 0, s, sc, b, cur, bt)
+#define SH2(I, F) if (matset == 1) { SH3(I, F, 1); } else if (matset == 7) { SH3(I, F, 7); } else { SH3(I, F, kAnyBsdf); }
+#define SH1(I, F) SH3(I, F, kAnyBsdf)
+#define SH(I, W) case I: if (first) { W(I, true); } else { W(I, false); } break;
+        SH(0, SH1) SH(1, SH1) SH(2, SH1) SH(3, SH2) SH(4, SH2) SH(5, SH2) SH(6, SH2)
 #undef SH
+#undef SH1
 #undef SH2
+#undef SH3
     }
 }
 
@@ -1040,7 +1060,40 @@ struct WfEngine {
     hipStream_t streams[2] = {nullptr, nullptr};
     hipEvent_t events[3] = {nullptr, nullptr, nullptr};
     int n_cus = 0;                  /* hipDeviceProp_t::multiProcessorCount of the context's device */
+    /* the CUs of the device shared out between the two kinds of work (wavefront_render, "split"): [0] the stream of the
+       traversal kernels, on all CUs but split_cus, [1] the stream of the shading and film kernels, on split_cus CUs */
+    hipStream_t split_streams[2] = {nullptr, nullptr};
+    int split_cus = 0;
+    hipEvent_t pipe_events[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      /* per pipe: its traversal / its shading is done */
 };
+
+/* Two streams whose kernels run on disjoint sets of CUs (hipExtStreamCreateWithCUMask).  The shading side gets `cus` CUs (a
+   multiple of 8) as whole ROWS of eight consecutive mask bits, rows spread evenly over the mask: the driver hands bit i of a
+   queue's mask to XCD i mod 8 and walks an XCD's shader engines with the bits it gets, so a row is one CU of every XCD and the
+   two sets are even over XCDs and shader engines.  Returns false (and leaves the engine unsplit) if the runtime refuses. */
+bool ensure_split_streams(WfEngine &e, int cus) {
+    if (e.split_cus == cus && e.split_streams[0] && e.split_streams[1]) return true;
+    for (hipStream_t &st : e.split_streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
+    e.split_cus = 0;
+    const int rows_total = e.n_cus / 8, rows = cus / 8;
+    if (rows < 1 || rows >= rows_total) return false;
+    const uint32_t words = (uint32_t) ((e.n_cus + 31) / 32);
+    std::vector<uint32_t> shade(words, 0u), extend(words, 0u);
+    std::vector<char> taken((size_t) rows_total, 0);
+    for (int j = 0; j < rows; ++j) taken[(size_t) ((long long) j * rows_total / rows)] = 1;
+    for (int i = 0; i < e.n_cus; ++i) {
+        const bool in_row = i / 8 < rows_total && taken[(size_t) (i / 8)];
+        (in_row ? shade : extend)[(size_t) i / 32] |= 1u << (i % 32);
+    }
+    if (hipExtStreamCreateWithCUMask(&e.split_streams[0], words, extend.data()) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&e.split_streams[1], words, shade.data()) != hipSuccess) {
+        (void) hipGetLastError();
+        for (hipStream_t &st : e.split_streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
+        return false;
+    }
+    e.split_cus = cus;
+    return true;
+}
 
 WfEngine *wavefront_create() {
     WfEngine *e = new WfEngine();
@@ -1054,7 +1107,9 @@ void wavefront_destroy(WfEngine *e) {
     if (!e) return;
     e->pool.release();
     for (hipStream_t &st : e->streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
+    for (hipStream_t &st : e->split_streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
     for (hipEvent_t &ev : e->events) if (ev) { (void) hipEventDestroy(ev); ev = nullptr; }
+    for (auto &pe : e->pipe_events) for (hipEvent_t &ev : pe) if (ev) { (void) hipEventDestroy(ev); ev = nullptr; }
     delete e;
 }
 
@@ -1081,7 +1136,9 @@ size_t wavefront_held_bytes(const WfEngine *e, const FilmStore &film) {
    HIP stream.  Two pipes interleave so that one pipe's wf_shade (HBM-bound) overlaps the other
    pipe's wf_extend (VALU-bound); the persistent extend grid is sized to leave room for it. */
 struct Pipe {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;            /* shading, film, counters: everything but ... */
+    hipStream_t extend_stream = nullptr;     /* ... the traversal kernels (the same stream unless the CUs are split) */
+    hipEvent_t ev_extend = nullptr, ev_shade = nullptr;      /* split: the hand-over between the two streams */
     WfBuf b;
     FilmStore film;
     uint32_t *h_ctr = nullptr;
@@ -1118,7 +1175,20 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
 
     int n_pipes = 1;        /* measured: 2 pipes are 5 % slower (wf_extend wants all 8 waves/SIMD); NORI_HIP_WF_PIPES=2 to try */
     if (const char *e = getenv("NORI_HIP_WF_PIPES")) n_pipes = std::min(2, std::max(1, atoi(e)));
+    /* Split: the device's CUs shared out between the two kinds of work.  wf_extend is bound by the vector ALU (its time follows
+       the number of CUs it runs on), wf_shade and the film by the memory system (theirs does not, down to a few dozen CUs): run
+       one after the other, each leaves idle what the other needs.  Two pipes -- each half of the tiles -- with the traversal
+       kernels of both on a stream that owns all CUs but `split_cus`, shading and film on a stream that owns those: while one
+       pipe's paths are traversed the other pipe's are shaded, both kernels at their full occupancy on their own CUs (two pipes
+       that SHARE every CU halve each kernel's waves per SIMD and gain nothing: profiles/r4_05).  NORI_HIP_WF_SPLIT_CUS: CUs of
+       the shading side (a multiple of 8; 0: no split). */
+    int split_cus = kSplitCusDefault;
+    if (const char *e = getenv("NORI_HIP_WF_SPLIT_CUS")) split_cus = std::max(0, atoi(e)) & ~7;
+    if (getenv("NORI_HIP_WF_PIPES")) split_cus = 0;
+    if (L.n_sel_tiles < 2 || (size_t) L.n_sel_tiles * 256 * L.spp_count < kSplitMinSamples || L.film_reference || L.count_traversal) split_cus = 0;
     if (L.n_sel_tiles < 2 || (size_t) L.n_sel_tiles * 256 * L.spp_count < ((size_t) 1 << 22)) n_pipes = 1;
+    if (split_cus > 0 && ensure_split_streams(eng, split_cus)) n_pipes = 2; else split_cus = 0;
+    const bool split = split_cus > 0;
 
     /* state budget per pipe; batch = a range of the pipe's tiles x as many samples per pixel as fit */
     const size_t budget = std::max<size_t>(L.max_paths / n_pipes, 256);
@@ -1151,10 +1221,14 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     for (int k = 0; k < 3; ++k) if (!g_events[k]) WF_TRY(hipEventCreateWithFlags(&g_events[k], hipEventDisableTiming));
     for (int k = 0; k < n_pipes; ++k) {
         Pipe &P = pipes[k];
-        if (n_pipes == 1) P.stream = s;
+        if (split) {
+            P.extend_stream = eng.split_streams[0]; P.stream = eng.split_streams[1];
+            for (hipEvent_t &ev : eng.pipe_events[k]) if (!ev) WF_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            P.ev_extend = eng.pipe_events[k][0]; P.ev_shade = eng.pipe_events[k][1];
+        } else if (n_pipes == 1) P.stream = P.extend_stream = s;
         else {
             if (!g_streams[k]) WF_TRY(hipStreamCreateWithFlags(&g_streams[k], hipStreamNonBlocking));
-            P.stream = g_streams[k];
+            P.stream = P.extend_stream = g_streams[k];
         }
         P.b = slice(g_pool.buf, records * k, records, k);
         P.film = film; P.film.pos += per_pipe * k; P.film.L += per_pipe * k;
@@ -1163,7 +1237,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     }
     if (n_pipes > 1) {      /* the pipes start after whatever the caller queued on its stream */
         WF_TRY(hipEventRecord(g_events[2], s));
-        for (int k = 0; k < n_pipes; ++k) WF_TRY(hipStreamWaitEvent(pipes[k].stream, g_events[2], 0));
+        for (int k = 0; k < n_pipes; ++k) { WF_TRY(hipStreamWaitEvent(pipes[k].stream, g_events[2], 0)); if (split) WF_TRY(hipStreamWaitEvent(pipes[k].extend_stream, g_events[2], 0)); }
     }
 
     int refill = 32;
@@ -1214,10 +1288,12 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
        128 spp at 4 / 5 / 6 / 7 / 8 workgroups per CU: 65.7 / 57.8 / 53.9 / 53.6 / 54.2 -- the last two with the first pass still on the
        same grid; how many records the LDS image holds does not matter there: 113, 40 or none, profiles/r4_07_c5_occupancy.txt.) */
     if (sc.wide) per_cu = std::min(per_cu, kExtendWgsWide);
-    if (n_pipes > 1) per_cu = std::max(1, per_cu / 2);
+    if (n_pipes > 1 && !split) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(2048 / extend_block, std::max(1, atoi(e)));
-    const int extend_grid_first = eng.n_cus * (sc.wide ? std::min(per_cu, kExtendWgsWideFirst) : per_cu);
-    const int extend_grid = eng.n_cus * per_cu;
+    const int extend_cus = eng.n_cus - split_cus;      /* the persistent grid fills the CUs its stream owns */
+    const int extend_grid_first = extend_cus * (sc.wide ? std::min(per_cu, kExtendWgsWideFirst) : per_cu);
+    const int extend_grid = extend_cus * per_cu;
+    stats.trace_cus = (uint32_t) extend_cus;
     if (L.stack_depth > 16) {      /* wf_finish keeps 16 entries in LDS */
         const size_t per_pipe_ints = (size_t) (L.stack_depth - 16) * std::max(extend_grid * extend_block, finish_grid * kB), ints = per_pipe_ints * n_pipes;
         if (g_pool.spill_ints < ints) {
@@ -1263,6 +1339,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             P.bt.inner_repeat = inner_repeat;
             P.bt.flags = (no_asm_loop ? kBatchNoAsmLoop : 0u) | (count_q ? kBatchCountQ : 0u);
             WF_TRY(hipMemsetAsync(P.b.ctr, 0, C_COUNT * sizeof(uint32_t), P.stream));
+            if (split) WF_TRY(hipEventRecord(P.ev_shade, P.stream));      /* (and the film of the pipe's last batch, which read the sample store) */
             stats.n_batches++;
             P.cur = 0; P.first = true; P.active = true; any = true; P.batch_rounds = 0;
         }
@@ -1276,13 +1353,16 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             for (int k = 0; k < n_pipes; ++k) {
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
-                timer.begin(KC_TRACE, P.stream);
-                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, P.first ? extend_grid_first : extend_grid, P.bt, P.stream);
+                if (split) WF_TRY(hipStreamWaitEvent(P.extend_stream, P.ev_shade, 0));
+                timer.begin(KC_TRACE, P.extend_stream);
+                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, P.first ? extend_grid_first : extend_grid, P.bt, P.extend_stream);
                 WF_TRY(hipGetLastError());      /* a launch that did not fit (LDS, registers) must not pass for an empty pass */
-                timer.end(P.stream);
+                timer.end(P.extend_stream);
+                if (split) { WF_TRY(hipEventRecord(P.ev_extend, P.extend_stream)); WF_TRY(hipStreamWaitEvent(P.stream, P.ev_extend, 0)); }
                 timer.begin(KC_SHADE, P.stream);
                 launch_shade(sc, P.b, P.cur, P.bt, P.first, sh_grid, P.stream);
                 timer.end(P.stream);
+                if (split) WF_TRY(hipEventRecord(P.ev_shade, P.stream));
                 P.first = false;
                 P.cur ^= 1;
                 stats.n_launches += 2;

@@ -196,6 +196,46 @@ static f3 run_path_records(const DevScene &sc, const RayIn &cam, uint64_t rng_st
 extern "C" {
 
 /* tools/wave_sim.py: counts[level][14] for the first `max_levels` passes of a spp-sample frame under `policy` (7 ints) */
+/* policy[8 .. 11] (emu_wave_sim_ex): tile stride (only tiles whose index is a multiple are simulated -- a full-resolution frame
+   sampled), sort window in paths (0: none), key kind, origin-cell bits per axis.  Key kinds: 1 octant of the first ray traced;
+   2 (Morton cell of the origin, octant of the continuation ray); 3 (octant of the continuation ray, Morton cell); 4 as 2 with the
+   "has a shadow ray" bit on top; 5 (cell, 6-bit direction code of the continuation ray: octant + order of the components) */
+static uint32_t sim_morton3(uint32_t x, uint32_t y, uint32_t z, int bits) {
+    uint32_t m = 0;
+    for (int b = 0; b < bits; ++b) m |= (((x >> b) & 1u) << (3 * b)) | (((y >> b) & 1u) << (3 * b + 1)) | (((z >> b) & 1u) << (3 * b + 2));
+    return m;
+}
+static uint32_t sim_sort_key(const DevScene &sc, const SimEntry &e, int kind, int bits) {
+    const RayIn &first = e.hasB ? e.B : e.A;
+    const RayIn &cont = e.hasA ? e.A : e.B;
+    auto oct = [](const RayIn &r) { return (uint32_t) ((r.d.x < 0.0f ? 1 : 0) | (r.d.y < 0.0f ? 2 : 0) | (r.d.z < 0.0f ? 4 : 0)); };
+    if (kind == 1) return oct(first);
+    const float o[3] = {cont.o.x, cont.o.y, cont.o.z};
+    uint32_t q[3];
+    for (int a = 0; a < 3; ++a) {      /* the 16-bit grid of the node records (rt_nodeq.h) spans the scene: its top bits */
+        const float t = (o[a] - sc.grid.mn[a]) / (sc.grid.scale[a] * 65536.0f);
+        q[a] = (uint32_t) std::min((float) ((1 << bits) - 1), std::max(0.0f, t * (float) (1 << bits)));
+    }
+    const uint32_t cell = sim_morton3(q[0], q[1], q[2], bits);
+    if (kind == 2) return (cell << 3) | oct(cont);
+    if (kind == 3) return (oct(cont) << (3 * bits)) | cell;
+    if (kind == 4) return ((e.hasB ? 1u : 0u) << (3 * bits + 3)) | (cell << 3) | oct(cont);
+    if (kind == 5) {
+        const float ax = std::fabs(cont.d.x), ay = std::fabs(cont.d.y), az = std::fabs(cont.d.z);
+        const uint32_t major = ax >= ay && ax >= az ? 0u : ay >= az ? 1u : 2u;
+        return (cell << 5) | (oct(cont) << 2) | major;
+    }
+    if (kind == 6 || kind == 7) {      /* the continuation direction on the octahedral map, 16 x 16 cells */
+        const float n1 = std::fabs(cont.d.x) + std::fabs(cont.d.y) + std::fabs(cont.d.z);
+        float u = cont.d.x / n1, v = cont.d.y / n1;
+        if (cont.d.z < 0.0f) { const float uu = (1.0f - std::fabs(v)) * (u < 0.0f ? -1.0f : 1.0f), vv = (1.0f - std::fabs(u)) * (v < 0.0f ? -1.0f : 1.0f); u = uu; v = vv; }
+        const uint32_t du = (uint32_t) std::min(15.0f, std::max(0.0f, (u * 0.5f + 0.5f) * 16.0f)), dv = (uint32_t) std::min(15.0f, std::max(0.0f, (v * 0.5f + 0.5f) * 16.0f));
+        const uint32_t dir = sim_morton3(du, dv, 0u, 4);
+        return kind == 6 ? (dir << (3 * bits)) | cell : (cell << 12) | dir;
+    }
+    return 0u;
+}
+
 int emu_wave_sim(emu_ctx *c, uint32_t spp, uint32_t max_levels, const int *policy, uint64_t *counts) {
     const DevScene &sc = c->dev;
     if (sc.integrator.type != 6) return NORI_ERR_INVALID_ARGUMENT;      /* path_mis only */
@@ -203,7 +243,8 @@ int emu_wave_sim(emu_ctx *c, uint32_t spp, uint32_t max_levels, const int *polic
     const uint32_t tiles_x = (W + kTile - 1) / kTile, tiles_y = (H + kTile - 1) / kTile;
     std::vector<std::vector<SimEntry>> levels;
     ArrayStack stack;
-    for (uint32_t tile = 0; tile < tiles_x * tiles_y; ++tile)
+    const uint32_t tile_stride = policy[8] > 0 ? (uint32_t) policy[8] : 1u;
+    for (uint32_t tile = 0; tile < tiles_x * tiles_y; tile += tile_stride)
         for (uint32_t s = 0; s < spp; ++s)
             for (int pix = 0; pix < 256; ++pix) {
                 const int px = (int) (tile % tiles_x) * kTile + (((pix >> 6) & 1) << 3) + (pix & 7), py = (int) (tile / tiles_x) * kTile + ((pix >> 7) << 3) + ((pix & 63) >> 3);      /* film.h, film_tile_pixel */
@@ -215,11 +256,21 @@ int emu_wave_sim(emu_ctx *c, uint32_t spp, uint32_t max_levels, const int *polic
                 sim_capture_path<6>(sc, cam, rng.state, rng.inc, stack, levels, max_levels);
             }
     SimPolicy P; P.refill_threshold = policy[0]; P.leaf_threshold = policy[1]; P.inner_repeat = policy[2]; P.postpone = policy[3]; P.chunk = policy[4]; P.sort_octant = policy[5]; P.pend_threshold = policy[6]; P.pretest = policy[7];
+    const size_t window = (size_t) std::max(0, policy[9]);
+    const int kind = policy[10], bits = policy[11];
     for (size_t k = 0; k < levels.size() && k < max_levels; ++k) {
         std::vector<SimEntry> &e = levels[k];
         if (P.sort_octant)
             for (size_t b = 0; b < e.size(); b += 256)
                 std::stable_sort(e.begin() + b, e.begin() + std::min(e.size(), b + 256), [](const SimEntry &x, const SimEntry &y) { return sim_octant(x) < sim_octant(y); });
+        if (window && kind && k > 0) {
+            std::vector<std::pair<uint32_t, uint32_t>> keys(e.size());
+            for (size_t i = 0; i < e.size(); ++i) keys[i] = std::make_pair(sim_sort_key(sc, e[i], kind, bits), (uint32_t) i);
+            for (size_t b = 0; b < e.size(); b += window) std::stable_sort(keys.begin() + b, keys.begin() + std::min(e.size(), b + window));
+            std::vector<SimEntry> sorted(e.size());
+            for (size_t i = 0; i < e.size(); ++i) sorted[i] = e[keys[i].second];
+            e.swap(sorted);
+        }
         SimCounts C; std::memset(&C, 0, sizeof(C));
         for (size_t b = 0; b < e.size(); b += (size_t) P.chunk) sim_wave(sc, e.data() + b, std::min((size_t) P.chunk, e.size() - b), P, C);
         std::memcpy(counts + k * 16, &C, sizeof(C));

@@ -57,10 +57,15 @@ def test_the_production_traversal_kernels_keep_their_register_budget(wavefront_k
 def test_the_shading_kernels_do_not_spill(wavefront_kernels):
     rows, _ = wavefront_kernels
     for integ in range(7):
-        for first in ("true", "false"):
-            for lds_tables in ("true", "false"):      # wf_shade<INTEG, FIRST, LDSTAB>
-                k = _find(rows, f"wf_shade<{integ}, {first}, {lds_tables}>")
-                assert k["vgpr"] <= 128 and k["scratch"] == 0, k
+        # wf_shade<INTEG, FIRST, LDSTAB, MATSET>: integrators that ask a BSDF are compiled per material set (rt_path.h: 1 = all
+        # diffuse, 7 = no microfacet, 15 = any); the others once
+        for matset in ((1, 7, 15) if integ >= 3 else (15,)):
+            for first in ("true", "false"):
+                for lds_tables in ("true", "false"):
+                    k = _find(rows, f"wf_shade<{integ}, {first}, {lds_tables}, {matset}>")
+                    assert k["vgpr"] <= 128 and k["scratch"] == 0, k
+    # what the specialisation is for: the all-diffuse kernel of the headline scene is smaller than the general one
+    assert _find(rows, "wf_shade<6, false, true, 1>")["vgpr"] < _find(rows, "wf_shade<6, false, true, 15>")["vgpr"]
 
 
 def test_the_node_loop_reads_a_node_in_two_loads(wavefront_kernels):
