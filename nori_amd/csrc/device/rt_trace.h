@@ -258,8 +258,15 @@ NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
     f4 q0, q1, q2, q3;
     node_fetch(sc, top, tv.node, q0, q1, q2, q3);
 #if defined(__HIP_DEVICE_COMPILE__) && defined(NORI_EXP_WIDE_SENS)
-    /* (experiment: what one more / one fewer vector-memory instruction per wide node step is worth) */
+    /* (experiment: what one more vector-memory instruction per wide node step is worth -- 1 --, or 32 more VALU instructions -- 3) */
+#if NORI_EXP_WIDE_SENS == 3
+    { float x = q0.x; asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\t"
+                                 "v_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\t"
+                                 "v_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\t"
+                                 "v_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0" : "+v"(x)); q0.x = x; }
+#else
     if (!(tv.node & kTopBit)) { const f4 x = sc.nodes[(size_t) tv.node * kNodeQuads + (NORI_EXP_WIDE_SENS == 1 ? 3 : 2)]; asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
+#endif
 #endif
     if (COUNT) cnt.nodes++;
     const uint32_t meta = f2u(q0.w);
@@ -292,6 +299,27 @@ NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
     const uint32_t axis = (meta >> 24) & 3u;
     const bool rev = (axis == 0u && nx) || (axis == 1u && ny) || (axis == 2u && nz);      /* booleans only: selecting a component
                                                                                             of tv.rcp by index would send tv to scratch */
+    /* The same walk written as selects (the form with a lambda per slot compiled to ~25 skip branches and four regions with their
+       own copies of first / firstKey): slot j of the visiting order is slot j for a reversed ray, slot 3 - j otherwise; the first hit
+       child seen becomes `first`; a later one either takes its place (key <= firstKey: the old first is pushed) or is pushed itself. */
+#ifndef NORI_WIDE_VISIT_SELECTS
+#define NORI_WIDE_VISIT_SELECTS 1
+#endif
+#if NORI_WIDE_VISIT_SELECTS
+    const bool ha = rev ? h0 : h3, hb = rev ? h1 : h2, hc = rev ? h2 : h1, hd = rev ? h3 : h0;
+    const float ka = rev ? n0 : n3, kb = rev ? n1 : n2, kc = rev ? n2 : n1, kd = rev ? n3 : n0;
+    const int la = rev ? l0 : l3, lb = rev ? l1 : l2, lc = rev ? l2 : l1, ld = rev ? l3 : l0;
+    int first = la; float firstKey = ka; bool have = ha;
+#define NORI_WIDE_VISIT(h, key, lk) { \
+        const bool closer = (key) <= firstKey; \
+        if ((h) && have) stack.push(closer ? first : (lk)); \
+        const bool take = (h) && (!have || closer); \
+        first = take ? (lk) : first; firstKey = take ? (key) : firstKey; have = have || (h); }
+    NORI_WIDE_VISIT(hb, kb, lb)
+    NORI_WIDE_VISIT(hc, kc, lc)
+    NORI_WIDE_VISIT(hd, kd, ld)
+#undef NORI_WIDE_VISIT
+#else
     int first = kTravDone; float firstKey = 0.0f; bool have = false;
     auto visit = [&](bool h, float key, int lk) {
         if (!h) return;
@@ -303,6 +331,7 @@ NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
     visit(rev ? h1 : h2, rev ? n1 : n2, rev ? l1 : l2);
     visit(rev ? h2 : h1, rev ? n2 : n1, rev ? l2 : l1);
     visit(rev ? h3 : h0, rev ? n3 : n0, rev ? l3 : l0);
+#endif
     if (have) tv.node = first;
     else trav_pop(stack, tv);
 }

@@ -42,6 +42,7 @@
 #include "rt_path.h"
 #include "wavefront.h"
 #include "wf_records.h"
+#include "wf_sort.h"
 
 using namespace nrt;
 
@@ -80,6 +81,7 @@ struct WfBuf {
     uint32_t capacity; /* records per copy */
     int *stack_spill;  /* [entry beyond the LDS stack][lane of the wf_extend grid] */
     unsigned long long *census;   /* Z_* counters or null */
+    const uint32_t *perm;         /* wf_extend (later passes) takes slot perm[k] where it would take slot k (wf_sort.h), or null */
 };
 
 struct WfBatch {
@@ -550,7 +552,8 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
                     }
                 }
             } else if (pend || (!trav_active(tv) && rank < avail)) {
-                const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
+                uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
+                if (b.perm != nullptr && !pend) i = b.perm[i];      /* the pass in sorted order (wf_sort.h) */
                 /* a fresh path: origin and both directions (the flags ride with the continuation direction) are requested
                    together -- one round trip to HBM instead of two (the direction a path needs first depends on its
                    flags).  A path whose shadow ray was just answered needs its continuation direction again (16 B; its
@@ -1010,7 +1013,8 @@ void launch_shade(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &bt
     const bool lds_tables = shade_tables_fit(sc);
     /* the material set the kernel is compiled for: all-diffuse scenes (the Cornell box of the headline), scenes without a
        microfacet BSDF, any scene; integrators that never ask a BSDF (normals, ao, simple) have one kernel */
-    const int matset = sc.integrator.type < INT_WHITTED ? kAnyBsdf : sc.bsdf_mask == 1u ? 1 : (sc.bsdf_mask & 8u) == 0u ? 7 : kAnyBsdf;
+    int matset = sc.integrator.type < INT_WHITTED ? kAnyBsdf : sc.bsdf_mask == 1u ? 1 : (sc.bsdf_mask & 8u) == 0u ? 7 : kAnyBsdf;
+    if (getenv("NORI_HIP_SHADE_ANY_BSDF")) matset = kAnyBsdf;      /* A/B: the general kernel whatever the scene holds */
     switch (sc.integrator.type) {
 #define SH3(I, F, M) if (lds_tables) hipLaunchKernelGGL((wf_shade<I, F, true, M>), grid, block, 0, s, sc, b, cur, bt); \
                      else hipLaunchKernelGGL((wf_shade<I, F, false, M>), grid, block, 0, s, sc, b, cur, bt)
@@ -1065,6 +1069,7 @@ struct WfEngine {
     hipStream_t split_streams[2] = {nullptr, nullptr};
     int split_cus = 0;
     hipEvent_t pipe_events[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      /* per pipe: its traversal / its shading is done */
+    WfSortBuffers sort;             /* NORI_HIP_WF_SORT: the passes reordered before wf_extend (wf_sort.h) */
 };
 
 /* Two streams whose kernels run on disjoint sets of CUs (hipExtStreamCreateWithCUMask).  The shading side gets `cus` CUs (a
@@ -1106,6 +1111,7 @@ WfEngine *wavefront_create() {
 void wavefront_destroy(WfEngine *e) {
     if (!e) return;
     e->pool.release();
+    e->sort.release();
     for (hipStream_t &st : e->streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
     for (hipStream_t &st : e->split_streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
     for (hipEvent_t &ev : e->events) if (ev) { (void) hipEventDestroy(ev); ev = nullptr; }
@@ -1185,8 +1191,11 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     int split_cus = kSplitCusDefault;
     if (const char *e = getenv("NORI_HIP_WF_SPLIT_CUS")) split_cus = std::max(0, atoi(e)) & ~7;
     if (getenv("NORI_HIP_WF_PIPES")) split_cus = 0;
-    if (L.n_sel_tiles < 2 || (size_t) L.n_sel_tiles * 256 * L.spp_count < kSplitMinSamples || L.film_reference || L.count_traversal) split_cus = 0;
+    size_t split_min = kSplitMinSamples;
+    if (const char *e = getenv("NORI_HIP_WF_SPLIT_MIN")) split_min = (size_t) std::max(0ll, atoll(e));
+    if (L.n_sel_tiles < 2 || (size_t) L.n_sel_tiles * 256 * L.spp_count < split_min || L.film_reference || L.count_traversal) split_cus = 0;
     if (L.n_sel_tiles < 2 || (size_t) L.n_sel_tiles * 256 * L.spp_count < ((size_t) 1 << 22)) n_pipes = 1;
+    if (split_cus >= eng.n_cus) split_cus = 0;
     if (split_cus > 0 && ensure_split_streams(eng, split_cus)) n_pipes = 2; else split_cus = 0;
     const bool split = split_cus > 0;
 
@@ -1323,7 +1332,13 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
         WF_TRY(hipMalloc((void **) &d_census, Z_COUNT * sizeof(unsigned long long)));
         WF_TRY(hipMemsetAsync(d_census, 0, Z_COUNT * sizeof(unsigned long long), s));
     }
-    for (int k = 0; k < n_pipes; ++k) pipes[k].b.census = d_census;
+    for (int k = 0; k < n_pipes; ++k) { pipes[k].b.census = d_census; pipes[k].b.perm = nullptr; }
+    /* NORI_HIP_WF_SORT=kind[,cell bits][,from pass][,to pass]: the paths of the later passes sorted before wf_extend (wf_sort.h).
+       Needs the path count on the host before every pass: one readback per iteration. */
+    WfSortParams sortp; int sort_from = 1, sort_to = 1 << 30;
+    if (const char *e = getenv("NORI_HIP_WF_SORT")) { int a = 0, bb = 5, c = 1, d = 1 << 30; const int got = sscanf(e, "%d,%d,%d,%d", &a, &bb, &c, &d); sortp.kind = got >= 1 ? a : 0; sortp.cell_bits = bb; sort_from = c; sort_to = d; }
+    if (n_pipes != 1 || L.count_traversal) sortp.kind = 0;
+    if (sortp.kind) sync_every = 1;
     FilmLaunch fl;
     fl.tile_mod = L.tile_mod; fl.tile_rem = L.tile_rem; fl.tiles_x = L.tiles_x; fl.tiles_y = L.tiles_y; fl.tile_w = L.tile_w;
 
@@ -1354,6 +1369,14 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
                 if (split) WF_TRY(hipStreamWaitEvent(P.extend_stream, P.ev_shade, 0));
+                P.b.perm = nullptr;
+                if (sortp.kind && !P.first && (int) P.batch_rounds >= sort_from && (int) P.batch_rounds <= sort_to && P.h_ctr[C_N + P.cur] > (uint32_t) finish_paths) {
+                    timer.begin(KC_SORT, P.stream);
+                    err = wf_sort_pass(eng.sort, sc, P.b.st[P.cur].o, P.b.st[P.cur].dA, P.h_ctr[C_N + P.cur], sortp, P.stream);
+                    timer.end(P.stream);
+                    if (!err.empty()) return err;
+                    P.b.perm = eng.sort.vals[1];
+                }
                 timer.begin(KC_TRACE, P.extend_stream);
                 launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, P.first ? extend_grid_first : extend_grid, P.bt, P.extend_stream);
                 WF_TRY(hipGetLastError());      /* a launch that did not fit (LDS, registers) must not pass for an empty pass */
@@ -1428,6 +1451,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     }
     stats.n_invalid = film_invalid_count(film, s);
     timer.collect(stats.class_ms, stats.class_launches);
+    if (sortp.kind && L.time_kernels) fprintf(stderr, "[wavefront sort] kind %d, %d cell bits: %.2f ms in %u calls\n", sortp.kind, sortp.cell_bits, stats.class_ms[KC_SORT], stats.class_launches[KC_SORT]);
     if (d_census) {
         unsigned long long z[Z_COUNT];
         WF_TRY(hipMemcpy(z, d_census, sizeof(z), hipMemcpyDeviceToHost));

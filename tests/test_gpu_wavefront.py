@@ -140,6 +140,31 @@ def test_wavefront_schedule_knobs_do_not_change_the_frame(renderer_factory):
         assert np.array_equal(b, ref), env
 
 
+def test_cus_split_between_traversal_and_shading_give_the_same_frame(renderer_factory):
+    """The device's CUs shared out between the traversal stream and the shading / film stream (wavefront_render, "split"): two
+    pipes, each half of the tiles, the kernels of the two kinds on disjoint CUs.  Same samples, same order per pixel: the frame
+    has the bits of the one-stream frame and the ray counts are equal; the stats say how many CUs the ray queries had."""
+    sc = scenes.cornell_box(160, 128, 12, "path_mis", sphere_bsdfs=[Bsdf("mirror"), Bsdf("dielectric")])
+    wf = renderer_factory(sc)
+    wf.set_option("engine", "wavefront")
+    ref, sr = wf.render_host()
+    assert sr["trace_cus"] > 0
+    for cus in (8, 64, 128):
+        b, sb = _with_env({"NORI_HIP_WF_SPLIT_CUS": cus, "NORI_HIP_WF_SPLIT_MIN": 0}, lambda: wf.render_host())
+        assert sb["trace_cus"] == sr["trace_cus"] - cus, (cus, sb["trace_cus"], sr["trace_cus"])
+        assert np.array_equal(b, ref), cus
+        for k in ("n_camera_samples", "n_closest_rays", "n_shadow_rays"):
+            assert sr[k] == sb[k], (cus, k)
+    # several batches per pipe (a small path budget), and the tail kernel off.  (The film adds a pixel's samples batch by batch:
+    # the frame to compare with is the one of two pipes with the same budget on ONE stream.)
+    wf.set_option("wavefront_paths", 1 << 16)
+    ref2, sr2 = _with_env({"NORI_HIP_WF_PIPES": 2}, lambda: wf.render_host())
+    for env in ({}, {"NORI_HIP_WF_FINISH": 0}, {"NORI_HIP_WF_SYNC_EVERY": 1}):
+        b, sb = _with_env({"NORI_HIP_WF_SPLIT_CUS": 48, "NORI_HIP_WF_SPLIT_MIN": 0, **env}, lambda: wf.render_host())
+        assert np.array_equal(b, ref2), env
+        assert sr2["n_closest_rays"] == sb["n_closest_rays"] and sr2["n_shadow_rays"] == sb["n_shadow_rays"], env
+
+
 def test_wavefront_deep_tree_spills_the_stack(renderer_factory):
     """LBVH over a triangle soup is deeper than 16: with NORI_HIP_WF_STACK=16 wf_extend keeps 16 stack
     entries in LDS and the rest in its global spill columns; same frame and counts as the megakernel
