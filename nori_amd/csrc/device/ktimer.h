@@ -10,7 +10,7 @@
 
 namespace nrt {
 
-enum KernelClass { KC_TRACE = 0, KC_SHADE = 1, KC_FILM = 2, KC_SORT = 3, KC_COUNT = 4 };
+enum KernelClass { KC_TRACE = 0, KC_SHADE = 1, KC_FILM = 2, KC_COUNT = 3 };
 
 class KernelTimer {
 public:

@@ -556,16 +556,6 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
     d.n_emitters = (uint32_t) h.emitters.size();
     d.n_meshes = (uint32_t) h.meshes.size();
     d.bsdf_mask = 0u; for (const MeshRec &m : h.meshes) d.bsdf_mask |= 1u << (uint32_t) m.bsdf_type;
-    {
-        float lo[3] = {0.0f, 0.0f, 0.0f}, hi[3] = {0.0f, 0.0f, 0.0f};
-        bool any = false;
-        for (const f4 &p : h.positions) {
-            const float q[3] = {p.x, p.y, p.z};
-            for (int a = 0; a < 3; ++a) { if (!any || q[a] < lo[a]) lo[a] = q[a]; if (!any || q[a] > hi[a]) hi[a] = q[a]; }
-            any = true;
-        }
-        for (int a = 0; a < 3; ++a) { d.bounds_lo[a] = lo[a]; d.bounds_inv[a] = hi[a] > lo[a] ? 1.0f / (hi[a] - lo[a]) : 0.0f; }
-    }
     d.n_triangles = (uint32_t) h.tri_mesh.size();
     d.n_cdf = (uint32_t) h.emitter_cdf.size();
     d.camera = h.camera; d.filter = h.filter; d.integrator = h.integrator;

@@ -253,21 +253,14 @@ NORI_HD Wide4 wide_planes(uint32_t w, float A, float B) {
     return r;
 }
 
+#ifndef NORI_LAB_WIDE_STEP
+#define NORI_LAB_WIDE_STEP      /* (wf_experiments.h, variant builds: perturbations of the step) */
+#endif
 template <bool COUNT, class Stack>
 NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, TraversalCounters &cnt, TopNodesP top = nullptr) {
     f4 q0, q1, q2, q3;
     node_fetch(sc, top, tv.node, q0, q1, q2, q3);
-#if defined(__HIP_DEVICE_COMPILE__) && defined(NORI_EXP_WIDE_SENS)
-    /* (experiment: what one more vector-memory instruction per wide node step is worth -- 1 --, or 32 more VALU instructions -- 3) */
-#if NORI_EXP_WIDE_SENS == 3
-    { float x = q0.x; asm volatile("v_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\t"
-                                 "v_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\t"
-                                 "v_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\t"
-                                 "v_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0\n\tv_mov_b32 %0, %0" : "+v"(x)); q0.x = x; }
-#else
-    if (!(tv.node & kTopBit)) { const f4 x = sc.nodes[(size_t) tv.node * kNodeQuads + (NORI_EXP_WIDE_SENS == 1 ? 3 : 2)]; asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
-#endif
-#endif
+    NORI_LAB_WIDE_STEP
     if (COUNT) cnt.nodes++;
     const uint32_t meta = f2u(q0.w);
     const int l0 = (int) f2u(q3.x), l1 = (int) f2u(q3.y), l2 = (int) f2u(q3.z), l3 = (int) f2u(q3.w);
@@ -299,13 +292,10 @@ NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
     const uint32_t axis = (meta >> 24) & 3u;
     const bool rev = (axis == 0u && nx) || (axis == 1u && ny) || (axis == 2u && nz);      /* booleans only: selecting a component
                                                                                             of tv.rcp by index would send tv to scratch */
-    /* The same walk written as selects (the form with a lambda per slot compiled to ~25 skip branches and four regions with their
-       own copies of first / firstKey): slot j of the visiting order is slot j for a reversed ray, slot 3 - j otherwise; the first hit
-       child seen becomes `first`; a later one either takes its place (key <= firstKey: the old first is pushed) or is pushed itself. */
-#ifndef NORI_WIDE_VISIT_SELECTS
-#define NORI_WIDE_VISIT_SELECTS 1
-#endif
-#if NORI_WIDE_VISIT_SELECTS
+    /* Written as selects (a lambda per slot with branches compiled to ~25 skip branches and four regions with their own copies of
+       first / firstKey: 203 vector + 136 scalar instructions per step against 180 + 106 now; terrain wf_extend -0.5 %): slot j of
+       the visiting order is slot j for a reversed ray, slot 3 - j otherwise; the first hit child seen becomes `first`; a later one
+       either takes its place (key <= firstKey: the old first is pushed) or is pushed itself. */
     const bool ha = rev ? h0 : h3, hb = rev ? h1 : h2, hc = rev ? h2 : h1, hd = rev ? h3 : h0;
     const float ka = rev ? n0 : n3, kb = rev ? n1 : n2, kc = rev ? n2 : n1, kd = rev ? n3 : n0;
     const int la = rev ? l0 : l3, lb = rev ? l1 : l2, lc = rev ? l2 : l1, ld = rev ? l3 : l0;
@@ -319,19 +309,6 @@ NORI_HD void trav_wide_step(const DevScene &sc, Stack &stack, Trav &tv, Traversa
     NORI_WIDE_VISIT(hc, kc, lc)
     NORI_WIDE_VISIT(hd, kd, ld)
 #undef NORI_WIDE_VISIT
-#else
-    int first = kTravDone; float firstKey = 0.0f; bool have = false;
-    auto visit = [&](bool h, float key, int lk) {
-        if (!h) return;
-        if (!have) { first = lk; firstKey = key; have = true; }
-        else if (key <= firstKey) { stack.push(first); first = lk; firstKey = key; }
-        else stack.push(lk);
-    };
-    visit(rev ? h0 : h3, rev ? n0 : n3, rev ? l0 : l3);
-    visit(rev ? h1 : h2, rev ? n1 : n2, rev ? l1 : l2);
-    visit(rev ? h2 : h1, rev ? n2 : n1, rev ? l2 : l1);
-    visit(rev ? h3 : h0, rev ? n3 : n0, rev ? l3 : l0);
-#endif
     if (have) tv.node = first;
     else trav_pop(stack, tv);
 }

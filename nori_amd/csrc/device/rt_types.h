@@ -358,7 +358,6 @@ struct DevScene {
     uint32_t top_image_quads;   /* quads of top_image in use (its header's .w) */
     uint32_t top_image_q_quads;
     uint32_t bsdf_mask;         /* bit t: some mesh has a BSDF of nori_bsdf_type t (wf_shade is instantiated per material set) */
-    float bounds_lo[3], bounds_inv[3];   /* the vertices' box: lo and 1 / extent per axis (cells of the path-reordering keys, wf_sort.h) */
     NodeqGrid grid;             /* of nodes_q */
     CameraRec camera;
     FilterRec filter;

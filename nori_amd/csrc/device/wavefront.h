@@ -25,8 +25,8 @@ struct WfStats {
     unsigned long long n_camera = 0, n_closest = 0, n_shadow = 0, n_nodes = 0, n_tris = 0, n_invalid = 0;
     uint32_t n_batches = 0, n_iterations = 0, n_launches = 0;
     size_t state_bytes = 0;
-    float class_ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};      /* KernelClass: trace, shade, film, sort */
-    uint32_t class_launches[4] = {0, 0, 0, 0};
+    float class_ms[3] = {0.0f, 0.0f, 0.0f};      /* KernelClass: trace, shade, film */
+    uint32_t class_launches[3] = {0, 0, 0};
     uint32_t trace_cus = 0;                      /* CUs wf_extend's stream owned (fewer than the device has: shading ran beside it) */
 };
 

@@ -36,13 +36,29 @@
 #include <string>
 #include <vector>
 
+/* The laboratory -- perturbations of the node step and of wf_shade, the cycle profile of a wave -- lives in wf_experiments.h and is
+   compiled only into the variant libraries of tools/build_variant*.sh (-DNORI_LAB); the product build defines every hook empty. */
+#ifdef NORI_LAB
+#include "wf_experiments.h"
+#else
+#define NORI_EXP_Q_GLOBAL
+#define NORI_EXP_Q_LDS
+#define NORI_EXP_Q_ALU
+#define NORI_PROF_DECL
+#define NORI_PROF_MARK(acc)
+#define NORI_PROF_STORE
+#define NORI_PROF_REPORT(h, k)
+#define NORI_LAB_SHADE_PAD
+#define NORI_LAB_SHADE_VERTEX
+#define NORI_LAB_SHADE_STORE
+#endif
+
 #include "film.h"
 #include "ktimer.h"
 #include "shade_tables.h"
 #include "rt_path.h"
 #include "wavefront.h"
 #include "wf_records.h"
-#include "wf_sort.h"
 
 using namespace nrt;
 
@@ -81,7 +97,6 @@ struct WfBuf {
     uint32_t capacity; /* records per copy */
     int *stack_spill;  /* [entry beyond the LDS stack][lane of the wf_extend grid] */
     unsigned long long *census;   /* Z_* counters or null */
-    const uint32_t *perm;         /* wf_extend (later passes) takes slot perm[k] where it would take slot k (wf_sort.h), or null */
 };
 
 struct WfBatch {
@@ -196,34 +211,32 @@ __device__ __forceinline__ int lane_id() { return (int) (threadIdx.x & 63u); }
    level 1 = wf_extend's hit / sample-position stores and wf_shade's read of the hit record (wf_extend 47.9 -> 47.2),
    level 2 = wf_shade's state loads and stores (wf_shade 27.9 -> 27.1).  wf_extend's own state LOADS stay plain: nontemporal
    they cost it 2 ms (the 32 B a path re-reads after its shadow ray then miss). */
-#ifndef NORI_EXP_NT
-#define NORI_EXP_NT 2
-#endif
+constexpr int kNontemporalLevel = 2;
 typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef float v2f_t __attribute__((ext_vector_type(2)));
 template <int LEVEL> __device__ __forceinline__ void st_f4(f4 *p, const f4 &v) {
-    if (NORI_EXP_NT >= LEVEL) { v4f_t t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p)); }
+    if (kNontemporalLevel >= LEVEL) { v4f_t t = {v.x, v.y, v.z, v.w}; __builtin_nontemporal_store(t, reinterpret_cast<v4f_t *>(p)); }
     else *p = v;
 }
 template <int LEVEL> __device__ __forceinline__ void st_f2(f2 *p, const f2 &v) {
-    if (NORI_EXP_NT >= LEVEL) { v2f_t t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f_t *>(p)); }
+    if (kNontemporalLevel >= LEVEL) { v2f_t t = {v.x, v.y}; __builtin_nontemporal_store(t, reinterpret_cast<v2f_t *>(p)); }
     else *p = v;
 }
 template <int LEVEL> __device__ __forceinline__ f4 ld_f4(const f4 *p) {
-    if (NORI_EXP_NT >= LEVEL) { const v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p)); f4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r; }
+    if (kNontemporalLevel >= LEVEL) { const v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_t *>(p)); f4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w; return r; }
     return *p;
 }
 typedef float v3f_t __attribute__((ext_vector_type(3)));
 template <int LEVEL> __device__ __forceinline__ void st_p3(P3 *p, const P3 &v) {      /* 12 B, 4-B aligned: global_store_dwordx3 */
-    if (NORI_EXP_NT >= LEVEL) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); }
+    if (kNontemporalLevel >= LEVEL) { __builtin_nontemporal_store(v.x, &p->x); __builtin_nontemporal_store(v.y, &p->y); __builtin_nontemporal_store(v.z, &p->z); }
     else *p = v;
 }
 template <int LEVEL> __device__ __forceinline__ P3 ld_p3(const P3 *p) {
-    if (NORI_EXP_NT >= LEVEL) { P3 r; r.x = __builtin_nontemporal_load(&p->x); r.y = __builtin_nontemporal_load(&p->y); r.z = __builtin_nontemporal_load(&p->z); return r; }
+    if (kNontemporalLevel >= LEVEL) { P3 r; r.x = __builtin_nontemporal_load(&p->x); r.y = __builtin_nontemporal_load(&p->y); r.z = __builtin_nontemporal_load(&p->z); return r; }
     return *p;
 }
-template <int LEVEL, class T> __device__ __forceinline__ void st_w(T *p, T v) { if (NORI_EXP_NT >= LEVEL) __builtin_nontemporal_store(v, p); else *p = v; }
-template <int LEVEL, class T> __device__ __forceinline__ T ld_w(const T *p) { if (NORI_EXP_NT >= LEVEL) return __builtin_nontemporal_load(p); return *p; }
+template <int LEVEL, class T> __device__ __forceinline__ void st_w(T *p, T v) { if (kNontemporalLevel >= LEVEL) __builtin_nontemporal_store(v, p); else *p = v; }
+template <int LEVEL, class T> __device__ __forceinline__ T ld_w(const T *p) { if (kNontemporalLevel >= LEVEL) return __builtin_nontemporal_load(p); return *p; }
 
 /* The hot records of the tree (rt_top.h: the image is built once per acceleration structure) into the workgroup's LDS.
    Returns the link a walk starts with. */
@@ -277,32 +290,7 @@ __device__ __forceinline__ bool first_vertex(const DevScene &sc, const WfBatch &
  * Same operations in the same order as trav_inner_step_q -- the CPU harness walks that one, against the linear scan.
  * gfx950 hazards honoured by hand: a VALU-written vcc is read by v_cndmask two instructions later at the earliest.
  * Records are addressed as base + (node << 5) in 32 bits: the caller takes this path for trees below 2^25 nodes only. */
-#ifndef NORI_ASM_NODE_LOOP
-#define NORI_ASM_NODE_LOOP 1
-#endif
 #define NORI_SDWA(dst, src, half) "v_cvt_f32_u32_sdwa " dst ", " src " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_" half "\n\t"
-/* -DNORI_EXP_SENS=n (experiments, tools/build_variant.sh + tools/ab.sh): what the node step is sensitive to -- n = 1: one more
-   global_load_dwordx4, 2: the LDS reads over again, 3: sixteen v_mov, 4: sixteen s_mov, 5: 64 idle cycles (see above) */
-#define NORI_X16(s) s s s s s s s s s s s s s s s s
-#if NORI_EXP_SENS == 1
-#define NORI_EXP_Q_GLOBAL "\n\tglobal_load_dwordx4 v[36:39], v40, %[nodes] offset:16\n"
-#else
-#define NORI_EXP_Q_GLOBAL
-#endif
-#if NORI_EXP_SENS == 2
-#define NORI_EXP_Q_LDS "ds_read_b128 v[32:35], v40\n\tds_read_b128 v[36:39], v40 offset:16\n\t"
-#else
-#define NORI_EXP_Q_LDS
-#endif
-#if NORI_EXP_SENS == 3
-#define NORI_EXP_Q_ALU NORI_X16("v_mov_b32 v41, v40\n\t")
-#elif NORI_EXP_SENS == 4
-#define NORI_EXP_Q_ALU NORI_X16("s_mov_b64 %[u], %[t]\n\t")
-#elif NORI_EXP_SENS == 5
-#define NORI_EXP_Q_ALU "s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\t"
-#else
-#define NORI_EXP_Q_ALU
-#endif
 /* CHECK_FULL (trees deeper than the LDS stack, LdsStackHybrid): before a step, lanes whose LDS stack is full (top >= stack_limit)
    end the loop -- returns true, and the caller does that step in C++. */
 template <int STACK_STRIDE, bool CHECK_FULL>      /* STACK_STRIDE: bytes between a lane's stack slots */
@@ -453,16 +441,6 @@ __device__ __forceinline__ f4 hit_pack_here(const Hit *closest, bool shadow_occl
 /* BLOCK: threads per workgroup.  Every workgroup holds its own copy of the LDS image next to its stacks, so the bigger the
    workgroup the bigger the image can be: BVH2 trees run in workgroups of 1024 threads (two per CU: 2 x (68 KB of stacks +
    12 KB of image)), wide-node trees -- whose kernels need more than 64 registers, i.e. 5 or 6 waves per SIMD -- in workgroups of 256. */
-/* -DNORI_WF_PROFILE=1 (diagnostic builds, tools/build_variant.sh): where the waves of wf_extend spend their cycles -- refill
-   (results out, new rays in), node loop, triangle step -- summed over waves into stats slots 6, S_NODES, S_TRIS and 7 (total) */
-#ifndef NORI_WF_PROFILE
-#define NORI_WF_PROFILE 0
-#endif
-#if NORI_WF_PROFILE
-#define NORI_PROF_MARK(acc) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); acc += now_ - prof_t; prof_t = now_; }
-#else
-#define NORI_PROF_MARK(acc)
-#endif
 template <int STACK, bool SPILL, bool COUNT, bool FIRST, bool WIDE, bool ASM, int BLOCK>
 __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
@@ -503,10 +481,7 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
     uint32_t nClosest = 0, nShadow = 0, nCam = 0;      /* wave-uniform: counted from ballots at the refill */
     uint32_t zc[Z_COUNT] = {0, 0, 0, 0, 0, 0, 0, 0};      /* wave-uniform census */
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
-#if NORI_WF_PROFILE
-    unsigned long long prof_t = __builtin_amdgcn_s_memrealtime(), prof_refill = 0ull, prof_node = 0ull, prof_leaf = 0ull;
-    const unsigned long long prof_t0 = prof_t;
-#endif
+    NORI_PROF_DECL
     while (true) {
         /* a lane is idle when it has no ray in flight: either it needs a new path, or its path's
            shadow ray is answered and the continuation ray is still to be traced (rid bit 1) */
@@ -552,8 +527,7 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
                     }
                 }
             } else if (pend || (!trav_active(tv) && rank < avail)) {
-                uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
-                if (b.perm != nullptr && !pend) i = b.perm[i];      /* the pass in sorted order (wf_sort.h) */
+                const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
                 /* a fresh path: origin and both directions (the flags ride with the continuation direction) are requested
                    together -- one round trip to HBM instead of two (the direction a path needs first depends on its
                    flags).  A path whose shadow ray was just answered needs its continuation direction again (16 B; its
@@ -562,11 +536,9 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
                 P3 o0; o0.x = tv.o.x; o0.y = tv.o.y; o0.z = tv.o.z;      /* a path whose shadow ray was just answered: the origin is still here */
                 const f4 dA0 = S.dA[i];
                 if (!pend) { o0 = S.o[i]; dB0 = S.dB[i]; }
-#if !NORI_EXP_NO_PIN
                 /* (the compiler sinks loads below the test of the flags -- a second trip to HBM per refill; naming them as inputs
                    of an empty asm statement pins all of them in front of it) */
                 asm volatile("" :: "v"(o0.x), "v"(dA0.x), "v"(dB0.x));
-#endif
                 const uint32_t fl = pend ? F_HAS_A : state_flags(dA0);
                 if (fl & (F_HAS_A | F_HAS_B)) {      /* 0: empty slot */
                     const bool any = (fl & F_HAS_B) != 0u;
@@ -642,10 +614,7 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
         if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
         if (FIRST && nCam) atomicAdd(&b.stats[S_CAM], (unsigned long long) nCam);
         if (COUNT) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
-#if NORI_WF_PROFILE
-        atomicAdd(&b.stats[6], prof_refill); atomicAdd(&b.stats[S_NODES], prof_node); atomicAdd(&b.stats[S_TRIS], prof_leaf);
-        atomicAdd(&b.stats[7], __builtin_amdgcn_s_memrealtime() - prof_t0);
-#endif
+        NORI_PROF_STORE
         if (COUNT && b.census) for (int k = 0; k < Z_COUNT; ++k) if (zc[k]) atomicAdd(&b.census[k], (unsigned long long) zc[k]);
     }
 }
@@ -655,58 +624,28 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
    A workgroup owns a contiguous range of rounds (256 paths each) and reserves output space in
    chunks of <= kShadeChunk records with one atomic per chunk, sized by the survival rate it sees;
    what it leaves unused of its last chunk is marked empty (flags = 0) and dropped by the next pass. */
-/* threads per wf_shade workgroup (A/B: NORI_SHADE_BLOCK) */
-#ifndef NORI_SHADE_BLOCK
-#define NORI_SHADE_BLOCK 256
-#endif
-constexpr int kSB = NORI_SHADE_BLOCK;
-/* workgroups per CU the all-diffuse wf_shade is compiled for (4: as the general kernel) */
-#ifndef NORI_SHADE_WGS_DIFFUSE
-#define NORI_SHADE_WGS_DIFFUSE 4
-#endif
+constexpr int kSB = 256;      /* threads per wf_shade workgroup (128 / 64: slower, DESIGN_HISTORY.md) */
 
-/* -DNORI_EXP_SHADE=n (experiments, tools/build_variant_fast.sh + tools/ab.sh): what wf_shade is sensitive to, one resource at a time --
-   1: one more dense 16-B load per path, 2: one more 16-B store per survivor, 3: 64 more VALU instructions per path, 4: one more
-   dependent 16-B gather from the shading records, 5 / 6: LDS padding that leaves 3 / 2 workgroups per CU instead of 4 */
-#ifndef NORI_EXP_SHADE
-#define NORI_EXP_SHADE 0
-#endif
 /* wf_shade's workgroup barriers wait for LDS only: what the compaction exchanges lives there.  (__syncthreads() is also a fence,
    i.e. s_waitcnt vmcnt(0): a wave then sits out the trip of its own state STORES to L2 in every round.) */
-#ifndef NORI_SHADE_RAW_BARRIER
-#define NORI_SHADE_RAW_BARRIER 1    /* 0: __syncthreads() */
-#endif
-__device__ __forceinline__ void shade_barrier() {
-#if NORI_SHADE_RAW_BARRIER
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#else
-    __syncthreads();
-#endif
-}
+__device__ __forceinline__ void shade_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 /* LDSTAB: the scene's small tables fit LDS (shade_tables.h) -- else they are read from global memory (SceneTables) */
 template <bool LDSTAB> struct ShadeTab { typedef SceneTables type; static __device__ __forceinline__ type make(const DevScene &sc, uint4 *) { type t = {&sc}; return t; } };
 template <> struct ShadeTab<true> { typedef LdsTables type; static __device__ __forceinline__ type make(const DevScene &sc, uint4 *s_tab) { return shade_tables_copy(sc, s_tab); } };
 
-/* Software pipelining across rounds (NORI_EXP_SHADE_PREFETCH; 0: none): the head of the next round's record (continuation direction
-   with the flags, sample index, radiance, hit) is requested while this round computes, so that a round starts with its first
-   dependent loads already answered (round 3: wf_shade 27.1 -> 26.0 ms).  Going further does not pay -- measured in round 4
-   (profiles/r4_02_shade_pipeline_ab.txt): the WHOLE record of the next round sent straight into LDS (global_load_lds) with every
-   gather of the vertex issued at the top of the round, in one block of assembly so that the only wait of a round was "the gathers
-   are here" (s_waitcnt vmcnt(<requests>)): bit-identical, and 0.5 - 1 ms slower.  The kernel is bound by the volume it streams. */
-#ifndef NORI_EXP_SHADE_PREFETCH
-#define NORI_EXP_SHADE_PREFETCH 1
-#endif
+/* Software pipelining across rounds: the head of the next round's record (continuation direction with the flags, sample index,
+   radiance, hit) is requested while this round computes, so that a round starts with its first dependent loads already answered
+   (round 3: wf_shade 27.1 -> 26.0 ms; round 5, all-diffuse kernel: 23.7 -> 23.1).  Going further does not pay -- the WHOLE record
+   of the next round sent straight into LDS with every gather of the vertex issued at the top of the round: bit-identical and
+   0.5 - 1 ms slower (profiles/r4_02_shade_pipeline_ab.txt). */
 
 /* MATSET (rt_path.h): the BSDF types the scene contains -- the kernel of an all-diffuse scene carries no mirror, dielectric or
-   microfacet code; kShadeWgs: the workgroups per CU its register budget is held to */
-template <int MATSET> struct ShadeBudget { static constexpr int kWgs = MATSET == 1 ? NORI_SHADE_WGS_DIFFUSE : 4; };
+   microfacet code (the all-diffuse kernel: 117 registers instead of 128; held to the 96 of five workgroups per CU it spills and is
+   slower, profiles/r5_01_shade_matset_ab.txt) */
 template <int INTEG, bool FIRST, bool LDSTAB, int MATSET>
-__global__ __launch_bounds__(kSB, ShadeBudget<MATSET>::kWgs) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
-#if NORI_EXP_SHADE == 5 || NORI_EXP_SHADE == 6
-    __shared__ volatile char s_pad[NORI_EXP_SHADE == 5 ? 36 * 1024 : 50 * 1024];
-    s_pad[threadIdx.x * 64] = 0;
-#endif
+__global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
+    NORI_LAB_SHADE_PAD
     const WfState S = b.st[cur], D = b.st[cur ^ 1];
     const uint32_t s_first = bt.s_first, n_spp = bt.n_spp;
     __shared__ uint4 s_tab[LDSTAB ? kShadeTabWords / 4 : 1];
@@ -720,7 +659,7 @@ __global__ __launch_bounds__(kSB, ShadeBudget<MATSET>::kWgs) void wf_shade(DevSc
     bool overflow = false;
     const int wave = (int) (threadIdx.x >> 6), lane = lane_id();
     const uint32_t per_tile = 256u * n_spp;
-    constexpr bool kPf = !FIRST && NORI_EXP_SHADE_PREFETCH != 0;
+    constexpr bool kPf = !FIRST;
     uint32_t pf_sidx = 0u; f4 pf_d, pf_L, pf_h;
     pf_d.x = pf_d.y = pf_d.z = pf_d.w = 0.0f; pf_L = pf_h = pf_d;
     if (kPf && r0 < r1 && r0 * kSB + threadIdx.x < n) {
@@ -759,13 +698,7 @@ __global__ __launch_bounds__(kSB, ShadeBudget<MATSET>::kWgs) void wf_shade(DevSc
                 const f4 h = (FIRST || !kPf) ? ld_f4<1>(&b.hit[i]) : c_h;
                 const uint32_t hw = __float_as_uint(h.w);
                 bool done = false;
-#if NORI_EXP_SHADE == 1
-                if (!FIRST) { const f4 x = ld_f4<2>(&S.dB[i]); asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
-#elif NORI_EXP_SHADE == 3
-                { float x = h.x; asm volatile(NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") : "+v"(x)); }
-#elif NORI_EXP_SHADE == 4
-                if ((hw & kMissA) != kMissA) { const f4 x = sc.shade_tris[(size_t) (hw & kMissA) * kShadeQuads + 5]; asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
-#endif
+                NORI_LAB_SHADE_VERTEX
                 if (fl & F_HAS_B) {                       /* path_on_shadow: add the emitter sample if unoccluded */
                     if (!(hw & kOccludedB)) {
                         const P3 ld = ld_p3<2>(&S.Ld[i]);
@@ -821,9 +754,7 @@ __global__ __launch_bounds__(kSB, ShadeBudget<MATSET>::kWgs) void wf_shade(DevSc
             st_p3<2>(&D.o[j], p3_of(n_o)); st_f4<2>(&D.T_eta[j], n_T); st_f4<2>(&D.L_pdf[j], n_L);
             st_f4<2>(&D.dA[j], state_dA(n_dA, n_fl, (n_fl & F_HAS_A) != 0u)); st_w<2>(&D.rng[j], n_rng); st_w<2>(&D.sidx[j], sidx);
             if (n_fl & F_HAS_B) { st_f4<2>(&D.dB[j], n_dB); st_p3<2>(&D.Ld[j], p3_of(n_Ld)); }
-#if NORI_EXP_SHADE == 2
-            st_f4<2>(&S.dB[j], n_o);      /* (nobody reads S.dB in this kernel) */
-#endif
+            NORI_LAB_SHADE_STORE
         }
         if (c > room) { out_base = new_base; out_used = c - room; out_len = want; }
         else out_used += c;
@@ -966,11 +897,8 @@ std::string ensure_pool(Pool &pool, size_t records) {
 }
 
 /* threads per wf_extend workgroup and workgroups per CU the LDS image is sized for, per node layout (see wf_extend) */
-#ifndef NORI_EXTEND_BLOCK
-#define NORI_EXTEND_BLOCK 1024
-#endif
-constexpr int kExtendBlockBvh2 = NORI_EXTEND_BLOCK, kExtendBlockWide = kB;
-constexpr int kExtendWgsBvh2 = 2048 / NORI_EXTEND_BLOCK, kExtendWgsWide = 7, kExtendWgsWideFirst = 5;
+constexpr int kExtendBlockBvh2 = 1024, kExtendBlockWide = kB;
+constexpr int kExtendWgsBvh2 = 2048 / kExtendBlockBvh2, kExtendWgsWide = 7, kExtendWgsWideFirst = 5;
 constexpr size_t kLdsPerCu = 160 * 1024;
 template <int STACK, bool SPILL, bool COUNT, bool FIRST>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, const WfBatch &bt, hipStream_t s) {
@@ -983,7 +911,7 @@ void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int 
         /* the hand-written node loop (bvh2q_node_loop_asm) walks the tree's 32-B records (rt_nodeq.h: trees without unbounded boxes),
            addresses them by 32-bit byte offsets (trees below 2^25 nodes -- a BVH2 tree has fewer nodes than triangles) and keeps its
            stack in LDS; everything else takes the compiler's loop over the 64-B nodes */
-        constexpr bool kAsm = NORI_ASM_NODE_LOOP && !COUNT;
+        constexpr bool kAsm = !COUNT;
         const bool use_asm = kAsm && sc.nodes_q != nullptr && sc.n_triangles < (1u << 25) && (bt.flags & kBatchNoAsmLoop) == 0u;
         const bool image_q = use_asm || (COUNT && (bt.flags & kBatchCountQ) != 0u);
         const size_t lds = (use_asm ? (size_t) ExtendStack<STACK, SPILL, kAsm, kExtendBlockBvh2>::type::kLdsEntries : (size_t) LdsStackW<STACK, SPILL, kExtendBlockBvh2>::kLdsEntries) *
@@ -1069,7 +997,6 @@ struct WfEngine {
     hipStream_t split_streams[2] = {nullptr, nullptr};
     int split_cus = 0;
     hipEvent_t pipe_events[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      /* per pipe: its traversal / its shading is done */
-    WfSortBuffers sort;             /* NORI_HIP_WF_SORT: the passes reordered before wf_extend (wf_sort.h) */
 };
 
 /* Two streams whose kernels run on disjoint sets of CUs (hipExtStreamCreateWithCUMask).  The shading side gets `cus` CUs (a
@@ -1111,7 +1038,6 @@ WfEngine *wavefront_create() {
 void wavefront_destroy(WfEngine *e) {
     if (!e) return;
     e->pool.release();
-    e->sort.release();
     for (hipStream_t &st : e->streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
     for (hipStream_t &st : e->split_streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
     for (hipEvent_t &ev : e->events) if (ev) { (void) hipEventDestroy(ev); ev = nullptr; }
@@ -1275,7 +1201,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     /* LDS per workgroup: stack entries (+1: the "done" marker of the non-spilling stack) + the top-node cache */
     const int extend_block = sc.wide ? kExtendBlockWide : kExtendBlockBvh2;
     /* which node loop wf_extend will run (launch_extend): the hand-written one on 32-B records, or the compiler's on 64-B nodes */
-    const bool walk_q = NORI_ASM_NODE_LOOP && !sc.wide && sc.nodes_q != nullptr && sc.n_triangles < (1u << 25) && !no_asm_loop;      /* 32-B node records */
+    const bool walk_q = !sc.wide && sc.nodes_q != nullptr && sc.n_triangles < (1u << 25) && !no_asm_loop;      /* 32-B node records */
     const bool node_loop_q = walk_q && !L.count_traversal;         /* ... by the hand-written loop */
     const bool count_q = walk_q && L.count_traversal;              /* ... by its C++ statement, counting (the same tree form as the timed kernel's) */
     bool spill = false;
@@ -1332,13 +1258,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
         WF_TRY(hipMalloc((void **) &d_census, Z_COUNT * sizeof(unsigned long long)));
         WF_TRY(hipMemsetAsync(d_census, 0, Z_COUNT * sizeof(unsigned long long), s));
     }
-    for (int k = 0; k < n_pipes; ++k) { pipes[k].b.census = d_census; pipes[k].b.perm = nullptr; }
-    /* NORI_HIP_WF_SORT=kind[,cell bits][,from pass][,to pass]: the paths of the later passes sorted before wf_extend (wf_sort.h).
-       Needs the path count on the host before every pass: one readback per iteration. */
-    WfSortParams sortp; int sort_from = 1, sort_to = 1 << 30;
-    if (const char *e = getenv("NORI_HIP_WF_SORT")) { int a = 0, bb = 5, c = 1, d = 1 << 30; const int got = sscanf(e, "%d,%d,%d,%d", &a, &bb, &c, &d); sortp.kind = got >= 1 ? a : 0; sortp.cell_bits = bb; sort_from = c; sort_to = d; }
-    if (n_pipes != 1 || L.count_traversal) sortp.kind = 0;
-    if (sortp.kind) sync_every = 1;
+    for (int k = 0; k < n_pipes; ++k) pipes[k].b.census = d_census;
     FilmLaunch fl;
     fl.tile_mod = L.tile_mod; fl.tile_rem = L.tile_rem; fl.tiles_x = L.tiles_x; fl.tiles_y = L.tiles_y; fl.tile_w = L.tile_w;
 
@@ -1369,14 +1289,6 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
                 if (split) WF_TRY(hipStreamWaitEvent(P.extend_stream, P.ev_shade, 0));
-                P.b.perm = nullptr;
-                if (sortp.kind && !P.first && (int) P.batch_rounds >= sort_from && (int) P.batch_rounds <= sort_to && P.h_ctr[C_N + P.cur] > (uint32_t) finish_paths) {
-                    timer.begin(KC_SORT, P.stream);
-                    err = wf_sort_pass(eng.sort, sc, P.b.st[P.cur].o, P.b.st[P.cur].dA, P.h_ctr[C_N + P.cur], sortp, P.stream);
-                    timer.end(P.stream);
-                    if (!err.empty()) return err;
-                    P.b.perm = eng.sort.vals[1];
-                }
                 timer.begin(KC_TRACE, P.extend_stream);
                 launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, P.first ? extend_grid_first : extend_grid, P.bt, P.extend_stream);
                 WF_TRY(hipGetLastError());      /* a launch that did not fit (LDS, registers) must not pass for an empty pass */
@@ -1441,17 +1353,10 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     for (int k = 0; k < 2; ++k) {
         stats.n_camera += h[k * S_COUNT + S_CAM]; stats.n_closest += h[k * S_COUNT + S_CLOSEST]; stats.n_shadow += h[k * S_COUNT + S_SHADOW];
         stats.n_nodes += h[k * S_COUNT + S_NODES]; stats.n_tris += h[k * S_COUNT + S_TRIS];
-#if NORI_WF_PROFILE
-        { const double tot = (double) h[k * S_COUNT + 7];
-          if (tot > 0.0) fprintf(stderr, "[wf_extend profile] wave cycles: refill %.3f, node loop %.3f, triangle step %.3f of %.4g total\n", h[k * S_COUNT + 6] / tot,
-                  h[k * S_COUNT + S_NODES] / tot, h[k * S_COUNT + S_TRIS] / tot, tot);
-          else fprintf(stderr, "[wf_extend profile] raw %llu %llu %llu %llu %llu %llu %llu %llu\n", h[k * S_COUNT], h[k * S_COUNT + 1], h[k * S_COUNT + 2], h[k * S_COUNT + 3],
-                       h[k * S_COUNT + 4], h[k * S_COUNT + 5], h[k * S_COUNT + 6], h[k * S_COUNT + 7]); }
-#endif
+        NORI_PROF_REPORT(h, k)
     }
     stats.n_invalid = film_invalid_count(film, s);
     timer.collect(stats.class_ms, stats.class_launches);
-    if (sortp.kind && L.time_kernels) fprintf(stderr, "[wavefront sort] kind %d, %d cell bits: %.2f ms in %u calls\n", sortp.kind, sortp.cell_bits, stats.class_ms[KC_SORT], stats.class_launches[KC_SORT]);
     if (d_census) {
         unsigned long long z[Z_COUNT];
         WF_TRY(hipMemcpy(z, d_census, sizeof(z), hipMemcpyDeviceToHost));

@@ -6,7 +6,7 @@ ROOT=$(cd $(dirname $0)/.. && pwd)
 DEV=$ROOT/nori_amd/csrc/device
 TMP=$(mktemp -d)
 FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-sink -fPIC -Wno-comment -Wno-unused-result"
-for f in nori_hip.hip lbvh.hip wavefront.hip wf_sort.hip film.hip group.hip scene_prep.cpp; do
+for f in nori_hip.hip lbvh.hip wavefront.hip film.hip group.hip scene_prep.cpp; do
   /opt/rocm/bin/hipcc $FLAGS "$@" -c $DEV/$f -o $TMP/$f.o &
 done
 wait

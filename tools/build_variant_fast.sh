@@ -7,9 +7,9 @@ ROOT=$(cd $(dirname $0)/.. && pwd)
 DEV=$ROOT/nori_amd/csrc/device
 OBJ=$ROOT/build/obj
 mkdir -p $OBJ
-FLAGS="-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-sink -fPIC -Wno-comment -Wno-unused-result"
+FLAGS="-DNORI_LAB -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -fno-slp-vectorize -mllvm -disable-machine-sink -fPIC -Wno-comment -Wno-unused-result"
 UNITS=${UNITS:-wavefront.hip}
-ALL="nori_hip.hip lbvh.hip wavefront.hip wf_sort.hip film.hip group.hip scene_prep.cpp"
+ALL="nori_hip.hip lbvh.hip wavefront.hip film.hip group.hip scene_prep.cpp"
 NEWEST=$(ls -t $DEV/*.h $ROOT/include/nori_hip.h | head -1)
 for f in $ALL; do
   if [ ! -f $OBJ/$f.o ] || [ $DEV/$f -nt $OBJ/$f.o ] || [ $NEWEST -nt $OBJ/$f.o ]; then

@@ -1,8 +1,7 @@
-"""Reordering the paths between bounces (wf_sort.h), the ceiling measured on one box in one process:
-    WORKLOAD=... SPP=... CONFIGS="off 1,3 1,5 1,7 2,5 3,4" python tools/sort_probe.py
-Every configuration renders REPS frames with one path-count readback per pass (what the sort needs; `off` gets the same, and
-`default` the shipped cadence) and prints the HIP-event sums per kernel class -- wf_extend with the sort's cost excluded, the
-sort itself -- and whether the frame has the bits of the unsorted one."""
+"""Reordering the paths between bounces through a radix-sorted index, measured on one box in one process -- the experiment of round 5
+(profiles/r5_02_sort_ceiling.txt).  The knob it drives (NORI_HIP_WF_SORT, wf_sort.hip) exists in commit f64423d only: the result was negative
+(wf_extend slower with the sort cost excluded) and the code was removed again.  Kept as the record of what was run:
+    WORKLOAD=... SPP=... CONFIGS="off 1,3 1,5 1,7 2,5 3,4" python tools/sort_probe.py"""
 import os, sys, re, subprocess
 sys.path.insert(0, ".")
 import numpy as np, torch
