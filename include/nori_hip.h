@@ -252,6 +252,9 @@ typedef struct nori_render_stats {
     uint32_t trace_cus;      /* CUs the ray-query kernels ran on: all of the device's, or -- wavefront engine, big jobs -- all but
                                 the CUs set aside for the shading and film kernels, which then run BESIDE the ray queries of
                                 the other half of the tiles (trace_ms, shade_ms and film_ms overlap in that case) */
+    float tail_ms;           /* time_kernels != 0: summed durations of the wf_finish launches that ran BESIDE the next batch's kernels, on
+                                their own `tail_cus` CUs (wavefront engine, calls of two or more batches); not part of shade_ms */
+    uint32_t tail_cus;
 } nori_render_stats;
 
 typedef struct nori_accel_info {

@@ -81,7 +81,7 @@ class RenderStats(C.Structure):
                 ("n_tri_tests", C.c_uint64), ("n_invalid", C.c_uint64),
                 ("kernel_ms", C.c_float), ("n_workgroups", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("trace_ms", C.c_float), ("shade_ms", C.c_float), ("film_ms", C.c_float), ("n_trace_launches", C.c_uint32), ("engine", C.c_uint32),
-                ("trace_cus", C.c_uint32)]
+                ("trace_cus", C.c_uint32), ("tail_ms", C.c_float), ("tail_cus", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -10,7 +10,7 @@
 
 namespace nrt {
 
-enum KernelClass { KC_TRACE = 0, KC_SHADE = 1, KC_FILM = 2, KC_COUNT = 3 };
+enum KernelClass { KC_TRACE = 0, KC_SHADE = 1, KC_FILM = 2, KC_TAIL = 3, KC_COUNT = 4 };      /* KC_TAIL: wf_finish launches that ran BESIDE the next batch (wavefront.hip, tail overlap) */
 
 class KernelTimer {
 public:

@@ -1188,6 +1188,7 @@ static int render_impl(nori_hip_ctx *ctx, const nori_render_params *params, void
             stats->n_node_tests = wst.n_nodes; stats->n_tri_tests = wst.n_tris; stats->n_invalid = wst.n_invalid;
             stats->n_workgroups = wst.n_launches;
             stats->trace_cus = wst.trace_cus;
+            stats->tail_ms = wst.class_ms[KC_TAIL]; stats->tail_cus = wst.tail_cus;
             if (getenv("NORI_HIP_CENSUS")) fprintf(stderr, "[wavefront] batches %u iterations %u launches %u state %.1f MB\n", wst.n_batches, wst.n_iterations, wst.n_launches, wst.state_bytes / 1048576.0);
         }
         const uint32_t need = ctx->bvh.max_depth + 1;

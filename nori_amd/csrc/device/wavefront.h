@@ -25,9 +25,10 @@ struct WfStats {
     unsigned long long n_camera = 0, n_closest = 0, n_shadow = 0, n_nodes = 0, n_tris = 0, n_invalid = 0;
     uint32_t n_batches = 0, n_iterations = 0, n_launches = 0;
     size_t state_bytes = 0;
-    float class_ms[3] = {0.0f, 0.0f, 0.0f};      /* KernelClass: trace, shade, film */
-    uint32_t class_launches[3] = {0, 0, 0};
-    uint32_t trace_cus = 0;                      /* CUs wf_extend's stream owned (fewer than the device has: shading ran beside it) */
+    float class_ms[4] = {0.0f, 0.0f, 0.0f, 0.0f};      /* KernelClass: trace, shade, film, overlapped tails */
+    uint32_t class_launches[4] = {0, 0, 0, 0};
+    uint32_t trace_cus = 0;                      /* CUs wf_extend's stream owned (fewer than the device has: shading, or the tails of earlier batches, ran beside it) */
+    uint32_t tail_cus = 0;                       /* CUs set aside for the tails of the batches (0: tails run on the bulk's stream) */
 };
 
 /* The engine's per-context resources (path-state pool, pipe streams / events, device properties);

@@ -67,7 +67,7 @@ namespace {
 constexpr int kB = 256;
 
 /* counters: path count and dynamic-chunk head per state copy (index + copy), overflow flag */
-enum { C_N = 0, C_HEAD = 2, C_OVERFLOW = 4, C_COUNT = 8 };
+enum { C_N = 0, C_HEAD = 2, C_OVERFLOW = 4, C_TAIL_HEAD = 5, C_COUNT = 8 };
 enum { S_CAM = 0, S_CLOSEST = 1, S_SHADOW = 2, S_NODES = 3, S_TRIS = 4, S_INVALID = 5, S_COUNT = 8 };
 /* census (COUNT builds, NORI_HIP_CENSUS): wave-level trips of wf_extend's loop and the lanes they used */
 enum { Z_TRIPS = 0, Z_INNER_TRIPS = 1, Z_INNER_LANES = 2, Z_LEAF_TRIPS = 3, Z_LEAF_LANES = 4, Z_REFILLS = 5, Z_REFILL_LANES = 6, Z_COUNT = 8 };
@@ -768,12 +768,18 @@ __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur
    is a launch that lasts as long as ONE path vertex takes (~0.1 ms) however few paths there are.
    wf_finish ends it with one launch: each lane takes a path and walks it to its end -- shadow ray,
    continuation ray, Li vertex, repeat -- the megakernel's loop started from stored path state.
-   (Its lanes run nearly empty -- 6.5 of 64 per instruction -- and that is not what it costs: the launch lasts as long as the
-   LONGEST path, ~1300 vertices through glass at p = 0.99, one after the other.  A kernel that re-compacts a workgroup's paths
-   after every vertex keeps the lanes dense and is no faster: profiles/r4_04_tail_per_vertex_ab.txt.  Nor does walking through
+   (On a device of its own the launch lasts as long as the LONGEST path, ~1300 vertices through glass at p = 0.99, one after the
+   other, however its lanes are used: a kernel that re-compacts a workgroup's paths after every vertex keeps the lanes dense and
+   is no faster, profiles/r4_04_tail_per_vertex_ab.txt.  Nor does walking through
    the LDS image of the hot records help here -- pa5 table, 64 spp: 44.9 against 42.0 ms of shade time, a 1/8 share of the Cornell
    box 3.99 against 3.56: 2048 workgroups each copy 12 KB for a few hundred paths, and the C++ form of the 32-B node step pays 24
    instructions per step for the ray's plane coefficients.) */
+/* The lanes of a small persistent grid pull paths one by one -- a lane whose path has ended takes the next unclaimed one at the top
+   of the vertex loop (one atomic per wave and refill), so a wave's lanes stay busy while paths are left and all of them are at the
+   same stage of a vertex.  (Round 4's form -- one lane per path, a grid of finish_paths lanes -- ran at 6.5 of 64 lanes: pa5 table
+   scene 22 -> 19 ms per tail on all CUs, 223 -> 80 ms on 16 CUs, where the tail of a batch runs when the NEXT batch runs beside it:
+   what it costs there is CU time, not the length of the longest path.  profiles/r5_06_tail_probe_c4.txt.)  Same arithmetic per
+   path, hence the same radiance; which lane walks a path is not observable. */
 template <int INTEG>
 __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, WfBatch bt, int count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -786,37 +792,56 @@ __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, W
     const uint32_t per_tile = 256u * bt.n_spp;
     uint32_t nClosest = 0, nShadow = 0;
     TraversalCounters tc; tc.nodes = 0; tc.tris = 0;
-    for (uint32_t i = blockIdx.x * kB + threadIdx.x; i < n; i += gridDim.x * kB) {
-        f4 dA = S.dA[i];
-        uint32_t fl = state_flags(dA);
-        if (!(fl & (F_HAS_A | F_HAS_B))) continue;
-        const uint32_t sidx = S.sidx[i];
-        f4 o, dB = S.dB[i], T = S.T_eta[i], L = S.L_pdf[i], Ld;
-        { const P3 o3 = S.o[i], l3 = S.Ld[i]; o.x = o3.x; o.y = o3.y; o.z = o3.z; o.w = kStoredMint; Ld.x = l3.x; Ld.y = l3.y; Ld.z = l3.z; Ld.w = 0.0f; }
-        dA.w = kInf;      /* (the stored w was the flags: a stored continuation ray reaches to infinity, wf_records.h) */
-        unsigned long long rng_state = S.rng[i];
-        const uint64_t inc = ((uint64_t) (bt.s_first + ((sidx % per_tile) >> 8)) << 1u) | 1u;
-        while (true) {
+    bool have = false, dry = false;      /* this lane walks a path / the paths have run out */
+    uint32_t sidx = 0u, fl = 0u;
+    f4 o, dA, dB, T, L, Ld;
+    o.x = o.y = o.z = o.w = 0.0f; dA = dB = T = L = Ld = o;
+    unsigned long long rng_state = 0ull;
+    while (true) {
+        const unsigned long long want = __ballot(!have && !dry);
+        if (want != 0ull) {
+            uint32_t base = 0u;
+            if (lane_id() == 0) base = atomicAdd(&b.ctr[C_TAIL_HEAD], (uint32_t) __popcll(want));
+            base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+            const uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t) (want >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) want, 0u));
+            if (!have && !dry) {
+                if (i >= n) dry = true;
+                else {
+                    dA = S.dA[i];
+                    fl = state_flags(dA);
+                    if (fl & (F_HAS_A | F_HAS_B)) {      /* (else: an empty slot -- the lane asks again in the next trip) */
+                        have = true;
+                        sidx = S.sidx[i]; dB = S.dB[i]; T = S.T_eta[i]; L = S.L_pdf[i];
+                        const P3 o3 = S.o[i], l3 = S.Ld[i];
+                        o.x = o3.x; o.y = o3.y; o.z = o3.z; o.w = kStoredMint; Ld.x = l3.x; Ld.y = l3.y; Ld.z = l3.z; Ld.w = 0.0f;
+                        dA.w = kInf;
+                        rng_state = S.rng[i];
+                    }
+                }
+            }
+        }
+        if (__ballot(have) == 0ull) { if (__ballot(!dry) == 0ull) break; continue; }
+        if (have) {      /* one vertex */
+            bool fin = false;
             if (fl & F_HAS_B) {
                 RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(dB.x, dB.y, dB.z); ray.mint = kEpsilon; ray.maxt = dB.w;
                 Hit sh; ++nShadow;
                 if (!traverse<true>(sc, ray, true, stack, sh, tc)) { L.x = L.x + Ld.x; L.y = L.y + Ld.y; L.z = L.z + Ld.z; }
-                if (fl & F_END_AFTER_B) break;
+                fin = (fl & F_END_AFTER_B) != 0u;
             }
-            RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(dA.x, dA.y, dA.z); ray.mint = o.w; ray.maxt = dA.w;
-            Hit hit; ++nClosest;
-            const bool found = traverse<true>(sc, ray, false, stack, hit, tc);
-            if (found) hit.mesh = f2u(sc.shade_tris[(size_t) hit.tri * kShadeQuads].w);
-            PathState st;
-            vertex_unpack(st, fl, L, T, rng_state, inc);
-            const bool done = path_on_closest<INTEG>(sc, st, hit, found, ray.d);
-            L.x = st.L.x; L.y = st.L.y; L.z = st.L.z;
-            if (done) break;
-            vertex_pack(st, o, dA, dB, T, L, Ld, fl);
-            rng_state = st.rng.state;
+            if (!fin) {
+                RayIn ray; ray.o = mk3(o.x, o.y, o.z); ray.d = mk3(dA.x, dA.y, dA.z); ray.mint = o.w; ray.maxt = dA.w;
+                Hit hit; ++nClosest;
+                const bool found = traverse<true>(sc, ray, false, stack, hit, tc);
+                if (found) hit.mesh = f2u(sc.shade_tris[(size_t) hit.tri * kShadeQuads].w);
+                PathState st;
+                vertex_unpack(st, fl, L, T, rng_state, ((uint64_t) (bt.s_first + ((sidx % per_tile) >> 8)) << 1u) | 1u);
+                fin = path_on_closest<INTEG>(sc, st, hit, found, ray.d);
+                L.x = st.L.x; L.y = st.L.y; L.z = st.L.z;
+                if (!fin) { vertex_pack(st, o, dA, dB, T, L, Ld, fl); rng_state = st.rng.state; }
+            }
+            if (fin) { P3 out; out.x = L.x; out.y = L.y; out.z = L.z; b.samp_L[sidx] = out; have = false; }
         }
-        P3 out; out.x = L.x; out.y = L.y; out.z = L.z;
-        b.samp_L[sidx] = out;
     }
     for (int off = 32; off > 0; off >>= 1) {
         nClosest += (uint32_t) __shfl_down((int) nClosest, off);
@@ -828,6 +853,18 @@ __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, W
         if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
         if (count) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
     }
+}
+
+/* Tail overlap (wavefront_render): the records of a batch's last live paths move out of the state pool -- which the next batch
+   is about to overwrite -- into the engine's side copy, where wf_finish walks them on its own CUs. */
+__global__ __launch_bounds__(kB) void wf_tail_copy(WfBuf b, int cur, WfState D, uint32_t *d_ctr) {
+    const WfState S = b.st[cur];
+    const uint32_t n = b.ctr[C_N + cur];
+    for (uint32_t i = blockIdx.x * kB + threadIdx.x; i < n; i += gridDim.x * kB) {
+        D.o[i] = S.o[i]; D.dA[i] = S.dA[i]; D.dB[i] = S.dB[i]; D.T_eta[i] = S.T_eta[i]; D.L_pdf[i] = S.L_pdf[i]; D.Ld[i] = S.Ld[i];
+        D.sidx[i] = S.sidx[i]; D.rng[i] = S.rng[i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { d_ctr[C_N] = n; d_ctr[C_TAIL_HEAD] = 0u; }
 }
 
 /* ----------------------------------------------------------- host driver */
@@ -997,7 +1034,54 @@ struct WfEngine {
     hipStream_t split_streams[2] = {nullptr, nullptr};
     int split_cus = 0;
     hipEvent_t pipe_events[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};      /* per pipe: its traversal / its shading is done */
+    /* tail overlap: the side copy of a batch's last live paths (wf_tail_copy), walked by wf_finish on split_streams[1] */
+    struct TailSide {
+        WfState st; uint32_t *ctr = nullptr; size_t capacity = 0; std::vector<void *> allocs;
+        int *spill = nullptr; size_t spill_ints = 0;
+        void release() { for (void *q : allocs) (void) hipFree(q); allocs.clear(); capacity = 0; ctr = nullptr; if (spill) { (void) hipFree(spill); spill = nullptr; spill_ints = 0; } }
+    } tail;
+    hipEvent_t tail_events[3] = {nullptr, nullptr, nullptr};      /* the side copy is filled / the tail is done / the tail is about to be dispatched */
+    hipStream_t tail_stream = nullptr;
+    int tail_stream_cus = 0;
 };
+
+/* The stream of the overlapped tails: it owns the CUs of the first `cus` mask bits.  The driver hands bit i of a queue's mask to
+   XCD i mod 8 and walks an XCD's shader engines with the bits it gets, so 32 bits are one CU of every shader engine of every XCD:
+   what is left for the other streams' kernels is even over XCDs (a kernel's workgroups go round the XCDs, b mod 8, whatever their
+   CUs hold) and over the shader engines of an XCD (taking CUs from one shader engine only costs the bulk kernels twice the CUs'
+   share -- pa5 table scene, bulk on the complement of 8 / 16 / 32 CUs of the FIRST shader engines: wf_extend +6 / +14 / +37 %,
+   profiles/r5_07_tail_overlap_masks.txt). */
+bool ensure_tail_stream(WfEngine &e, int cus) {
+    if (e.tail_stream && e.tail_stream_cus == cus) return true;
+    if (e.tail_stream) { (void) hipStreamDestroy(e.tail_stream); e.tail_stream = nullptr; e.tail_stream_cus = 0; }
+    if (cus < 8 || cus >= e.n_cus) return false;
+    const uint32_t words = (uint32_t) ((e.n_cus + 31) / 32);
+    std::vector<uint32_t> mask(words, 0u);
+    for (int i = 0; i < cus; ++i) mask[(size_t) i / 32] |= 1u << (i % 32);
+    if (hipExtStreamCreateWithCUMask(&e.tail_stream, words, mask.data()) != hipSuccess) { (void) hipGetLastError(); e.tail_stream = nullptr; return false; }
+    e.tail_stream_cus = cus;
+    return true;
+}
+
+std::string ensure_tail_side(WfEngine &e, size_t records, size_t spill_ints) {
+    WfEngine::TailSide &t = e.tail;
+    if (t.capacity < records) {
+        t.release();
+#define A(field, T) { void *q = nullptr; WF_TRY(hipMalloc(&q, records * sizeof(T))); t.allocs.push_back(q); t.st.field = reinterpret_cast<T *>(q); }
+        A(o, P3) A(dA, f4) A(dB, f4) A(T_eta, f4) A(L_pdf, f4) A(Ld, P3) A(sidx, uint32_t) A(rng, unsigned long long)
+#undef A
+        { void *q = nullptr; WF_TRY(hipMalloc(&q, C_COUNT * sizeof(uint32_t))); t.allocs.push_back(q); t.ctr = reinterpret_cast<uint32_t *>(q); }
+        t.capacity = records;
+    }
+    if (t.spill_ints < spill_ints) {
+        if (t.spill) (void) hipFree(t.spill);
+        t.spill = nullptr; t.spill_ints = 0;
+        WF_TRY(hipMalloc((void **) &t.spill, spill_ints * sizeof(int)));
+        t.spill_ints = spill_ints;
+    }
+    for (hipEvent_t &ev : e.tail_events) if (!ev) WF_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return std::string();
+}
 
 /* Two streams whose kernels run on disjoint sets of CUs (hipExtStreamCreateWithCUMask).  The shading side gets `cus` CUs (a
    multiple of 8) as whole ROWS of eight consecutive mask bits, rows spread evenly over the mask: the driver hands bit i of a
@@ -1042,6 +1126,9 @@ void wavefront_destroy(WfEngine *e) {
     for (hipStream_t &st : e->split_streams) if (st) { (void) hipStreamDestroy(st); st = nullptr; }
     for (hipEvent_t &ev : e->events) if (ev) { (void) hipEventDestroy(ev); ev = nullptr; }
     for (auto &pe : e->pipe_events) for (hipEvent_t &ev : pe) if (ev) { (void) hipEventDestroy(ev); ev = nullptr; }
+    for (hipEvent_t &ev : e->tail_events) if (ev) { (void) hipEventDestroy(ev); ev = nullptr; }
+    if (e->tail_stream) { (void) hipStreamDestroy(e->tail_stream); e->tail_stream = nullptr; }
+    e->tail.release();
     delete e;
 }
 
@@ -1058,7 +1145,7 @@ bool wavefront_excursions(unsigned long long out[4], bool reset) {
 #endif
 }
 
-size_t wavefront_bytes_per_path() { return kStateBytesPerRecord + sizeof(f2) + sizeof(P3); }
+size_t wavefront_bytes_per_path() { return kStateBytesPerRecord + 2 * (sizeof(f2) + sizeof(P3)); }      /* (two halves of the sample store: tail overlap) */
 
 size_t wavefront_held_bytes(const WfEngine *e, const FilmStore &film) {
     return (e ? e->pool.bytes : 0) + film.capacity * (sizeof(f2) + sizeof(P3));
@@ -1139,6 +1226,26 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
         need[k] = (size_t) P.tiles_b * 256 * P.spp_b;
         P.t0 = P.tile_lo; P.s0 = 0;
     }
+    /* Tail overlap.  A batch ends with wf_finish walking its last <= finish_paths live paths to their ends: a launch as long as the
+       batch's longest path (inside glass ~1300 vertices, one after the other) during which the device is next to idle -- 12 % of
+       the pa5 table scene at 2048^2 x 1024 spp.  In a call of two or more batches the tail of batch k runs BESIDE the kernels of
+       batch k + 1 instead: its records are copied out of the state pool (wf_tail_copy) and the persistent form of wf_finish walks
+       them on a stream that owns `tail_cus` CUs (ensure_tail_stream) while the bulk of the next batch goes on on the caller's
+       stream -- on the CUs the tail leaves it while it lasts (46 ms on 32 CUs), on all of them afterwards; the film gather of
+       batch k -- which needs the tail's radiance -- is queued behind the bulk of batch k + 1.  The sample store has two halves,
+       one per batch in flight.  Gathers stay in batch order, so the frame keeps its bits.  NORI_HIP_WF_TAIL_CUS (a multiple of 8;
+       0: tails on the bulk's stream, as a call of one batch runs them). */
+    int tail_cus = 32;
+    if (const char *e = getenv("NORI_HIP_WF_TAIL_CUS")) tail_cus = std::max(0, atoi(e)) & ~7;
+    {
+        const Pipe &P0 = pipes[0];
+        const uint64_t nt0 = P0.tile_hi - P0.tile_lo;
+        const uint64_t batches = ((nt0 + P0.tiles_b - 1) / std::max(1u, P0.tiles_b)) * ((L.spp_count + P0.spp_b - 1) / std::max(1u, P0.spp_b));
+        if (n_pipes != 1 || split || batches < 2 || L.film_reference || L.count_traversal || tail_cus >= eng.n_cus) tail_cus = 0;
+        if (getenv("NORI_HIP_WF_FINISH") && atoi(getenv("NORI_HIP_WF_FINISH")) == 0) tail_cus = 0;
+        if (tail_cus > 0 && !ensure_tail_stream(eng, tail_cus)) tail_cus = 0;
+    }
+    const bool overlap = tail_cus > 0;
     if (L.film_reference && (n_pipes != 1 || pipes[0].tiles_b != L.n_sel_tiles || pipes[0].spp_b != L.spp_count || L.tile_mod != 1))
         return "wavefront: film_order = reference needs the whole frame in one batch (tile_mod 1, wavefront_paths >= pixels x samples)";
     const size_t per_pipe = std::max(need[0], need[1]);
@@ -1148,9 +1255,9 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     std::string err = ensure_pool(g_pool, records * n_pipes);
     if (!err.empty()) return err;
     FilmStore film;
-    err = film_prepare(film_store, per_pipe * n_pipes, L.n_sel_tiles, L.tile_w, s, film);
+    err = film_prepare(film_store, per_pipe * (overlap ? 2 : n_pipes), L.n_sel_tiles, L.tile_w, s, film);
     if (!err.empty()) return err;
-    stats.state_bytes = g_pool.bytes + per_pipe * n_pipes * (sizeof(f2) + sizeof(P3));
+    stats.state_bytes = g_pool.bytes + per_pipe * (overlap ? 2 : n_pipes) * (sizeof(f2) + sizeof(P3));
     WF_TRY(hipMemsetAsync(g_pool.buf.stats, 0, 2 * S_COUNT * sizeof(unsigned long long), s));
 
     for (int k = 0; k < 3; ++k) if (!g_events[k]) WF_TRY(hipEventCreateWithFlags(&g_events[k], hipEventDisableTiming));
@@ -1160,8 +1267,9 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             P.extend_stream = eng.split_streams[0]; P.stream = eng.split_streams[1];
             for (hipEvent_t &ev : eng.pipe_events[k]) if (!ev) WF_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
             P.ev_extend = eng.pipe_events[k][0]; P.ev_shade = eng.pipe_events[k][1];
-        } else if (n_pipes == 1) P.stream = P.extend_stream = s;
-        else {
+        } else if (n_pipes == 1 && !overlap) P.stream = P.extend_stream = s;
+        else {      /* (overlap: the bulk on a stream of the engine's own, too -- the caller's may be the legacy default stream, which
+                       runs nothing beside the work of another stream) */
             if (!g_streams[k]) WF_TRY(hipStreamCreateWithFlags(&g_streams[k], hipStreamNonBlocking));
             P.stream = P.extend_stream = g_streams[k];
         }
@@ -1170,7 +1278,9 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
         P.b.samp_pos = P.film.pos; P.b.samp_L = P.film.L;
         P.h_ctr = g_pool.h_ctr + (size_t) k * C_COUNT;
     }
-    if (n_pipes > 1) {      /* the pipes start after whatever the caller queued on its stream */
+    const bool own_streams = n_pipes > 1 || overlap;
+    hipStream_t tail_stream = overlap ? eng.tail_stream : nullptr;
+    if (own_streams) {      /* the pipes start after whatever the caller queued on its stream */
         WF_TRY(hipEventRecord(g_events[2], s));
         for (int k = 0; k < n_pipes; ++k) { WF_TRY(hipStreamWaitEvent(pipes[k].stream, g_events[2], 0)); if (split) WF_TRY(hipStreamWaitEvent(pipes[k].extend_stream, g_events[2], 0)); }
     }
@@ -1225,10 +1335,13 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     if (sc.wide) per_cu = std::min(per_cu, kExtendWgsWide);
     if (n_pipes > 1 && !split) per_cu = std::max(1, per_cu / 2);
     if (const char *e = getenv("NORI_HIP_WF_EXTEND_WGS_PER_CU")) per_cu = std::min(2048 / extend_block, std::max(1, atoi(e)));
-    const int extend_cus = eng.n_cus - split_cus;      /* the persistent grid fills the CUs its stream owns */
+    const int extend_cus = eng.n_cus - split_cus;      /* the persistent grid fills the CUs its stream owns (a tail beside it: some of its
+                                                          workgroups start when the tail's have left -- handing them their first chunk in
+                                                          the order they start instead of by position was measured and is no faster,
+                                                          profiles/r5_11_tail_overlap_c4.txt) */
     const int extend_grid_first = extend_cus * (sc.wide ? std::min(per_cu, kExtendWgsWideFirst) : per_cu);
     const int extend_grid = extend_cus * per_cu;
-    stats.trace_cus = (uint32_t) extend_cus;
+    stats.trace_cus = (uint32_t) extend_cus; stats.tail_cus = (uint32_t) tail_cus;
     if (L.stack_depth > 16) {      /* wf_finish keeps 16 entries in LDS */
         const size_t per_pipe_ints = (size_t) (L.stack_depth - 16) * std::max(extend_grid * extend_block, finish_grid * kB), ints = per_pipe_ints * n_pipes;
         if (g_pool.spill_ints < ints) {
@@ -1239,6 +1352,16 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
         }
         for (int k = 0; k < n_pipes; ++k) pipes[k].b.stack_spill = g_pool.spill + per_pipe_ints * k;
     }
+
+    /* wf_finish: the persistent form (a lane pulls path after path) on four workgroups per CU of the stream it runs on -- the pa5
+       table scene's tail 22 -> 19 ms on all CUs, 223 -> 80 ms on 16 (profiles/r5_06_tail_probe_c4.txt) */
+    const int finish_grid_main = std::min(finish_grid, std::max(1, extend_cus * 4));
+    const int finish_grid_side = std::min(finish_grid, std::max(1, tail_cus * 4));
+    if (overlap) {
+        err = ensure_tail_side(eng, (size_t) finish_paths, L.stack_depth > 16 ? (size_t) (L.stack_depth - 16) * finish_grid_side * kB : 0);
+        if (!err.empty()) return err;
+    }
+    struct { bool active = false; FilmLaunch fl; FilmStore film; } pend;      /* overlap: the batch whose tail is in flight -- its film gather is still to come */
 
     /* node steps repeat in a tight loop while >= 24 lanes of the wave are at inner nodes -- without the refill test, the leaf
        vote and the rest of the trip's bookkeeping, which cost as much as the node step itself (measured, wf_extend: Cornell
@@ -1275,6 +1398,11 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             P.bt.flags = (no_asm_loop ? kBatchNoAsmLoop : 0u) | (count_q ? kBatchCountQ : 0u);
             WF_TRY(hipMemsetAsync(P.b.ctr, 0, C_COUNT * sizeof(uint32_t), P.stream));
             if (split) WF_TRY(hipEventRecord(P.ev_shade, P.stream));      /* (and the film of the pipe's last batch, which read the sample store) */
+            if (overlap) {      /* the sample store's halves alternate: the previous batch's tail and gather still use the other one */
+                const size_t half = (size_t) (stats.n_batches & 1u) * per_pipe;
+                P.film = film; P.film.pos += half; P.film.L += half;
+                P.b.samp_pos = P.film.pos; P.b.samp_L = P.film.L;
+            }
             stats.n_batches++;
             P.cur = 0; P.first = true; P.active = true; any = true; P.batch_rounds = 0;
         }
@@ -1311,20 +1439,59 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             Pipe &P = pipes[k];
             if (P.active && P.h_ctr[C_OVERFLOW] != 0) return "wavefront: path state pool overflow";
             if (census && P.active) fprintf(stderr, "[wavefront] pipe %d iteration %u: %u path slots\n", k, stats.n_iterations, P.h_ctr[C_N + P.cur]);
-            if (P.active && P.h_ctr[C_N + P.cur] != 0 && P.h_ctr[C_N + P.cur] <= (uint32_t) finish_paths && use_finish) {
-                timer.begin(KC_SHADE, P.stream);
-                launch_finish(sc, P.b, P.cur, P.bt, L.count_traversal, finish_grid, P.stream);
+            /* the film gather of the batch whose tail ran beside this one: behind the tail, in front of everything that follows on
+               this stream (gathers stay in batch order) */
+            auto flush_pending = [&]() -> std::string {
+                if (!pend.active) return std::string();
+                WF_TRY(hipStreamWaitEvent(P.stream, eng.tail_events[1], 0));
+                timer.begin(KC_FILM, P.stream);
+                film_gather(sc, d_filter_table, pend.film, pend.fl, P.stream);
                 timer.end(P.stream);
                 stats.n_launches++;
+                pend.active = false;
+                return std::string();
+            };
+            bool gather_deferred = false;
+            if (P.active && P.h_ctr[C_N + P.cur] != 0 && P.h_ctr[C_N + P.cur] <= (uint32_t) finish_paths && use_finish) {
+                const bool last_batch = P.s0 + P.bt.n_spp >= L.spp_count && P.t0 + P.bt.n_tiles >= P.tile_hi;
+                if (overlap && !last_batch) {
+                    err = flush_pending();      /* (also: the previous tail is done with the side copy) */
+                    if (!err.empty()) return err;
+                    hipLaunchKernelGGL(wf_tail_copy, dim3(std::max(1u, (P.h_ctr[C_N + P.cur] + kB - 1) / kB)), dim3(kB), 0, P.stream, P.b, P.cur, eng.tail.st, eng.tail.ctr);
+                    WF_TRY(hipEventRecord(eng.tail_events[0], P.stream));
+                    WF_TRY(hipStreamWaitEvent(tail_stream, eng.tail_events[0], 0));
+                    /* the bulk goes on once the tail is about to be dispatched: its workgroups take their CUs first */
+                    WF_TRY(hipEventRecord(eng.tail_events[2], tail_stream));
+                    WF_TRY(hipStreamWaitEvent(P.stream, eng.tail_events[2], 0));
+                    WfBuf tb = P.b;
+                    tb.st[0] = eng.tail.st; tb.ctr = eng.tail.ctr; tb.stack_spill = eng.tail.spill; tb.capacity = (uint32_t) eng.tail.capacity;
+                    timer.begin(KC_TAIL, tail_stream);
+                    launch_finish(sc, tb, 0, P.bt, false, finish_grid_side, tail_stream);
+                    timer.end(tail_stream);
+                    WF_TRY(hipEventRecord(eng.tail_events[1], tail_stream));
+                    pend.active = true; pend.film = P.film;
+                    pend.fl = fl; pend.fl.tile_first = P.bt.tile_first; pend.fl.store_tile_first = P.bt.tile_first; pend.fl.n_tiles = P.bt.n_tiles; pend.fl.n_spp = P.bt.n_spp;
+                    gather_deferred = true;
+                    stats.n_launches += 2;
+                } else {
+                    timer.begin(KC_SHADE, P.stream);
+                    launch_finish(sc, P.b, P.cur, P.bt, L.count_traversal, finish_grid_main, P.stream);
+                    timer.end(P.stream);
+                    stats.n_launches++;
+                }
                 P.h_ctr[C_N + P.cur] = 0;
             }
             if (!P.active || P.h_ctr[C_N + P.cur] != 0) continue;
             /* batch done: splat its samples (each pipe owns its tiles' accumulators) */
-            fl.tile_first = P.bt.tile_first; fl.store_tile_first = P.bt.tile_first; fl.n_tiles = P.bt.n_tiles; fl.n_spp = P.bt.n_spp;
-            timer.begin(KC_FILM, P.stream);
-            if (!L.film_reference) film_gather(sc, d_filter_table, P.film, fl, P.stream);
-            timer.end(P.stream);
-            stats.n_launches++;
+            if (!gather_deferred) {
+                err = flush_pending();
+                if (!err.empty()) return err;
+                fl.tile_first = P.bt.tile_first; fl.store_tile_first = P.bt.tile_first; fl.n_tiles = P.bt.n_tiles; fl.n_spp = P.bt.n_spp;
+                timer.begin(KC_FILM, P.stream);
+                if (!L.film_reference) film_gather(sc, d_filter_table, P.film, fl, P.stream);
+                timer.end(P.stream);
+                stats.n_launches++;
+            }
             P.active = false;
             P.s0 += P.bt.n_spp;
             if (P.s0 >= L.spp_count) { P.s0 = 0; P.t0 += P.bt.n_tiles; }
@@ -1334,7 +1501,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
         for (int k = 0; k < n_pipes; ++k)
             if (pipes[k].active && ++pipes[k].batch_rounds > 20000) return "wavefront: path loop did not terminate";
     }
-    if (n_pipes > 1)        /* back to the caller's stream */
+    if (own_streams)        /* back to the caller's stream */
         for (int k = 0; k < n_pipes; ++k) {
             WF_TRY(hipEventRecord(g_events[k], pipes[k].stream));
             WF_TRY(hipStreamWaitEvent(s, g_events[k], 0));

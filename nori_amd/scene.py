@@ -142,7 +142,19 @@ class Scene:
         return (self.camera.height + 2 * b, self.camera.width + 2 * b, 4)
 
     # --------------------------------------------------------- (de)serialise
-    def save_npz(self, path: str) -> None:
+    def geometry_digest(self) -> str:
+        """sha256 over everything a fixture stores as arrays (camera transform, per mesh V / F / N / UV)."""
+        import hashlib
+        h = hashlib.sha256()
+        h.update(np.ascontiguousarray(self.camera.to_world, dtype=np.float32).tobytes())
+        for m in self.meshes:
+            for a in (m.positions, m.indices, m.normals, m.texcoords):
+                h.update(b"-" if a is None else np.ascontiguousarray(a).tobytes())
+        return h.hexdigest()
+
+    def save_npz(self, path: str, base: Optional[str] = None) -> None:
+        """`base`: name of a fixture in the same directory with the same arrays (several shipped scenes differ in the integrator,
+        the sample count or one BSDF only): the file then holds the parameters and the digest of the arrays, not the arrays."""
         meta = {
             "camera": {"width": self.camera.width, "height": self.camera.height, "fov": self.camera.fov,
                        "near_clip": self.camera.near_clip, "far_clip": self.camera.far_clip},
@@ -157,6 +169,10 @@ class Scene:
                         "normals": m.normals is not None, "texcoords": m.texcoords is not None}
                        for m in self.meshes],
         }
+        if base is not None:
+            meta["base"], meta["geometry_digest"] = base, self.geometry_digest()
+            np.savez_compressed(path, meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+            return
         arrays = {"to_world": np.asarray(self.camera.to_world, dtype=np.float32)}
         for i, m in enumerate(self.meshes):
             arrays[f"m{i}_V"] = m.positions
@@ -172,6 +188,23 @@ class Scene:
     def load_npz(path: str) -> "Scene":
         z = np.load(path)
         meta = json.loads(bytes(z["meta"]).decode())
+        if "base" in meta:      # parameters of this scene over the arrays of another fixture (save_npz)
+            import os
+            sc = Scene.load_npz(os.path.join(os.path.dirname(os.path.abspath(path)), meta["base"] + ".npz"))
+            assert len(sc.meshes) == len(meta["meshes"]), "variant fixture does not match its base"
+            cam = sc.camera.to_world
+            sc.camera = Camera(to_world=cam, **meta["camera"])
+            sc.rfilter = RFilter(**meta["rfilter"])
+            it = meta["integrator"]
+            sc.integrator = Integrator(it["type"], tuple(it["position"]), tuple(it["energy"]))
+            sc.sample_count = meta["sample_count"]
+            for m, mm in zip(sc.meshes, meta["meshes"]):
+                b = mm["bsdf"]
+                m.bsdf = Bsdf(b["type"], tuple(b["albedo"]), b["alpha"], b["int_ior"], b["ext_ior"])
+                m.radiance = tuple(mm["radiance"]) if mm["radiance"] is not None else None
+                m.name = mm["name"]
+            assert sc.geometry_digest() == meta["geometry_digest"], "variant fixture: the base fixture's arrays have changed"
+            return sc
         sc = Scene()
         sc.camera = Camera(to_world=z["to_world"].astype(np.float32), **meta["camera"])
         sc.rfilter = RFilter(**meta["rfilter"])

@@ -165,6 +165,44 @@ def test_cus_split_between_traversal_and_shading_give_the_same_frame(renderer_fa
         assert sr2["n_closest_rays"] == sb["n_closest_rays"] and sr2["n_shadow_rays"] == sb["n_shadow_rays"], env
 
 
+def test_tail_of_a_batch_beside_the_next_batch_gives_the_same_frame(renderer_factory):
+    """Tail overlap (wavefront_render): in a call of several batches the last live paths of batch k are copied out of the state
+    pool and walked by the persistent wf_finish on a stream that owns a few CUs while batch k + 1 runs on the caller's stream; the film gather of batch k
+    follows that of batch k - 1 and precedes that of batch k + 1 as before.  Same samples, same order per pixel: the bits of the
+    frame rendered with the tails on the bulk's stream, equal ray counts, and the stats say which CUs did what."""
+    sc = scenes.cornell_box(160, 128, 12, "path_mis", sphere_bsdfs=[Bsdf("mirror"), Bsdf("dielectric")])
+    wf = renderer_factory(sc)
+    wf.set_option("engine", "wavefront")
+    for budget in (160 * 128 * 5, 256 * 12, 1 << 20):      # 3 sample batches of all tiles; tile batches; one batch (nothing to overlap)
+        wf.set_option("wavefront_paths", budget)
+        ref, sr = _with_env({"NORI_HIP_WF_TAIL_CUS": 0}, lambda: wf.render_host())
+        assert sr["tail_cus"] == 0 and sr["tail_ms"] == 0.0
+        for cus in (8, 32, 64):
+            for env in ({}, {"NORI_HIP_WF_FINISH_PATHS": 256}, {"NORI_HIP_WF_SYNC_EVERY": 1}):
+                b, sb = _with_env({"NORI_HIP_WF_TAIL_CUS": cus, **env}, lambda: wf.render_host())
+                assert np.array_equal(b, ref), (budget, cus, env)
+                for k in ("n_camera_samples", "n_closest_rays", "n_shadow_rays"):
+                    assert sr[k] == sb[k], (budget, cus, k)
+                if budget < (1 << 20):
+                    assert sb["tail_cus"] == cus and sb["trace_cus"] == sr["trace_cus"], (budget, cus, sb["tail_cus"], sb["trace_cus"])
+                else:
+                    assert sb["tail_cus"] == 0 and sb["trace_cus"] == sr["trace_cus"]
+    # a tree deeper than wf_finish's LDS stack: the side launch spills into its own columns
+    sc = scenes.soup_scene(30000, seed=3, width=80, height=56, integrator="path_mis")
+    sc.sample_count = 6
+    from nori_amd.scene import Mesh
+    v, f = scenes.quad((-3, 3, -3), (3, 3, -3), (3, 3, 3), (-3, 3, 3))
+    sc.meshes.append(Mesh(v, f, bsdf=Bsdf("diffuse", (0, 0, 0)), radiance=(5.0, 5.0, 5.0), name="light"))
+    wf = renderer_factory(sc, builder=1)
+    wf.set_option("engine", "wavefront")
+    assert wf.accel_info()["max_depth"] + 1 > 16
+    wf.set_option("wavefront_paths", 80 * 56 * 2)
+    ref, sr = _with_env({"NORI_HIP_WF_TAIL_CUS": 0}, lambda: wf.render_host())
+    b, sb = _with_env({"NORI_HIP_WF_TAIL_CUS": 16}, lambda: wf.render_host())
+    assert np.array_equal(b, ref) and sb["tail_cus"] == 16
+    assert sr["n_closest_rays"] == sb["n_closest_rays"] and sr["n_shadow_rays"] == sb["n_shadow_rays"]
+
+
 def test_wavefront_deep_tree_spills_the_stack(renderer_factory):
     """LBVH over a triangle soup is deeper than 16: with NORI_HIP_WF_STACK=16 wf_extend keeps 16 stack
     entries in LDS and the rest in its global spill columns; same frame and counts as the megakernel
@@ -223,9 +261,11 @@ def test_kernel_class_timing(renderer_factory):
 
 
 @pytest.mark.parametrize("name", ["pa1-bunny", "pa4-cbox-distributed", "pa4-cbox-path_mis", "pa4-cbox-whitted",
-                                  "pa4-motto-dielectric", "pa5-cbox_mis", "pa5-table_mis", "pa5-veach_mis"])
+                                  "pa4-motto-dielectric", "pa4-motto-diffuse", "pa5-cbox_mis", "pa5-cbox_ems", "pa5-cbox_mats",
+                                  "pa5-table_mis", "pa5-table_ems", "pa5-table_mats", "pa5-veach_mis", "pa5-veach_ems", "pa5-veach_mats"])
 def test_reference_scenes_both_engines_and_oracle(renderer_factory, name):
-    """Every shipped scene (geometry, materials, camera, integrator as in the XML; reduced resolution
+    """Every shipped scene whose meshes ship with the reference (the ajax scenes' OBJ does not): geometry, materials, camera,
+    integrator as in the XML (tools/make_goldens.py; scene x integrator pairs that share their arrays share one fixture's; reduced resolution
     and sample count): both engines trace the same rays and produce the same frame, and the frame
     agrees with the CPU oracle within the SURVEY 8(d) image contract (>= 99.9 % of pixels within 1e-3,
     mean relative error <= 1e-4)."""

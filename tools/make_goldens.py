@@ -31,6 +31,15 @@ SCENES = {
     "pa5-cbox_mis": ("pa5/cbox/cbox_mis.xml", {}),
     "pa5-table_mis": ("pa5/table/table_mis.xml", {}),
     "pa5-veach_mis": ("pa5/veach_mi/veach_mis.xml", {}),
+    # the other loadable shipped scenes: the arrays of a fixture above under another integrator / sample count / BSDF --
+    # stored as parameters + the digest of the arrays (Scene.save_npz(base=...))
+    "pa4-motto-diffuse": ("pa4/motto/motto-diffuse.xml", {"variant": True}),
+    "pa5-cbox_ems": ("pa5/cbox/cbox_ems.xml", {"variant": True}),
+    "pa5-cbox_mats": ("pa5/cbox/cbox_mats.xml", {"variant": True}),
+    "pa5-table_ems": ("pa5/table/table_ems.xml", {"variant": True}),
+    "pa5-table_mats": ("pa5/table/table_mats.xml", {"variant": True}),
+    "pa5-veach_ems": ("pa5/veach_mi/veach_ems.xml", {"variant": True}),
+    "pa5-veach_mats": ("pa5/veach_mi/veach_mats.xml", {"variant": True}),
 }
 TESTS = ["pa4/tests/test-mesh-furnace.xml", "pa4/tests/test-mesh.xml", "pa5/tests/test-furnace.xml",
          "pa5/tests/test-direct.xml", "pa5/tests/ttest-microfacet.xml", "pa5/tests/chi2test-microfacet.xml"]
@@ -39,6 +48,7 @@ TESTS = ["pa4/tests/test-mesh-furnace.xml", "pa4/tests/test-mesh.xml", "pa5/test
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     os.makedirs(os.path.join(OUT, "tests"), exist_ok=True)
+    full = {}      # digest of a scene's arrays -> the fixture that stores them
     for name, (xml, ov) in SCENES.items():
         sc = host.load_xml(os.path.join(ref, "scenes", xml))
         if "integrator" in ov:
@@ -49,8 +59,12 @@ def main():
         for i, m in enumerate(sc.meshes):
             m.name = f"{name}:{i}"
         path = os.path.join(OUT, name + ".npz")
-        sc.save_npz(path)
-        print(f"{name}: {sc.n_triangles} tris, {os.path.getsize(path) / 1024:.0f} KiB")
+        digest = sc.geometry_digest()
+        base = full.get(digest) if ov.get("variant") else None
+        sc.save_npz(path, base=base)
+        if base is None:
+            full[digest] = name
+        print(f"{name}: {sc.n_triangles} tris, {os.path.getsize(path) / 1024:.0f} KiB" + (f" (arrays of {base})" if base else ""))
     for xml in TESTS:
         r = host.HostRoot(os.path.join(ref, "scenes", xml))
         t = r.test()
