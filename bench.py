@@ -334,7 +334,9 @@ def main():
             "metric": "Mrays/sec (primary+secondary) at 1024x1024 256spp" if wl.name == "pa4-cbox-path_mis" else "Mrays/sec (primary+secondary)",
             "value": round(mrays, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            # the triangles: a shipped scene of the reference flattened into tests/golden/ (tools/make_goldens.py), or a seeded generator
+            "data": ("reference scene (" + wl.generator + ")") if "tests/golden/" in wl.generator else "synthetic (" + wl.generator + ")",
             "config": {"workload": wl.name, "baseline_config": wl.config, "generator": wl.generator,
                        "integrator": sc.integrator.type, "width": width, "height": height, "spp": spp,
                        "triangles": info["n_triangles"],
@@ -343,6 +345,8 @@ def main():
             "roofline": roof,
             "pass": {"kernel_ms": round(k_ms, 3), "trace_ms": round(float(np.mean(trace_ms)), 3), "shade_ms": round(float(np.mean(shade_ms)), 3),
                      "film_ms": round(float(np.mean(film_ms)), 3),
+                     # wavefront engine, calls of two or more batches: wf_finish launches that ran beside the next batch on their own CUs
+                     "tail_beside_ms": round(float(last.get("tail_ms", 0.0)), 3), "tail_cus": int(last.get("tail_cus", 0)),
                      "hbm_measured_bytes": (ctr[1].get("pass_hbm_bytes") if ctr else None)},
             "accel": dict({k: (round(v, 3) if isinstance(v, float) else v) for k, v in info.items()}, builder=args.builder),
         }

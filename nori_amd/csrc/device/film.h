@@ -48,6 +48,7 @@ struct FilmStore {
     size_t block_floats = 0;
     uint32_t *spiral_rank = nullptr;     /* reference order: position of every 32x32 block in BlockGenerator's sequence */
     size_t n_rank = 0;
+    uint32_t rank_bx = 0, rank_by = 0;   /* the block grid the ranks on the device were computed for (uploaded once per frame geometry) */
 };
 
 struct FilmLaunch {

@@ -457,13 +457,16 @@ std::string film_resolve_blocks(FilmStore &store, const DevScene &sc, const floa
     const uint32_t bxn = (uint32_t) ((w + kBlock32 - 1) / kBlock32), byn = (uint32_t) ((h + kBlock32 - 1) / kBlock32), nb = bxn * byn;
     if (store.n_rank != nb) {
         if (store.spiral_rank) (void) hipFree(store.spiral_rank);
-        store.spiral_rank = nullptr; store.n_rank = 0;
+        store.spiral_rank = nullptr; store.n_rank = 0; store.rank_bx = store.rank_by = 0;
         FILM_TRY(hipMalloc((void **) &store.spiral_rank, (size_t) nb * sizeof(uint32_t)));
         store.n_rank = nb;
     }
-    const std::vector<uint32_t> rank = spiral_ranks((int) bxn, (int) byn);       /* the frame size may have changed: cheap, recomputed per call */
-    FILM_TRY(hipMemcpyAsync(store.spiral_rank, rank.data(), (size_t) nb * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t) stream));
-    FILM_TRY(hipStreamSynchronize((hipStream_t) stream));                       /* `rank` is a host temporary */
+    if (store.rank_bx != bxn || store.rank_by != byn) {      /* once per frame geometry: a merge that is timed (group, nori_amd.dist) then holds no upload and no wait */
+        const std::vector<uint32_t> rank = spiral_ranks((int) bxn, (int) byn);
+        FILM_TRY(hipMemcpyAsync(store.spiral_rank, rank.data(), (size_t) nb * sizeof(uint32_t), hipMemcpyHostToDevice, (hipStream_t) stream));
+        FILM_TRY(hipStreamSynchronize((hipStream_t) stream));                       /* `rank` is a host temporary */
+        store.rank_bx = bxn; store.rank_by = byn;
+    }
     const int cols = w + 2 * border, rows = h + 2 * border;
     hipLaunchKernelGGL(film_resolve_reference_kernel, dim3((cols + 255) / 256, rows), dim3(256), 0, (hipStream_t) stream, w, h, border, bxn, byn,
                        d_block_acc, (const uint32_t *) store.spiral_rank, d_rgbw);

@@ -114,6 +114,18 @@ struct nori_hip_group {
     std::vector<int32_t *> d_x_root;       /* on device 0: column list of device k */
     std::vector<ncclComm_t> comms;
     size_t frame_floats = 0, pack_floats = 0, x_ints = 0, recv_floats = 0;      /* what the buffers are sized for */
+    /* film_order = reference (group_render_reference): per device its block accumulators; on device 0 a receive buffer (peer-copy
+       transport) and the frame -- kept between frames like the others */
+    std::vector<float *> d_ref_acc;
+    float *d_ref_recv = nullptr, *d_ref_frame = nullptr;
+    size_t ref_acc_floats = 0, ref_frame_floats = 0;
+    void free_reference_buffers() {
+        for (size_t k = 0; k < d_ref_acc.size() && k < devices.size(); ++k) if (d_ref_acc[k]) { (void) hipSetDevice(devices[k]); (void) hipFree(d_ref_acc[k]); }
+        if (!devices.empty()) (void) hipSetDevice(devices[0]);
+        if (d_ref_recv) (void) hipFree(d_ref_recv);
+        if (d_ref_frame) (void) hipFree(d_ref_frame);
+        d_ref_acc.clear(); d_ref_recv = d_ref_frame = nullptr; ref_acc_floats = ref_frame_floats = 0;
+    }
     bool rccl = false;
     std::string error, warning;
     std::vector<uint32_t> engines;         /* what rendered each device's share of the last frame (nori_render_stats::engine) */
@@ -129,6 +141,7 @@ struct nori_hip_group {
         for (int32_t *p : d_x_root) if (p) (void) hipFree(p);
         d_frame.clear(); d_pack.clear(); d_x.clear(); d_recv.clear(); d_x_root.clear();
         frame_floats = pack_floats = x_ints = recv_floats = 0;
+        free_reference_buffers();
     }
 };
 
@@ -208,20 +221,16 @@ static int group_render_reference(nori_hip_group *g, const nori_render_params *p
     size_t acc_floats = 0;
     if (nori_hip_block_acc_floats(g->ctx[0], &acc_floats) != NORI_OK) { g->error = std::string("group_render: ") + nori_hip_last_error(g->ctx[0]); return NORI_ERR_NOT_READY; }
     const uint32_t block_rows = (uint32_t) ((height + 31) / 32);
-    struct Buffers {      /* this mode is for comparisons: its buffers live for one frame */
-        nori_hip_group *g; std::vector<float *> acc; float *recv = nullptr, *frame = nullptr;
-        ~Buffers() {
-            for (size_t k = 0; k < acc.size(); ++k) if (acc[k]) { (void) hipSetDevice(g->devices[k]); (void) hipFree(acc[k]); }
-            (void) hipSetDevice(g->devices[0]);
-            if (recv) (void) hipFree(recv);
-            if (frame) (void) hipFree(frame);
-        }
-    } buf;
-    buf.g = g; buf.acc.assign((size_t) n, nullptr);
-    for (int k = 0; k < n; ++k) { GRP_HIP(hipSetDevice(g->devices[(size_t) k])); GRP_HIP(hipMalloc((void **) &buf.acc[(size_t) k], acc_floats * sizeof(float))); }
-    GRP_HIP(hipSetDevice(g->devices[0]));
-    GRP_HIP(hipMalloc((void **) &buf.frame, frame_floats * sizeof(float)));
-    if (!g->rccl) GRP_HIP(hipMalloc((void **) &buf.recv, acc_floats * sizeof(float)));
+    struct { std::vector<float *> &acc; float *&recv, *&frame; } buf = {g->d_ref_acc, g->d_ref_recv, g->d_ref_frame};
+    if (g->ref_acc_floats != acc_floats || g->ref_frame_floats != frame_floats || (int) g->d_ref_acc.size() != n || (!g->rccl && !g->d_ref_recv)) {
+        g->free_reference_buffers();
+        g->d_ref_acc.assign((size_t) n, nullptr);
+        for (int k = 0; k < n; ++k) { GRP_HIP(hipSetDevice(g->devices[(size_t) k])); GRP_HIP(hipMalloc((void **) &g->d_ref_acc[(size_t) k], acc_floats * sizeof(float))); }
+        GRP_HIP(hipSetDevice(g->devices[0]));
+        GRP_HIP(hipMalloc((void **) &g->d_ref_frame, frame_floats * sizeof(float)));
+        if (!g->rccl) GRP_HIP(hipMalloc((void **) &g->d_ref_recv, acc_floats * sizeof(float)));
+        g->ref_acc_floats = acc_floats; g->ref_frame_floats = frame_floats;
+    }
 
     std::vector<int> rc((size_t) n, NORI_OK);
     std::vector<nori_render_stats> st((size_t) n);
@@ -390,6 +399,11 @@ int nori_hip_group_render_host(nori_hip_group *g, const nori_render_params *para
         if (n_ref != 0 && n_ref != n) { g->error = "group_render: film_order = reference on some devices of the group only"; return NORI_ERR_INVALID_ARGUMENT; }
         if (n_ref == n) {
             if (params->seed_mode == NORI_SEED_NORI_BLOCK) { g->error = "group_render: NORI_SEED_NORI_BLOCK renders whole frames on one device"; return NORI_ERR_UNSUPPORTED; }
+            /* the reference's order leaves no choice of split or merge: rows of 32x32 blocks, the blocks' accumulators reduced */
+            {
+                const char *note = "group_render: film_order = reference renders rows of 32x32 blocks per device and reduces their accumulators; the split and merge arguments do not apply";
+                if (g->warning.find(note) == std::string::npos) g->warning += (g->warning.empty() ? "" : "; ") + std::string(note);
+            }
             return group_render_reference(g, params, width, height, rgbw, stats, merge_ms);
         }
     }

@@ -1111,11 +1111,20 @@ static int render_impl(nori_hip_ctx *ctx, const nori_render_params *params, void
         wl.film_reference = ctx->film_reference; wl.film_share = share;
         wl.max_paths = ctx->wavefront_paths;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+        if (!getenv("NORI_HIP_WF_IGNORE_FREE") /* test hook: as if the free figure were stale */ && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t usable = (size_t) ((double) (free_b + wavefront_held_bytes(ctx->wf, ctx->film)) * 0.85);
             wl.max_paths = std::max<size_t>(256, std::min(wl.max_paths, usable / wavefront_bytes_per_path()));
         }
         std::string err = wavefront_render(*ctx->wf, ctx->film, ctx->dev, ctx->d_filter, wl, (float *) d_rgbw, s, wst);
+        /* The free figure above is a snapshot: another context on this device -- a group with a duplicated device list rendering
+           in parallel threads, a second process -- may have claimed the same bytes in the meantime.  Smaller batches then: nothing
+           has been accumulated yet when the pool or the sample store cannot be allocated (they are allocated before the first
+           launch), so the call is simply made again with half the paths in flight. */
+        while (!err.empty() && err.find("out of memory") != std::string::npos && wl.max_paths > ((size_t) 1 << 20) && !ctx->film_reference) {
+            (void) hipGetLastError();
+            wl.max_paths /= 2;
+            err = wavefront_render(*ctx->wf, ctx->film, ctx->dev, ctx->d_filter, wl, (float *) d_rgbw, s, wst);
+        }
         if (!err.empty()) {
             ctx->error = err;
             return err.find("out of memory") != std::string::npos ? NORI_ERR_OUT_OF_MEMORY : NORI_ERR_INTERNAL;

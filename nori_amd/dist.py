@@ -129,23 +129,35 @@ def render_distributed_reference(renderer, frame, spp: int, rank: int, world: in
     """film_order = reference over the ranks (module docstring).  `renderer`: nori_amd.render.Renderer with
     set_option("film_order", "reference") (anything with its block_rows / block_acc_floats / render_block_rows_into /
     resolve_blocks: the CPU tests pass a stand-in); `frame`: this rank's RGBW tensor, the merged frame on rank 0."""
+    import contextlib
     import time
     import torch
-    acc = torch.zeros(renderer.block_acc_floats(), dtype=torch.float32, device=frame.device)
-    r0, rn = block_rows(rank, world, renderer.block_rows())
-    stats = renderer.render_block_rows_into(acc, r0, rn, spp_count=spp, **kw)
-    timed = merge_ms is not None and _group_up()
-    if timed and frame.is_cuda:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    t0 = time.perf_counter()
-    reduce_frame(acc, 0)      # disjoint arrays: x + 0 = x, exact whatever order the ring adds in
-    frame.zero_()
-    if rank == 0:
-        renderer.resolve_blocks(acc, frame)
-    if timed and frame.is_cuda:
-        e1.record(); e1.synchronize()
-        merge_ms.append(float(e0.elapsed_time(e1)))
-    elif timed:
-        merge_ms.append((time.perf_counter() - t0) * 1e3)
+    # A caller's stream (kw["stream"], a torch.cuda.Stream) carries EVERYTHING of this call: the zeroing of the accumulators,
+    # the render, the reduce (torch.distributed orders a collective after the current stream's work), the frame's zeroing and the
+    # block merge -- each step reads what the previous one wrote, and a non-blocking stream is ordered against no other.
+    stream = kw.pop("stream", None)
+    on = torch.cuda.stream(stream) if (stream is not None and frame.is_cuda) else contextlib.nullcontext()
+    with on:
+        acc = torch.zeros(renderer.block_acc_floats(), dtype=torch.float32, device=frame.device)
+        r0, rn = block_rows(rank, world, renderer.block_rows())
+        if stream is not None:
+            kw["stream"] = stream
+        stats = renderer.render_block_rows_into(acc, r0, rn, spp_count=spp, **kw)
+        timed = merge_ms is not None and _group_up()
+        if timed and frame.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        t0 = time.perf_counter()
+        reduce_frame(acc, 0)      # disjoint arrays: x + 0 = x, exact whatever order the ring adds in
+        frame.zero_()
+        if rank == 0:
+            if stream is not None:
+                renderer.resolve_blocks(acc, frame, stream=stream)
+            else:
+                renderer.resolve_blocks(acc, frame)
+        if timed and frame.is_cuda:
+            e1.record(); e1.synchronize()
+            merge_ms.append(float(e0.elapsed_time(e1)))
+        elif timed:
+            merge_ms.append((time.perf_counter() - t0) * 1e3)
     return stats

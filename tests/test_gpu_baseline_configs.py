@@ -48,6 +48,54 @@ def test_baseline_config_at_full_geometry_matches_the_oracle(name, spp, triangle
     r.close(); o.close()
 
 
+def test_device_builder_at_ten_million_triangles_gives_the_host_trees_hits():
+    """builder = auto on the 10 M-triangle terrain: above 2^22 triangles it is the device's PLOC builder with its treelet sweeps on
+    (lbvh.hip: a wave per treelet, tree data handed over at agent scope) -- the path no small scene takes.  A valid tree gives the
+    scan's answers, and so does the host's SAH tree (checked against the oracle above): every field of the intersection record equal
+    for a grid of vertical rays that reaches every cell of the height field (each triangle is hit by at least one ray or shares its
+    leaf with one that is), for slanted rays, for shadow queries; and the frame of a render has the same bits, ray for ray."""
+    from nori_amd import workloads
+    from nori_amd._capi import RAY_DTYPE
+    from nori_amd.render import Renderer
+    from tests.test_gpu_parity import ITS_FIELDS
+    sc = workloads.load("c5-terrain-10m", spp=1).scene
+    host = Renderer(0).upload(sc, builder=0)
+    dev = Renderer(0).upload(sc, builder=2)
+    ih, idv = host.accel_info(), dev.accel_info()
+    assert idv["n_triangles"] == ih["n_triangles"] == 9_999_394 and idv["node_children"] == ih["node_children"] == 4
+    assert (idv["n_nodes"], idv["sah_cost"]) != (ih["n_nodes"], ih["sah_cost"])      # two builders, two trees
+    assert idv["build_ms"] < 0.25 * ih["build_ms"], (idv["build_ms"], ih["build_ms"])
+    n = 3200                                              # 10.2 M vertical rays over the 2236 x 2236 cells: ~2 per triangle
+    xs = (np.arange(n, dtype=np.float32) + 0.5) / n * 2.0 - 1.0
+    X, Z = np.meshgrid(xs, xs, indexing="xy")
+    rays = np.zeros(n * n, dtype=RAY_DTYPE)
+    rays["o"] = np.stack([X.ravel(), np.full(n * n, 1.4, np.float32), Z.ravel()], axis=1)
+    rays["d"] = np.array([0.0, -1.0, 0.0], np.float32)
+    rays["mint"], rays["maxt"] = 1e-4, np.inf
+    rng = np.random.default_rng(7)
+    slanted = np.zeros(1 << 20, dtype=RAY_DTYPE)
+    slanted["o"] = np.stack([rng.uniform(-1, 1, 1 << 20), rng.uniform(0.3, 1.0, 1 << 20), rng.uniform(-1, 1, 1 << 20)], axis=1).astype(np.float32)
+    d = np.stack([rng.normal(size=1 << 20), -np.abs(rng.normal(size=1 << 20)) * 0.2, rng.normal(size=1 << 20)], axis=1)
+    slanted["d"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    slanted["mint"], slanted["maxt"] = 1e-4, np.inf
+    for batch in (rays, slanted):
+        a, b = host.intersect(batch), dev.intersect(batch)
+        assert (a["tri"] != 0xffffffff).mean() > 0.5
+        for k in ITS_FIELDS:
+            assert np.array_equal(a[k], b[k]), k
+        assert np.array_equal(host.intersect(batch, True)["mesh"], dev.intersect(batch, True)["mesh"])
+    hit = np.unique(host.intersect(rays)["tri"])
+    assert hit.size > 0.8 * idv["n_triangles"], hit.size          # the grid reaches (nearly) every triangle
+    for r in (host, dev):
+        r.set_option("engine", "wavefront")
+    A, sa = host.render_host()
+    B, sb = dev.render_host()
+    for k in ("n_camera_samples", "n_closest_rays", "n_shadow_rays"):
+        assert sa[k] == sb[k], k
+    assert np.array_equal(A, B)
+    host.close(); dev.close()
+
+
 def test_shading_arithmetic_stays_inside_its_verified_domain_on_the_baseline_configs():
     """exact_rcp / exact_div / exact_sqrt (rt_types.h) carry no fallback: outside their verified domains IEEE's inf / 0 may come
     out as NaN, and a sample the reference would count with value 0 would be DROPPED (src/block.cpp:63-67).  The golden scenes

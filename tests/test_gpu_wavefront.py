@@ -203,6 +203,32 @@ def test_tail_of_a_batch_beside_the_next_batch_gives_the_same_frame(renderer_fac
     assert sr["n_closest_rays"] == sb["n_closest_rays"] and sr["n_shadow_rays"] == sb["n_shadow_rays"]
 
 
+def test_out_of_memory_for_the_path_state_means_smaller_batches(renderer_factory):
+    """The number of paths in flight is bounded by what hipMemGetInfo reports free -- a snapshot another context may have spent by the
+    time the pool is allocated.  The render call then halves its batches until the state fits (nori_hip.hip) instead of failing:
+    same frame as with the budget that fits from the start (same batches), and OUT_OF_MEMORY only when nothing fits."""
+    import torch
+    sc = scenes.cornell_box(1024, 1024, 48, "path_mis")          # 50 M paths x 236 B = 11.9 GB of state + sample store in one batch
+    wf = renderer_factory(sc)
+    wf.set_option("engine", "wavefront")
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(0, free - (7 << 30)), dtype=torch.uint8, device="cuda")      # leave 7 GB: a quarter of the frame per batch fits
+    try:
+        frame = torch.zeros(wf.frame_shape(), device="cuda")
+        st = _with_env({"NORI_HIP_WF_IGNORE_FREE": 1}, lambda: wf.render_into(frame))
+        assert st["n_camera_samples"] == 1024 * 1024 * 48
+        got = frame.cpu().numpy()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    wf2 = renderer_factory(sc)
+    wf2.set_option("engine", "wavefront")
+    wf2.set_option("wavefront_paths", 1 << 24)       # what the halving arrives at: 2^29 -> 2^24 (16.7 M paths = 4 GB)
+    ref, sr = wf2.render_host()
+    assert np.array_equal(got, ref)
+    assert sr["n_closest_rays"] == st["n_closest_rays"] and sr["n_shadow_rays"] == st["n_shadow_rays"]
+
+
 def test_wavefront_deep_tree_spills_the_stack(renderer_factory):
     """LBVH over a triangle soup is deeper than 16: with NORI_HIP_WF_STACK=16 wf_extend keeps 16 stack
     entries in LDS and the rest in its global spill columns; same frame and counts as the megakernel
@@ -598,6 +624,12 @@ def test_reference_order_over_torch_distributed_ranks():
         torch.cuda.synchronize()
         assert np.array_equal(frame.cpu().numpy().view(np.uint32), whole.view(np.uint32))
         assert len(ms) == 1
+        side = torch.cuda.Stream()          # a caller's non-blocking stream carries every step of the call
+        frame2 = torch.full(r.frame_shape(), 7.0, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        ndist.render_distributed_reference(r, frame2, sc.sample_count, dist.get_rank(), dist.get_world_size(), stream=side)
+        side.synchronize()
+        assert np.array_equal(frame2.cpu().numpy().view(np.uint32), whole.view(np.uint32))
         dist.destroy_process_group()
         print("REFERENCE-ORDER-RANKS-OK")
     """)
