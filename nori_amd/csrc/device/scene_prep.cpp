@@ -223,9 +223,212 @@ struct BuildNode {
 constexpr int kBins = 32;
 static uint32_t kLeafTarget = 4;      /* NORI_HIP_SAH_LEAF overrides (experiments) */
 constexpr float kCostNode = 1.0f;
+constexpr float kSbvhMargin = 0.99f;            /* a spatial split must beat the object split's SAH estimate by this factor: the estimate is greedy, and a split
+                                                   that wins by a fraction of a percent pays for its duplicated references with a worse tree below */
+constexpr float kSbvhBudgetDefault = 0.3f;      /* spatial splits: references beyond one per triangle, as a fraction of the triangle count (build_tree_spatial) */
 static float kCostTri = 1.0f;      /* relative cost of one triangle test; NORI_HIP_SAH_TRI_COST overrides (experiments) */
 
+/* ---- spatial splits (Stich, Friedrich, Dietrich: "Spatial Splits in Bounding Volume Hierarchies", HPG 2009)
+   A reference = a triangle and the box of the part of it a subtree is responsible for.  A spatial split cuts the references that
+   straddle its plane in two -- the triangle then hangs in two leaves.  That is safe for Accel::rayIntersect (src/accel.cpp:23-43):
+   a leaf step tests the WHOLE triangle (Mesh::rayIntersect, src/mesh.cpp:39-76, same operands, same t, u, v from either leaf), and
+   the tie rule of the scan -- equal t: the larger index wins -- replaces a hit by itself.  What a reference's box must hold: every
+   point of the triangle inside the cut, padded as the whole triangle's box is (tri_box_pad: the slab test and the triangle test
+   round differently). */
+struct Ref { Box box; uint32_t tri; };
+
+/* the part of polygon `in` (n vertices) on one side of the plane x[axis] = pos; returns the number of vertices in `out` */
+static int clip_poly(const double (*in)[3], int n, int axis, double pos, bool keep_above, double (*out)[3]) {
+    int m = 0;
+    for (int i = 0; i < n; ++i) {
+        const double *a = in[i], *b = in[(i + 1) % n];
+        const double da = keep_above ? a[axis] - pos : pos - a[axis], db = keep_above ? b[axis] - pos : pos - b[axis];
+        if (da >= 0.0) { for (int k = 0; k < 3; ++k) out[m][k] = a[k]; ++m; }
+        if ((da > 0.0 && db < 0.0) || (da < 0.0 && db > 0.0)) {
+            const double t = da / (da - db);
+            for (int k = 0; k < 3; ++k) out[m][k] = a[k] + t * (b[k] - a[k]);
+            out[m][axis] = pos;
+            ++m;
+        }
+    }
+    return m;
+}
+
+static float round_down(double v) { float f = (float) v; if ((double) f > v) f = std::nextafterf(f, -std::numeric_limits<float>::infinity()); return f; }
+static float round_up(double v) { float f = (float) v; if ((double) f < v) f = std::nextafterf(f, std::numeric_limits<float>::infinity()); return f; }
+
+/* box of (triangle within lo <= x[axis] <= hi), padded by `pad`, within `within`; false: nothing of the triangle lies there */
+static bool clip_tri_box(const double tri[3][3], int axis, double lo, double hi, float pad, const Box &within, Box &out) {
+    double a[8][3], b[8][3];
+    int n = clip_poly(tri, 3, axis, lo, true, a);
+    if (n > 0) n = clip_poly(a, n, axis, hi, false, b);
+    if (n <= 0) return false;
+    double mn[3] = {b[0][0], b[0][1], b[0][2]}, mx[3] = {b[0][0], b[0][1], b[0][2]};
+    for (int i = 1; i < n; ++i) for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], b[i][k]); mx[k] = std::max(mx[k], b[i][k]); }
+    for (int k = 0; k < 3; ++k) {
+        out.mn[k] = std::max(within.mn[k], round_down(mn[k]) - pad);
+        out.mx[k] = std::min(within.mx[k], round_up(mx[k]) + pad);
+        if (!(out.mn[k] <= out.mx[k])) return false;
+    }
+    return true;
+}
+
 } // namespace
+
+/* Top-down SAH with object AND spatial splits (single thread: the scenes it serves are small).  Fills `bn` (node 0 = the root)
+   and `prim` = the triangle of every leaf reference, leaf after leaf in depth-first order -- what the flattening below reads.
+   budget: references the tree may hold beyond one per triangle, as a fraction of the triangle count. */
+static void build_tree_spatial(const HostScene &sc, const std::vector<Box> &boxes, const std::vector<float> &padOf, uint32_t max_depth_limit,
+                               float budget, std::vector<BuildNode> &bn, std::vector<uint32_t> &prim, uint32_t &n_spatial) {
+    const uint32_t n = (uint32_t) boxes.size();
+    auto log2ceil = [](uint32_t v) { uint32_t r = 0; while ((1u << r) < v) ++r; return r; };
+    auto triangle = [&](uint32_t g, double t[3][3]) {
+        for (int k = 0; k < 3; ++k) { const f4 &p = sc.positions[sc.indices[3 * (size_t) g + k]]; t[k][0] = p.x; t[k][1] = p.y; t[k][2] = p.z; }
+    };
+    auto centre = [](const Box &b, int ax) { return 0.5f * (b.mn[ax] + b.mx[ax]); };
+    struct Task { uint32_t node; std::vector<Ref> refs; };
+    std::vector<Task> todo;
+    bn.clear(); prim.clear(); n_spatial = 0;
+    bn.emplace_back();
+    { Task t; t.node = 0; t.refs.resize(n); for (uint32_t g = 0; g < n; ++g) { t.refs[g].box = boxes[g]; t.refs[g].tri = g; } todo.push_back(std::move(t)); }
+    long long spare = (long long) (budget * (float) n);       /* references still to be handed out */
+    float rootArea = 0.0f;
+    const float margin = std::getenv("NORI_HIP_SBVH_MARGIN") ? (float) std::atof(std::getenv("NORI_HIP_SBVH_MARGIN")) : kSbvhMargin;
+    constexpr float kMinOverlap = 0.01f;                     /* ... and its extent along the object split's axis, relative to the node's */
+    constexpr float kAlpha = 1e-5f;                          /* overlap of the object split's children, relative to the root: below it no spatial split is tried */
+
+    while (!todo.empty()) {
+        Task task = std::move(todo.back()); todo.pop_back();
+        std::vector<Ref> &refs = task.refs;
+        const uint32_t count = (uint32_t) refs.size(), depth = bn[task.node].depth;
+        Box nb, cb; nb.reset(); cb.reset();
+        for (const Ref &r : refs) { nb.grow(r.box); const float c[3] = {centre(r.box, 0), centre(r.box, 1), centre(r.box, 2)}; cb.grow(c); }
+        bn[task.node].box = nb;
+        if (task.node == 0) rootArea = std::max(nb.area(), 1e-30f);
+        auto makeLeaf = [&] { bn[task.node].first = (uint32_t) prim.size(); bn[task.node].count = count; for (const Ref &r : refs) prim.push_back(r.tri); };
+        if (count <= 1) { makeLeaf(); continue; }
+        const uint32_t needBalanced = log2ceil((count + kLeafTarget - 1) / kLeafTarget) + 1;
+        const bool forceMedian = depth + needBalanced + 1 >= max_depth_limit;
+
+        /* object split: bins over the centres of the references' boxes */
+        float objCost = std::numeric_limits<float>::infinity(); int objAxis = -1, objBin = -1; Box objL, objR;
+        float scale[3] = {0, 0, 0};
+        if (!forceMedian)
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!(cb.mx[ax] > cb.mn[ax])) continue;
+                scale[ax] = kBins / (cb.mx[ax] - cb.mn[ax]);
+                Box bb[kBins]; uint32_t bc[kBins];
+                for (int b = 0; b < kBins; ++b) { bb[b].reset(); bc[b] = 0; }
+                for (const Ref &r : refs) {
+                    int b = (int) ((centre(r.box, ax) - cb.mn[ax]) * scale[ax]);
+                    b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+                    bb[b].grow(r.box); bc[b]++;
+                }
+                Box rb[kBins]; uint32_t rc[kBins]; Box acc; acc.reset(); uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); c += bc[b]; rb[b] = acc; rc[b] = c; }
+                Box la; la.reset(); uint32_t lc = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    la.grow(bb[b]); lc += bc[b];
+                    if (lc == 0 || rc[b + 1] == 0) continue;
+                    const float cost = la.area() * (float) lc + rb[b + 1].area() * (float) rc[b + 1];
+                    if (cost < objCost) { objCost = cost; objAxis = ax; objBin = b; objL = la; objR = rb[b + 1]; }
+                }
+            }
+
+        /* spatial split: bins over the node's box; a reference enters the bin its box starts in, leaves the bin it ends in, and
+           grows every bin it touches by the part of its triangle inside */
+        float spCost = std::numeric_limits<float>::infinity(); int spAxis = -1; float spPos = 0.0f; uint32_t spL = 0, spR = 0;
+        bool trySpatial = !forceMedian && spare > 0 && objAxis >= 0;
+        if (trySpatial) {
+            Box ov;
+            for (int k = 0; k < 3; ++k) { ov.mn[k] = std::max(objL.mn[k], objR.mn[k]); ov.mx[k] = std::min(objL.mx[k], objR.mx[k]); }
+            /* (the second test: boxes are padded, so the children of ANY object split overlap by a sliver whose faces have the area
+               of the node's cross-section -- Stich's surface-area criterion alone sends every node through the clipping below) */
+            trySpatial = ov.mn[0] <= ov.mx[0] && ov.mn[1] <= ov.mx[1] && ov.mn[2] <= ov.mx[2] && ov.area() / rootArea > kAlpha &&
+                         ov.mx[objAxis] - ov.mn[objAxis] > kMinOverlap * (nb.mx[objAxis] - nb.mn[objAxis]);
+        }
+        if (trySpatial)
+            for (int ax = 0; ax < 3; ++ax) {
+                const float lo = nb.mn[ax], ext = nb.mx[ax] - nb.mn[ax];
+                if (!(ext > 0.0f)) continue;
+                if (ax != objAxis) continue;      /* the axis the object split chose: on the pa5 table scene the trees of all three axes are no better
+                                                     (node / triangle tests per ray 11.01 / 5.60 against 11.01 / 5.58) and take twice as long to build */
+                const float inv = kBins / ext;
+                Box bb[kBins]; uint32_t enter[kBins], leave[kBins];
+                for (int b = 0; b < kBins; ++b) { bb[b].reset(); enter[b] = leave[b] = 0; }
+                auto binOf = [&](float v) { int b = (int) ((v - lo) * inv); return b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b); };
+                auto plane = [&](int b) { return lo + ext * ((float) b / (float) kBins); };      /* lower plane of bin b */
+                for (const Ref &r : refs) {
+                    const int b0 = binOf(r.box.mn[ax]), b1 = binOf(r.box.mx[ax]);
+                    enter[b0]++; leave[b1]++;
+                    if (b0 == b1) { bb[b0].grow(r.box); continue; }
+                    /* (the triangle clipped per bin, not its box cut per bin: 11.79 / 7.36 tests per ray with boxes) */
+                    double t[3][3]; triangle(r.tri, t);
+                    for (int b = b0; b <= b1; ++b) {
+                        Box part;
+                        const double plo = b == b0 ? -1e300 : (double) plane(b), phi = b == b1 ? 1e300 : (double) plane(b + 1);
+                        if (clip_tri_box(t, ax, plo, phi, padOf[r.tri], r.box, part)) bb[b].grow(part);
+                    }
+                }
+                Box rb[kBins]; uint32_t rc[kBins]; Box acc; acc.reset(); uint32_t c = 0;
+                for (int b = kBins - 1; b > 0; --b) { acc.grow(bb[b]); c += leave[b]; rb[b] = acc; rc[b] = c; }
+                Box la; la.reset(); uint32_t lc = 0;
+                for (int b = 0; b < kBins - 1; ++b) {
+                    la.grow(bb[b]); lc += enter[b];
+                    if (lc == 0 || rc[b + 1] == 0 || lc >= count || rc[b + 1] >= count) continue;      /* a split must shrink both sides */
+                    const float cost = la.area() * (float) lc + rb[b + 1].area() * (float) rc[b + 1];
+                    if (cost < spCost) { spCost = cost; spAxis = ax; spPos = plane(b + 1); spL = lc; spR = rc[b + 1]; }
+                }
+            }
+
+        const float area = nb.area();
+        const bool spatial = spAxis >= 0 && spCost < margin * objCost && (long long) (spL + spR) - (long long) count <= spare;
+        const float bestCost = spatial ? spCost : objCost;
+        const bool haveSplit = spatial || objAxis >= 0;
+        if (!forceMedian && haveSplit && count <= kLeafTarget && !(kCostNode * area + kCostTri * bestCost < kCostTri * area * (float) count)) { makeLeaf(); continue; }
+
+        std::vector<Ref> L, R;
+        if (spatial) {
+            L.reserve(spL); R.reserve(spR);
+            for (const Ref &r : refs) {
+                if (r.box.mx[spAxis] <= spPos) { L.push_back(r); continue; }
+                if (r.box.mn[spAxis] >= spPos) { R.push_back(r); continue; }
+                double t[3][3]; triangle(r.tri, t);
+                Ref a = r, b = r;
+                const bool inL = clip_tri_box(t, spAxis, -1e300, (double) spPos, padOf[r.tri], r.box, a.box);
+                const bool inR = clip_tri_box(t, spAxis, (double) spPos, 1e300, padOf[r.tri], r.box, b.box);
+                if (inL) L.push_back(a);
+                if (inR) R.push_back(b);
+                if (!inL && !inR) L.push_back(r);      /* (cannot happen: the triangle lies somewhere) */
+            }
+            if (L.empty() || R.empty() || L.size() >= count || R.size() >= count) { L.clear(); R.clear(); }      /* fall through to the object split */
+            else { spare -= (long long) (L.size() + R.size()) - (long long) count; ++n_spatial;
+                   if (std::getenv("NORI_HIP_SBVH_DEBUG")) fprintf(stderr, "[sbvh] depth %u count %u: axis %d pos %g, %zu + %zu refs, cost %g (object %g on axis %d), node area %g\n", depth, count, spAxis, spPos, L.size(), R.size(), spCost, objCost, objAxis, area); }
+        }
+        if (L.empty() && !forceMedian && objAxis >= 0) {
+            for (const Ref &r : refs) {
+                int b = (int) ((centre(r.box, objAxis) - cb.mn[objAxis]) * scale[objAxis]);
+                b = b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+                (b <= objBin ? L : R).push_back(r);
+            }
+            if (L.empty() || R.empty()) { L.clear(); R.clear(); }
+        }
+        if (L.empty()) {
+            if (count <= kLeafTarget) { makeLeaf(); continue; }
+            int axis = 0;
+            { const float e0 = cb.mx[0] - cb.mn[0], e1 = cb.mx[1] - cb.mn[1], e2 = cb.mx[2] - cb.mn[2]; axis = (e0 >= e1 && e0 >= e2) ? 0 : (e1 >= e2 ? 1 : 2); }
+            const size_t mid = count / 2;
+            std::nth_element(refs.begin(), refs.begin() + mid, refs.end(), [&](const Ref &a, const Ref &b) { return centre(a.box, axis) < centre(b.box, axis); });
+            L.assign(refs.begin(), refs.begin() + mid); R.assign(refs.begin() + mid, refs.end());
+        }
+        const int32_t l = (int32_t) bn.size(); bn.emplace_back();
+        const int32_t r = (int32_t) bn.size(); bn.emplace_back();
+        bn[task.node].left = l; bn[task.node].right = r;
+        bn[l].depth = bn[r].depth = depth + 1;
+        { Task t; t.node = (uint32_t) r; t.refs = std::move(R); todo.push_back(std::move(t)); }
+        { Task t; t.node = (uint32_t) l; t.refs = std::move(L); todo.push_back(std::move(t)); }      /* left first: leaves in depth-first order */
+    }
+}
 
 std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh &out, bool wide) {
     if (const char *e = std::getenv("NORI_HIP_SAH_TRI_COST")) kCostTri = std::max(0.1f, (float) std::atof(e));
@@ -245,7 +448,7 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
     std::vector<Box> boxes(n);
     std::vector<uint8_t> isUnbounded(n, 0);      /* numerically collinear triangles: rt_types.h, tri_box_pad */
     uint32_t nUnbounded = 0;
-    std::vector<float> cent(3 * (size_t) n);
+    std::vector<float> cent(3 * (size_t) n), padOf(n);
     Box sceneBox; sceneBox.reset();
     for (uint32_t t = 0; t < n; ++t) {
         Box b; b.reset();
@@ -262,7 +465,7 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
             const f3 p0 = xyz(sc.positions[id[0]]), p1 = xyz(sc.positions[id[1]]), p2 = xyz(sc.positions[id[2]]);
             bool unbounded;
             const float padT = tri_box_pad(p1 - p0, p2 - p0, pad, unbounded);      /* slivers: rt_types.h */
-            isUnbounded[t] = unbounded ? 1 : 0;
+            isUnbounded[t] = unbounded ? 1 : 0; padOf[t] = padT;
             nUnbounded += unbounded ? 1u : 0u;
             for (int k = 0; k < 3; ++k) {
                 if (unbounded) { boxes[t].mn[k] = -kBoxInf; boxes[t].mx[k] = kBoxInf; }
@@ -413,6 +616,16 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
 
     std::vector<BuildNode> bn;
     bn.reserve((size_t) n / 2 + 16);
+    /* spatial splits: scenes the single-threaded builder serves (below 2^18 triangles), none of whose triangles has an unbounded
+       box; NORI_HIP_SBVH = references the tree may hold beyond one per triangle, as a fraction of the triangle count (0: object
+       splits only) */
+    float sbvhBudget = kSbvhBudgetDefault;
+    if (const char *e = std::getenv("NORI_HIP_SBVH")) sbvhBudget = std::max(0.0f, (float) std::atof(e));
+    uint32_t nSpatial = 0;
+    if (sbvhBudget > 0.0f && nThreads <= 1 && nUnbounded == 0 && n > kLeafTarget) {
+        build_tree_spatial(sc, boxes, padOf, max_depth_limit, sbvhBudget, bn, prim, nSpatial);
+        if (timing) fprintf(stderr, "[sah] spatial splits: %u, references %zu for %u triangles\n", nSpatial, prim.size(), n);
+    } else {
     bn.emplace_back();
     bn[0].first = 0; bn[0].count = n; bn[0].depth = 0;
     if (nThreads <= 1) {
@@ -462,17 +675,20 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
         }
     }
 
+    }
     lap("tree");
+    const uint32_t nRefs = (uint32_t) prim.size();      /* = n unless spatial splits duplicated references */
+    if (nRefs >= (1u << 28)) return "too many triangle references (limit 2^28)";
     /* leaf triangle records: pairs, leaf by leaf in prim order (rt_types.h) */
     auto isLeaf = [&](int32_t b) { return bn[b].left < 0; };
     std::vector<uint32_t> firstPair(bn.size(), 0);
     {
         /* leaves in prim order: the leaf that starts at prim position p, if any */
-        std::vector<int32_t> leafAt(n, -1), leaves;
+        std::vector<int32_t> leafAt(nRefs, -1), leaves;
         for (size_t b = 0; b < bn.size(); ++b) if (isLeaf((int32_t) b)) leafAt[bn[b].first] = (int32_t) b;
         leaves.reserve(bn.size() / 2 + 1);
         uint32_t nPairs = wide ? 1u : 0u;        /* wide trees reserve pair 0 as the all-zero pair unused child slots point to */
-        for (uint32_t p = 0; p < n; ++p)
+        for (uint32_t p = 0; p < nRefs; ++p)
             if (leafAt[p] >= 0) { const int32_t b = leafAt[p]; leaves.push_back(b); firstPair[b] = nPairs; nPairs += (bn[b].count + 1) / 2; }
         out.tris.assign((size_t) std::max<uint32_t>(nPairs, 1) * kPairQuads, f4{0.0f, 0.0f, 0.0f, 0.0f});
         parallelFor(0, (uint32_t) leaves.size(), nThreads, [&](uint32_t lo, uint32_t hi, uint32_t) {

@@ -60,6 +60,63 @@ def test_duplicate_triangles_tie_rule():
     assert (a["tri"][a["mesh"] == 1] == 1).all()
 
 
+def _mixed_soup(seed, n_small=3000, n_big=60, coincident=True):
+    """Many small triangles and a few that span the scene (the inputs spatial splits are for), some of them twice."""
+    from nori_amd.scene import Mesh
+    v1, f1 = scenes.triangle_soup(n_small, seed, size=0.06)
+    v2, f2 = scenes.triangle_soup(n_big, seed + 1, extent=0.3, size=1.2)
+    sc = scenes.soup_scene(1)
+    sc.meshes = [Mesh(v1, f1, name="small"), Mesh(v2, f2, name="big")]
+    if coincident:
+        sc.meshes.append(Mesh(v2[:30], f2[:10], name="big again"))      # equal t on a duplicated triangle: the larger index wins
+    return sc
+
+
+@pytest.mark.parametrize("seed,margin,budget", [(21, 1.0, 1.0), (22, 0.99, 0.3), (23, 1.0, 4.0)])
+def test_spatial_splits_give_the_scans_answers(monkeypatch, seed, margin, budget):
+    """build_tree_spatial (scene_prep.cpp): a triangle cut by a spatial split hangs in several leaves.  A leaf step tests the whole
+    triangle whichever leaf it is reached through (src/mesh.cpp:39-76: same operands, same t, u, v), and the scan's tie rule (equal t:
+    the larger index wins, src/accel.cpp:30-40) replaces a hit by itself -- so every field of the record is the scan's, for closest
+    hits and shadow queries, on 64-B nodes and on the 32-B records, also with coincident triangles in different meshes."""
+    sc = _mixed_soup(seed)
+    rays = scenes.random_rays(20000, seed=seed + 10)
+    o = Oracle(sc)
+    monkeypatch.setenv("NORI_HIP_SBVH", "0")
+    plain = Emu(sc).accel_info()
+    monkeypatch.setenv("NORI_HIP_SBVH", str(budget)); monkeypatch.setenv("NORI_HIP_SBVH_MARGIN", str(margin))
+    e = Emu(sc)
+    info = e.accel_info()
+    assert info["n_leaves"] > plain["n_leaves"] and info["total_bytes"] > plain["total_bytes"]      # references were duplicated
+    assert info["sah_cost"] < plain["sah_cost"]
+    a = o.intersect(rays)
+    _assert_its_equal(a, e.intersect(rays))
+    assert (a["mesh"] == 2).any() and not (a["mesh"] == 1)[np.isin(a["tri"], np.arange(10))].any()       # the second copy wins its ties
+    assert np.array_equal(o.intersect(rays, True)["mesh"], e.intersect(rays, True)["mesh"])
+    monkeypatch.setenv("NORI_EMU_NODEQ", "0")       # ... and on the 64-B nodes
+    _assert_its_equal(a, Emu(sc).intersect(rays))
+
+
+def test_spatial_splits_on_wide_nodes_and_in_renders(monkeypatch):
+    """The same tree collapsed into wide (BVH4) nodes, and whole renders: the frame and the ray counts of the tree without spatial
+    splits (the hits are the scan's either way, so every path is the same path)."""
+    monkeypatch.setenv("NORI_HIP_SBVH", "1.0"); monkeypatch.setenv("NORI_HIP_SBVH_MARGIN", "1.0")
+    sc = _mixed_soup(31, 2000, 40)
+    rays = scenes.random_rays(8000, seed=41)
+    e = _with_layout("bvh4q", lambda: Emu(sc))
+    assert e.accel_info()["node_children"] == 4
+    _assert_its_equal(Oracle(sc).intersect(rays), e.intersect(rays))
+    from tests.scenes import cornell_box
+    from nori_amd.scene import Mesh
+    cb = cornell_box(24, 24, 2, "path_mis")
+    v, f = scenes.triangle_soup(12, 5, extent=0.3, size=0.9)
+    cb.meshes.append(Mesh((v * 0.4 + np.float32([0, 1.0, 0])).astype(np.float32), f, bsdf=Bsdf("diffuse", (0.4, 0.5, 0.6)), name="shards"))
+    with_splits, sa = Emu(cb).render_host()
+    monkeypatch.setenv("NORI_HIP_SBVH", "0")
+    without, sb = Emu(cb).render_host()
+    assert np.array_equal(with_splits, without)
+    assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
+
+
 def test_empty_scene():
     from nori_amd.scene import Scene
     sc = scenes.soup_scene(1)

@@ -75,7 +75,8 @@ def test_device_builder_at_ten_million_triangles_gives_the_host_trees_hits():
     rng = np.random.default_rng(7)
     slanted = np.zeros(1 << 20, dtype=RAY_DTYPE)
     slanted["o"] = np.stack([rng.uniform(-1, 1, 1 << 20), rng.uniform(0.3, 1.0, 1 << 20), rng.uniform(-1, 1, 1 << 20)], axis=1).astype(np.float32)
-    d = np.stack([rng.normal(size=1 << 20), -np.abs(rng.normal(size=1 << 20)) * 0.2, rng.normal(size=1 << 20)], axis=1)
+    target = np.stack([rng.uniform(-1, 1, 1 << 20), np.zeros(1 << 20), rng.uniform(-1, 1, 1 << 20)], axis=1)
+    d = target - slanted["o"].astype(np.float64)
     slanted["d"] = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     slanted["mint"], slanted["maxt"] = 1e-4, np.inf
     for batch in (rays, slanted):

@@ -300,6 +300,42 @@ def test_error_behaviour():
     r.close()
 
 
+@pytest.mark.parametrize("seed,margin,budget,layout", [(21, 1.0, 1.0, "bvh2"), (22, 0.99, 0.3, "bvh2"), (23, 1.0, 4.0, "bvh4q")])
+def test_spatial_splits_give_the_scans_answers(monkeypatch, seed, margin, budget, layout):
+    """Spatial splits in the host builder (scene_prep.cpp, build_tree_spatial): triangles hang in several leaves.  Every field of
+    the intersection record is the linear scan's (src/accel.cpp:23-99) -- a leaf step tests the whole triangle whichever leaf it is
+    reached through, and the tie rule replaces a hit by itself -- through the batch kernels and, in a render, through the
+    hand-written node loop on the 32-B records or the wide-node walk: the frame and ray counts of the tree without spatial splits."""
+    from nori_amd.render import Renderer
+    from tests.test_device_logic_cpu import _mixed_soup
+    sc = _mixed_soup(seed)
+    rays = scenes.random_rays(50000, seed=seed + 10)
+    o = Oracle(sc)
+
+    def make(scene, sbvh):
+        monkeypatch.setenv("NORI_HIP_SBVH", str(sbvh)); monkeypatch.setenv("NORI_HIP_SBVH_MARGIN", str(margin))
+        r = Renderer(0); r.set_option("accel_layout", layout); r.upload(scene)
+        return r
+    plain, r = make(sc, 0), make(sc, budget)
+    info, pinfo = r.accel_info(), plain.accel_info()
+    assert info["node_children"] == (4 if layout == "bvh4q" else 2)
+    assert info["total_bytes"] > pinfo["total_bytes"] and info["sah_cost"] < pinfo["sah_cost"]
+    a, b = o.intersect(rays), r.intersect(rays)
+    for k in ITS_FIELDS:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(o.intersect(rays, True)["mesh"], r.intersect(rays, True)["mesh"])
+    plain.close(); r.close()
+    sc.integrator.type = "ao"; sc.sample_count = 4; sc.camera.width, sc.camera.height = 96, 64
+    p2, r2 = make(sc, 0), make(sc, budget)
+    for eng in (("wavefront",) if layout == "bvh4q" else ("megakernel", "wavefront")):
+        p2.set_option("engine", eng); r2.set_option("engine", eng)
+        A, sa = p2.render_host()
+        B, sb = r2.render_host()
+        assert np.array_equal(A, B), eng
+        assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
+    p2.close(); r2.close()
+
+
 @pytest.mark.parametrize("builder", [1, 3])
 @pytest.mark.parametrize("n_tris,seed", [(1, 3), (3, 4), (5, 5), (6, 2), (300, 6), (20000, 7)])
 def test_gpu_lbvh_builder_same_hits_as_brute_force(renderer_factory, n_tris, seed, builder):
