@@ -285,12 +285,23 @@ def main():
         valu_ach = ops / (t_ms * 1e-3) / 1e12                                   # Tops/s of algorithmic vector operations
         fr_hbm, fr_valu = hbm_alg / HBM_PEAK_GBS, valu_ach / VALU_PEAK_TOPS
         cd = ctr[1].get("dominant_kernel", {}) if ctr else {}
-        traffic = ctr[1].get("dominant_kernel_hbm_bytes") if ctr else None
+        # HBM bytes of the dominant kernel from the counters.  FETCH_SIZE counts a wide stream at half its bytes (the guide's doubling)
+        # but record gathers 1 : 1 (tools/ubench_fetch.hip, profiles/r5_03_fetch_write_size_calibration.txt): the traversal kernels'
+        # reads are gathers of node / leaf records plus the path state they stream -- known bytes, which the counter saw once
+        # instead of twice.  `traffic_streaming_rule` = every read priced as a stream (rounds 1 - 4 reported that one).
+        traffic_stream_rule = ctr[1].get("dominant_kernel_hbm_bytes") if ctr else None
+        traffic = ctr[1].get("dominant_kernel_hbm_bytes_gather_rule") if ctr else None
+        if traffic is not None:
+            streamed_reads = rec_bytes - counted["n_closest_rays"] * 16 if engine == "wavefront" else 0      # (the 16-B hit records are stores)
+            traffic = int(traffic + max(0, streamed_reads) // 2)
+        else:
+            traffic = traffic_stream_rule
         fr_hbm_measured = traffic / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
         # which roof binds: the counters of this build if they are committed (share of SIMD time issuing VALU vs share of the
         # HBM peak actually moved), else the structural rule: a cache-resident tree cannot be HBM bound
         if cd.get("valu_busy_frac") is not None and fr_hbm_measured is not None:
             bound = "valu" if cd["valu_busy_frac"] >= fr_hbm_measured else "hbm"
+            near_both = abs(cd["valu_busy_frac"] - fr_hbm_measured) < 0.2      # the kernel sits against both roofs: say so (roof["bound_detail"])
         else:
             bound = "valu" if (cache_resident or fr_hbm > 1.0) else "hbm"
         roof = {"kernel": dom_name, "kernel_ms": round(t_ms, 3), "launches": int(trace_launches), "bound": bound,
@@ -323,6 +334,10 @@ def main():
         roof["issued_valu_instr"] = int(issued)
         roof["issued_frac"] = round(issued / (t_ms * 1e-3) / VALU_ISSUE_SLOTS, 5)
         roof["traffic"] = traffic
+        if traffic_stream_rule is not None and traffic_stream_rule != traffic:
+            roof["traffic_streaming_rule"] = traffic_stream_rule
+        if cd.get("valu_busy_frac") is not None and fr_hbm_measured is not None:
+            roof["bound_detail"] = "valu+hbm" if near_both else bound
         if ctr:
             roof["traffic_source"] = os.path.relpath(ctr[0], ROOT)
             if fr_hbm_measured is not None:

@@ -410,7 +410,8 @@ struct nori_hip_ctx {
     int engine = -1;                /* -1 auto, 0 megakernel, 1 wavefront */
     int accel_layout = -1;          /* -1 auto (wide from 2^20 triangles), 0 bvh2, 1 bvh4q (wide nodes) */
     bool film_reference = false;    /* film_order = reference: samples added in the reference's own order (film.h) */
-    /* 216 B of state each (two copies of the 100-B record + the hit record) + 20 B of film: 2^29 paths = 127 GB of the 288 GB.
+    /* 216 B of state each (two copies of the 100-B record + the hit record) + 20 B of film, twice when a call has several batches (the
+       sample store's two halves, wavefront.hip "tail overlap"): 2^29 paths = 137 GB of the 288 GB.
        A batch ends with a tail that lasts as long as its longest path (wf_finish: ~19 ms on the pa5 table scene), so fewer,
        bigger batches are cheaper: the table scene at 2048^2 x 1024 spp is 8 batches instead of the 16 of 2^28 */
     size_t wavefront_paths = (size_t) 1 << 29;

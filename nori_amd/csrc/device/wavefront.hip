@@ -19,6 +19,8 @@
  *                (Integrator::Li state machine), write the surviving path with its
  *                next rays COMPACTED into the second state copy (ping-pong), so
  *                every pass streams dense arrays however many paths have died
+ *   wf_finish  once a batch has few live paths left a small persistent grid walks them to their ends (a lane pulls path after
+ *              path); in a call of several batches it does so on its own CUs BESIDE the next batch (wavefront_render, "tail overlap")
  *   film_gather / film_resolve (film.hip)  the finished samples sit tile-major in the
  *                film's store; the reconstruction filter and the block merge
  *                (ImageBlock::put, src/block.cpp:62-102) run as gathers

@@ -10,7 +10,14 @@ coalesced stream on gfx950 -> doubled; counters are summed over the chip):
                        profiles/*_valu_mix.json; 3.3 when no mix is on file).  <= 1 for any kernel that really runs.
   valu_lanes_per_instr SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU                  active lanes per VALU instruction (of 64)
   valu_useful_frac     valu_busy_frac x lanes / 64                                  share of VALU lane-cycles doing work
-  hbm_bytes            (2 x FETCH_SIZE + WRITE_SIZE) x 1024
+  hbm_bytes            (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- the guide's rule, calibrated on wide coalesced streams (film_gather).
+                       It does NOT hold for gathers: tools/ubench_fetch.hip (profiles/r5_03_fetch_write_size_calibration.txt) reads known
+                       byte counts through each access pattern -- a stream reads 2.00 bytes per counted byte, random 64-B and 96-B records
+                       (the wide node, the leaf pair) 0.99 and 1.00, random 32-B records 0.30 (a 128-B line per record); WRITE_SIZE counts
+                       streamed stores 1 : 1 and scattered 16-B nontemporal stores at 2 : 1 (a 32-B sector each -- bus traffic all the same).
+  hbm_bytes_gather_rule  (1 x FETCH_SIZE + WRITE_SIZE) x 1024 -- what the kernel moved if ALL its reads were record gathers.  The traversal
+                       kernels (wf_extend, wf_finish, render_kernel) lie between the two; bench.py places them with the bytes of path
+                       state they are known to stream (`traffic` = gather rule + half the streamed reads, which FETCH_SIZE counted once).
   l2_hit_rate          TCC_HIT / (TCC_HIT + TCC_MISS)
 """
 import collections, csv, glob, hashlib, json, os, re, sys
@@ -74,6 +81,7 @@ def derive(c, kernel=None):
         out["valu_useful_frac"] = round(out["valu_busy_frac"] * out["valu_lanes_per_instr"] / 64.0, 4)
     if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
         out["hbm_bytes"] = int((2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024)
+        out["hbm_bytes_gather_rule"] = int((c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024)
     if c.get("TCC_HIT_sum", 0) + c.get("TCC_MISS_sum", 0) > 0:
         out["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 4)
     if c.get("SQ_WAVE_CYCLES"):
@@ -96,7 +104,7 @@ dd = derive(dom, next((k for k in sorted(acc, key=lambda k: -acc[k].get("SQ_INST
 out = {"tag": tag, "workload": workload, "engine": engine, "device_source_sha": source_sha(),
        "collected_with": "tools/profile_round.sh: one rocprofv3 --kernel-trace --pmc run per counter group, one render pass each (tools/wf_probe.py, REPS=1)",
        "kernels": kernels, "dominant_kernel": dict(dd, name=dom_prefix + " (all launches of the pass)"),
-       "dominant_kernel_hbm_bytes": dd.get("hbm_bytes"),
+       "dominant_kernel_hbm_bytes": dd.get("hbm_bytes"), "dominant_kernel_hbm_bytes_gather_rule": dd.get("hbm_bytes_gather_rule"),
        "pass_hbm_bytes": int(sum(v["derived"].get("hbm_bytes", 0) for v in kernels.values())) or None}
 path = os.path.join(d, f"{tag}_counters.json")
 json.dump(out, open(path, "w"), indent=1)
