@@ -336,6 +336,37 @@ def test_spatial_splits_give_the_scans_answers(monkeypatch, seed, margin, budget
     p2.close(); r2.close()
 
 
+def test_tree_optimised_by_reinsertion_gives_the_scans_answers(monkeypatch):
+    """optimize_tree_reinsertion in the host builder (scene_prep.cpp; kept when the SAH cost drops by 2 %): the records of the scan,
+    field by field, and a render with the bits and ray counts of the top-down builder's tree -- fewer node tests for the same rays."""
+    from nori_amd.render import Renderer
+    from tests.test_device_logic_cpu import _objects_on_planes
+    sc = _objects_on_planes()
+    rays = scenes.random_rays(50000, seed=61, extent=1.5, target_extent=0.3)
+    o = Oracle(sc)
+
+    def make(scene, passes):
+        monkeypatch.setenv("NORI_HIP_REINSERT", str(passes))
+        return Renderer(0).upload(scene)
+    plain, r = make(sc, 0), make(sc, 10)
+    assert r.accel_info()["sah_cost"] < 0.95 * plain.accel_info()["sah_cost"]
+    a, b = o.intersect(rays), r.intersect(rays)
+    for k in ITS_FIELDS:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(o.intersect(rays, True)["mesh"], r.intersect(rays, True)["mesh"])
+    plain.close(); r.close()
+    sc.integrator.type = "ao"; sc.sample_count = 4; sc.camera.width, sc.camera.height = 96, 64
+    p2, r2 = make(sc, 0), make(sc, 10)
+    for eng in ("megakernel", "wavefront"):
+        p2.set_option("engine", eng); r2.set_option("engine", eng)
+        A, sa = p2.render_host(count_traversal=True)
+        B, sb = r2.render_host(count_traversal=True)
+        assert np.array_equal(A, B), eng
+        assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
+        assert sb["n_node_tests"] < sa["n_node_tests"]
+    p2.close(); r2.close()
+
+
 @pytest.mark.parametrize("builder", [1, 3])
 @pytest.mark.parametrize("n_tris,seed", [(1, 3), (3, 4), (5, 5), (6, 2), (300, 6), (20000, 7)])
 def test_gpu_lbvh_builder_same_hits_as_brute_force(renderer_factory, n_tris, seed, builder):
