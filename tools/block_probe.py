@@ -1,6 +1,8 @@
 """wf_extend in workgroups of 512 threads at 6 waves per SIMD with the ray's plane coefficients kept in registers (NORI_HIP_WF_EXTEND_BLOCK=512)
 against the shipped 1024-thread workgroups at 8 waves per SIMD; one process, alternating, frames compared bit for bit.
-    WORKLOAD=pa4-cbox-path_mis python tools/block_probe.py"""
+    WORKLOAD=pa4-cbox-path_mis python tools/block_probe.py
+(The variant -- wf_extend<..., BLOCK = 512> with the coefficients made at the refill -- measured slower and is not in the tree: it is the
+working copy of the commit before "wf_extend at 6 waves per SIMD ... removed"; profiles/r5_16_*.)"""
 import os, sys
 sys.path.insert(0, ".")
 import torch
