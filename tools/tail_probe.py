@@ -25,7 +25,7 @@ def run(label, **env):
     print(f"{wl} {label:38s}: frame {best['kernel_ms']:8.2f} ms | trace {best['trace_ms']:8.2f} shade+tail {best['shade_ms']:8.2f} tail beside {best['tail_ms']:7.2f} film {best['film_ms']:6.2f} | {rays / best['kernel_ms'] / 1e3:8.1f} Mrays/s | {same} rays {rays}", flush=True)
 run.ref = None
 run("tails on the bulk's stream", TAIL_CUS=0)
-for cus in (32, 16, 64, 8, 32):
-    run(f"tails beside the next batch, {cus} CUs", TAIL_CUS=cus)
-    run(f"same, first chunks static", TAIL_CUS=cus, STATIC_FIRST=1)
+for fp in (524288, 1048576, 2097152, 4194304, 262144):
+    for cus in (32, 64):
+        run(f"beside, {cus} CUs, finish from {fp} paths", TAIL_CUS=cus, FINISH_PATHS=fp)
 run("tails on the bulk's stream", TAIL_CUS=0)
