@@ -117,6 +117,66 @@ def test_spatial_splits_on_wide_nodes_and_in_renders(monkeypatch):
     assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
 
 
+def _check_bvh2_invariants(e, n_refs_min):
+    """A flattened BVH2 tree (64-B nodes, rt_types.h): every inner node is reached exactly once from the root, a child's box lies
+    inside its parent's (centre / half-extent: [c - h, c + h]), every leaf link covers its own range of pair records and the ranges
+    tile [0, n_pairs) without overlap.  Returns the number of leaves."""
+    n64 = e.node_records()[0]
+    n = n64.shape[0]
+    links = n64[:, 12:14].copy().view(np.uint32).astype(np.int64)
+    links[links >= 2 ** 31] -= 2 ** 32
+    # q0 = (lc.x, lc.y, rc.x, rc.y), q1 = (lc.z, rc.z, lh.z, rh.z), q2 = (lh.x, lh.y, rh.x, rh.y)
+    c = np.stack([np.stack([n64[:, 0], n64[:, 1], n64[:, 4]], 1), np.stack([n64[:, 2], n64[:, 3], n64[:, 5]], 1)], 1).astype(np.float64)
+    h = np.stack([np.stack([n64[:, 8], n64[:, 9], n64[:, 6]], 1), np.stack([n64[:, 10], n64[:, 11], n64[:, 7]], 1)], 1).astype(np.float64)
+    lo, hi = c - h, c + h
+    seen = np.zeros(n, np.int32); ranges = []
+    stack = [(0, None, None)]
+    while stack:
+        i, plo, phi = stack.pop()
+        seen[i] += 1
+        for k in (0, 1):
+            if plo is not None:                                 # this node's two boxes lie inside the box its parent holds for it
+                assert (lo[i, k] >= plo - 1e-6 * (1 + np.abs(plo))).all() and (hi[i, k] <= phi + 1e-6 * (1 + np.abs(phi))).all(), i
+            link = int(links[i, k])
+            if link >= 0:
+                stack.append((link, lo[i, k], hi[i, k]))
+            else:
+                code = ~link
+                ranges.append((code >> 3, (code & 7) + 1))
+    assert (seen == 1).all(), "an inner node is unreachable or reached twice"
+    ranges.sort()
+    pos = ranges[0][0]
+    assert pos in (0, 1)
+    for first, cnt in ranges:
+        assert first == pos, "leaf ranges overlap or leave a gap"
+        pos += cnt
+    assert 2 * (pos - ranges[0][0]) >= n_refs_min
+    return len(ranges)
+
+
+def test_tree_invariants_after_spatial_splits_and_reinsertion(monkeypatch):
+    """The structure itself, not only what rays see of it: inner nodes reachable exactly once, children inside their parents' boxes,
+    leaf ranges tiling the pair records -- for the top-down tree, with spatial splits forced, and after re-insertion."""
+    from nori_amd.scene import Scene
+    table = Scene.load_npz(os.path.join(os.path.dirname(__file__), "golden", "pa5-table_mis.npz"))
+    table.camera.width = table.camera.height = 16; table.sample_count = 1
+    for sc, n_tris in ((_objects_on_planes(), 5006), (_mixed_soup(23, coincident=False), 3060), (table, 22766)):
+        counts = {}
+        for name, env in (("plain", {"NORI_HIP_SBVH": "0", "NORI_HIP_REINSERT": "0"}), ("splits", {"NORI_HIP_SBVH": "1.0", "NORI_HIP_SBVH_MARGIN": "1.0", "NORI_HIP_REINSERT": "0"}),
+                          ("default", {})):
+            for k in ("NORI_HIP_SBVH", "NORI_HIP_SBVH_MARGIN", "NORI_HIP_REINSERT"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            e = Emu(sc)
+            info = e.accel_info()
+            leaves = _check_bvh2_invariants(e, n_tris)
+            assert leaves == info["n_leaves"] == info["n_nodes"] + 1
+            counts[name] = info
+        assert counts["splits"]["n_leaves"] > counts["plain"]["n_leaves"]
+        assert counts["default"]["sah_cost"] <= counts["plain"]["sah_cost"]
+
+
 def _objects_on_planes():
     """Small objects between planes many times their size -- the pa5 table scene's proportions."""
     from nori_amd.scene import Mesh
