@@ -305,7 +305,13 @@ int nori_hip_debug_excursions(nori_hip_ctx *ctx, unsigned long long out[4], int 
 /* Tuning / engine selection (no reference counterpart).  Keys:
  *   "engine"          "auto" (default: wavefront for >= 2^19 camera samples per call -- 2^24 for the `normals`
  *                     integrator --, else megakernel) | "megakernel" | "wavefront"
- *   "wavefront_paths" paths in flight per wavefront batch (default 2^29, 236 B of HBM each; bounded by 85 % of the free memory)
+ *   "wavefront_paths" paths in flight in the wavefront engine: records of its state pool (default 2^29, 216 B of HBM each;
+ *                     bounded by 85 % of the free memory)
+ *   "wavefront_samples" camera samples per batch: what the film's sample store holds at a time, 20 B each (twice when a call
+ *                     has several batches).  "0" (default): as many as wavefront_paths -- a batch starts all its samples in its
+ *                     first pass, the fastest schedule.  A batch bigger than the pool starts its samples pass by pass in the
+ *                     slots finished paths leave (regeneration): same frame, bit for bit, ~15 % slower traversal; it is what
+ *                     lets an out-of-memory retry shrink the pool and keep the frame, and film_order = reference run on any pool
  *   "accel_layout"    node layout of the NEXT nori_hip_build_accel: "bvh2" (64-B node = two full-precision child
  *                     boxes; the wavefront engine walks a second, 32-B form of them, see nori_accel_info) | "bvh4q"
  *                     (64-B node = four child boxes quantised to 8 bits: half the node fetches, for trees that do
@@ -317,7 +323,7 @@ int nori_hip_debug_excursions(nori_hip_ctx *ctx, unsigned long long out[4], int 
  *                     render of the same samples by the reference's loops)
  * Unknown keys return NORI_ERR_INVALID_ARGUMENT. */
 int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value);
-/* The current value of an option as set_option would take it ("engine", "wavefront_paths", "film_order", "accel_layout"),
+/* The current value of an option as set_option would take it ("engine", "wavefront_paths", "wavefront_samples", "film_order", "accel_layout"),
  * NUL-terminated into value[capacity]; NORI_ERR_INVALID_ARGUMENT for unknown keys or a buffer too small. */
 int nori_hip_get_option(const nori_hip_ctx *ctx, const char *key, char *value, size_t capacity);
 

@@ -30,30 +30,27 @@
 
 #include "../../../include/nori_hip.h"
 #include "group_merge.h"
+#include "rccl_abi.h"
 
 using namespace nrt;
+/* The handful of RCCL types and entry points the group uses are declared by hand in rccl_abi.h (the library itself is dlopen'ed at
+   the first group of more than one device: a one-GPU build needs neither the RCCL headers nor the library) and held against the
+   installed <rccl/rccl.h> at build-test time (tests/abi/rccl_abi_check.cpp); the version is checked at load time. */
+using nori_rccl::ncclComm_t; using nori_rccl::ncclResult_t; using nori_rccl::ncclSuccess; using nori_rccl::ncclFloat; using nori_rccl::ncclSum;
 
 namespace {
 
-/* The handful of RCCL types and entry points the group uses, declared here (the library itself is dlopen'ed at the first
-   group of more than one device): a one-GPU build needs neither the RCCL headers nor the library.  Values as in rccl.h /
-   nccl.h 2.x (ncclSuccess = 0, ncclFloat32 = 7, ncclSum = 0) -- checked at load time against ncclGetVersion. */
-typedef struct ncclComm *ncclComm_t;
-typedef int ncclResult_t;
-constexpr ncclResult_t ncclSuccess = 0;
-constexpr int ncclFloat = 7, ncclSum = 0;
-
 struct Rccl {
     void *lib = nullptr;
-    ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    const char *(*GetErrorString)(ncclResult_t) = nullptr;
-    ncclResult_t (*GetVersion)(int *) = nullptr;
-    ncclResult_t (*Reduce)(const void *, void *, size_t, int, int, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    ncclResult_t (*GroupStart)() = nullptr;
-    ncclResult_t (*GroupEnd)() = nullptr;
+    nori_rccl::CommInitAll_t CommInitAll = nullptr;
+    nori_rccl::CommDestroy_t CommDestroy = nullptr;
+    nori_rccl::GetErrorString_t GetErrorString = nullptr;
+    nori_rccl::GetVersion_t GetVersion = nullptr;
+    nori_rccl::Reduce_t Reduce = nullptr;
+    nori_rccl::Send_t Send = nullptr;
+    nori_rccl::Recv_t Recv = nullptr;
+    nori_rccl::GroupStart_t GroupStart = nullptr;
+    nori_rccl::GroupEnd_t GroupEnd = nullptr;
     std::string load() {
         if (lib) return std::string();
         std::string why;
@@ -69,7 +66,7 @@ struct Rccl {
         SYM(Reduce, "ncclReduce") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv") SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd")
 #undef SYM
         int version = 0;
-        if (GetVersion(&version) != ncclSuccess || version < 20000) { dlclose(lib); lib = nullptr; return "librccl: version " + std::to_string(version) + " (the enum values used here are those of 2.x)"; }
+        if (GetVersion(&version) != ncclSuccess || version < nori_rccl::kMinVersion) { dlclose(lib); lib = nullptr; return "librccl: version " + std::to_string(version) + " (the enum values used here are those of 2.x)"; }
         return std::string();
     }
 };
@@ -150,23 +147,62 @@ struct nori_hip_group {
 
 static std::string g_group_create_error;
 
-/* ncclReduce(sum) of kCheckFloats floats per rank, rank k contributing (k + 1) * (i % 251 + 1): exact in binary32 for <= 64
-   ranks, so rank 0 must read n (n + 1) / 2 * (i % 251 + 1) bit for bit.  Returns "" or what went wrong. */
-constexpr size_t kCheckFloats = 4096;
+/* The communicators proven before a frame depends on them, on a buffer the size of the biggest frame the bench merges (a 2052^2
+   RGBW frame, 67 MB -- a token-sized message takes other protocols and channels inside RCCL than a frame does):
+     1. ncclReduce(sum) to rank 0, rank k contributing (k + 1) * (i % 251 + 1): exact in binary32 for <= 64 ranks, so rank 0 must
+        read n (n + 1) / 2 * (i % 251 + 1) bit for bit;
+     2. the gather merge's exchange: in ONE group every other rank ncclSends its buffer to rank 0, which ncclRecvs each into its
+        own slot (a group of one rank sends to and receives from itself) and must find rank k's pattern in slot k.
+   Returns "" or what went wrong. */
+constexpr size_t kCheckFloats = (size_t) 2052 * 2052 * 4;
 __global__ void check_fill_kernel(float *p, size_t n, float scale) {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = scale * (float) (i % 251 + 1);
 }
+/* first element of p[0, n) that is not scale * (i % 251 + 1), or n */
+__global__ void check_verify_kernel(const float *p, size_t n, float scale, unsigned long long *first_bad) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && p[i] != scale * (float) (i % 251 + 1)) atomicMin(first_bad, (unsigned long long) i);
+}
 static std::string rccl_self_check(nori_hip_group *g) {
     const int n = (int) g->devices.size();
-    std::vector<float *> buf((size_t) n, nullptr);
+    const unsigned grid = (unsigned) ((kCheckFloats + 255) / 256);
+    std::vector<float *> buf((size_t) n, nullptr), slot((size_t) n, nullptr);      /* slot[k]: on device 0, what rank k sent */
+    unsigned long long *d_bad = nullptr;
     std::string err;
     auto hip_ok = [&](hipError_t e, const char *what) { if (e != hipSuccess && err.empty()) err = std::string(what) + ": " + hipGetErrorString(e); return e == hipSuccess; };
-    for (int k = 0; k < n && err.empty(); ++k) {
+    auto fill = [&]() {
+        for (int k = 0; k < n && err.empty(); ++k) {
+            if (!hip_ok(hipSetDevice(g->devices[(size_t) k]), "hipSetDevice")) break;
+            hipLaunchKernelGGL(check_fill_kernel, dim3(grid), dim3(256), 0, g->streams[(size_t) k], buf[(size_t) k], kCheckFloats, (float) (k + 1));
+            hip_ok(hipGetLastError(), "check_fill_kernel");
+        }
+    };
+    auto sync_all = [&]() { for (int k = 0; k < n && err.empty(); ++k) { hip_ok(hipSetDevice(g->devices[(size_t) k]), "hipSetDevice"); hip_ok(hipStreamSynchronize(g->streams[(size_t) k]), "hipStreamSynchronize"); } };
+    /* on device 0: p must hold scale * pattern */
+    auto verify = [&](const float *p, float scale, const char *what) {
+        if (!err.empty() || !hip_ok(hipSetDevice(g->devices[0]), "hipSetDevice")) return;
+        const unsigned long long none = ~0ull;
+        unsigned long long bad = none;
+        if (!hip_ok(hipMemcpyAsync(d_bad, &none, sizeof(none), hipMemcpyHostToDevice, g->streams[0]), "hipMemcpyAsync")) return;
+        hipLaunchKernelGGL(check_verify_kernel, dim3(grid), dim3(256), 0, g->streams[0], p, kCheckFloats, scale, d_bad);
+        if (!hip_ok(hipGetLastError(), "check_verify_kernel") || !hip_ok(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, g->streams[0]), "hipMemcpyAsync") ||
+            !hip_ok(hipStreamSynchronize(g->streams[0]), "hipStreamSynchronize")) return;
+        if (bad != none) {
+            float got = 0.0f;
+            (void) hipMemcpy(&got, p + bad, sizeof(float), hipMemcpyDeviceToHost);
+            err = std::string(what) + ": rank 0 holds " + std::to_string(got) + " at element " + std::to_string(bad) + " of " + std::to_string(kCheckFloats) +
+                  ", expected " + std::to_string(scale * (float) (bad % 251 + 1));
+        }
+    };
+    for (int k = 0; k < n && err.empty(); ++k)
         if (!hip_ok(hipSetDevice(g->devices[(size_t) k]), "hipSetDevice") || !hip_ok(hipMalloc((void **) &buf[(size_t) k], kCheckFloats * sizeof(float)), "hipMalloc")) break;
-        hipLaunchKernelGGL(check_fill_kernel, dim3((unsigned) (kCheckFloats / 256)), dim3(256), 0, g->streams[(size_t) k], buf[(size_t) k], kCheckFloats, (float) (k + 1));
-        hip_ok(hipGetLastError(), "check_fill_kernel");
+    if (err.empty() && hip_ok(hipSetDevice(g->devices[0]), "hipSetDevice")) {
+        hip_ok(hipMalloc((void **) &d_bad, sizeof(unsigned long long)), "hipMalloc");
+        for (int k = (n == 1 ? 0 : 1); k < n && err.empty(); ++k) hip_ok(hipMalloc((void **) &slot[(size_t) k], kCheckFloats * sizeof(float)), "hipMalloc");
     }
+    /* 1. reduce */
+    fill();
     if (err.empty()) {
         ncclResult_t r = g_rccl.GroupStart();
         for (int k = 0; k < n && r == ncclSuccess; ++k) r = g_rccl.Reduce(buf[(size_t) k], buf[(size_t) k], kCheckFloats, ncclFloat, ncclSum, 0, g->comms[(size_t) k], g->streams[(size_t) k]);
@@ -174,17 +210,27 @@ static std::string rccl_self_check(nori_hip_group *g) {
         if (r == ncclSuccess) r = e;
         if (r != ncclSuccess) err = std::string("ncclReduce: ") + g_rccl.GetErrorString(r);
     }
-    for (int k = 0; k < n && err.empty(); ++k) { hip_ok(hipSetDevice(g->devices[(size_t) k]), "hipSetDevice"); hip_ok(hipStreamSynchronize(g->streams[(size_t) k]), "hipStreamSynchronize"); }
+    sync_all();
+    verify(buf[0], (float) (n * (n + 1) / 2), "ncclReduce");
+    /* 2. send / receive, grouped as the gather merge groups them */
+    fill();
+    sync_all();
     if (err.empty()) {
-        std::vector<float> h(kCheckFloats);
-        if (hip_ok(hipSetDevice(g->devices[0]), "hipSetDevice") && hip_ok(hipMemcpy(h.data(), buf[0], kCheckFloats * sizeof(float), hipMemcpyDeviceToHost), "hipMemcpy")) {
-            const float total = (float) (n * (n + 1) / 2);
-            for (size_t i = 0; i < kCheckFloats; ++i)
-                if (h[i] != total * (float) (i % 251 + 1)) { err = "rank 0 holds " + std::to_string(h[i]) + " at element " + std::to_string(i) + ", expected " + std::to_string(total * (float) (i % 251 + 1)); break; }
+        ncclResult_t r = g_rccl.GroupStart();
+        for (int k = (n == 1 ? 0 : 1); k < n && r == ncclSuccess; ++k) {
+            r = g_rccl.Send(buf[(size_t) k], kCheckFloats, ncclFloat, 0, g->comms[(size_t) k], g->streams[(size_t) k]);
+            if (r == ncclSuccess) r = g_rccl.Recv(slot[(size_t) k], kCheckFloats, ncclFloat, k, g->comms[0], g->streams[0]);
         }
+        const ncclResult_t e = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) err = std::string("ncclSend / ncclRecv: ") + g_rccl.GetErrorString(r);
     }
+    sync_all();
+    for (int k = (n == 1 ? 0 : 1); k < n; ++k) verify(slot[(size_t) k], (float) (k + 1), "ncclSend / ncclRecv");
     for (int k = 0; k < n; ++k) if (buf[(size_t) k]) { (void) hipSetDevice(g->devices[(size_t) k]); (void) hipFree(buf[(size_t) k]); }
     (void) hipSetDevice(g->devices[0]);
+    for (float *p : slot) if (p) (void) hipFree(p);
+    if (d_bad) (void) hipFree(d_bad);
     return err;
 }
 

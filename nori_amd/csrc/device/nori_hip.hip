@@ -415,6 +415,13 @@ struct nori_hip_ctx {
        A batch ends with a tail that lasts as long as its longest path (wf_finish: ~19 ms on the pa5 table scene), so fewer,
        bigger batches are cheaper: the table scene at 2048^2 x 1024 spp is 8 batches instead of the 16 of 2^28 */
     size_t wavefront_paths = (size_t) 1 << 29;
+    /* camera samples per batch (0: as many as the pool holds paths -- every batch starts all its samples in its first pass, the
+       fastest schedule: profiles/r6_01_pool_sweep.txt): 20 B each in the film's sample store, twice when a call has several
+       batches.  A batch bigger than the pool starts its samples pass by pass in the slots finished paths leave (regeneration,
+       wavefront.hip): the pool bounds the STATE, this bounds the film store.  What it is for: a context short of memory keeps its
+       batches -- hence the bits of its frame -- on a smaller pool (the out-of-memory retry below), and film_order = reference,
+       which needs the frame in ONE batch, runs on any pool */
+    size_t wavefront_samples = 0;
     /* render-time resources of THIS context (never shared, freed in nori_hip_destroy): the wavefront
        engine's state pool / streams / events and the film's sample store + tile accumulators */
     WfEngine *wf = nullptr;
@@ -702,6 +709,12 @@ int nori_hip_set_option(nori_hip_ctx *ctx, const char *key, const char *value) {
         ctx->wavefront_paths = (size_t) n;
         return NORI_OK;
     }
+    if (k == "wavefront_samples") {
+        const long long n = atoll(value);
+        if (n != 0 && (n < 256 || n > (1ll << 31))) { ctx->error = "set_option: wavefront_samples must be 0 (as wavefront_paths) or in [256, 2^31]"; return NORI_ERR_INVALID_ARGUMENT; }
+        ctx->wavefront_samples = (size_t) n;
+        return NORI_OK;
+    }
     if (k == "film_order") {
         if (v == "fast") ctx->film_reference = false;
         else if (v == "reference") ctx->film_reference = true;
@@ -725,6 +738,7 @@ int nori_hip_get_option(const nori_hip_ctx *ctx, const char *key, char *value, s
     std::string v;
     if (k == "engine") v = ctx->engine == 0 ? "megakernel" : ctx->engine == 1 ? "wavefront" : "auto";
     else if (k == "wavefront_paths") v = std::to_string(ctx->wavefront_paths);
+    else if (k == "wavefront_samples") v = std::to_string(ctx->wavefront_samples);
     else if (k == "film_order") v = ctx->film_reference ? "reference" : "fast";
     else if (k == "accel_layout") v = ctx->accel_layout == 0 ? "bvh2" : ctx->accel_layout == 1 ? "bvh4q" : "auto";
     else return NORI_ERR_INVALID_ARGUMENT;
@@ -1110,20 +1124,41 @@ static int render_impl(nori_hip_ctx *ctx, const nori_render_params *params, void
         /* paths in flight: the option, bounded by what this GPU has free right now (state already held by
            this context counts as free) -- a second context or another process may own part of the HBM */
         wl.film_reference = ctx->film_reference; wl.film_share = share;
-        wl.max_paths = ctx->wavefront_paths;
+        /* what the call can use at all: a batch never holds more samples than the call has, the pool never more paths than a batch */
+        const size_t call_samples = (size_t) a.n_sel_tiles * 256 * a.spp_count;
+        /* (reference film order: the frame is one batch whatever the options say -- the pool need not hold it) */
+        const size_t opt_samples = ctx->film_reference ? call_samples : ctx->wavefront_samples ? ctx->wavefront_samples : ctx->wavefront_paths;
+        wl.max_samples = std::max<size_t>(256, std::min(opt_samples, call_samples));
+        wl.max_paths = std::max<size_t>(256, std::min(ctx->wavefront_paths, wl.max_samples));
+        const size_t per_path = wavefront_bytes_per_path(), per_sample = wavefront_bytes_per_sample();
         size_t free_b = 0, total_b = 0;
         if (!getenv("NORI_HIP_WF_IGNORE_FREE") /* test hook: as if the free figure were stale */ && hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const size_t usable = (size_t) ((double) (free_b + wavefront_held_bytes(ctx->wf, ctx->film)) * 0.85);
-            wl.max_paths = std::max<size_t>(256, std::min(wl.max_paths, usable / wavefront_bytes_per_path()));
+            if (wl.max_paths * per_path + wl.max_samples * per_sample > usable) {
+                /* reference film order: the batch is the frame, the pool takes what is left.  Else the pool keeps its size while the
+                   sample store can still hold four pools' worth of samples; else both shrink */
+                if (ctx->film_reference) wl.max_paths = std::max<size_t>(256, usable > wl.max_samples * per_sample ? (usable - wl.max_samples * per_sample) / per_path : 0);
+                else if (usable >= wl.max_paths * (per_path + 4 * per_sample)) wl.max_samples = (usable - wl.max_paths * per_path) / per_sample;
+                else { wl.max_paths = std::max<size_t>(256, usable / (per_path + 4 * per_sample)); wl.max_samples = std::min(wl.max_samples, 4 * wl.max_paths); }
+            }
         }
         std::string err = wavefront_render(*ctx->wf, ctx->film, ctx->dev, ctx->d_filter, wl, (float *) d_rgbw, s, wst);
         /* The free figure above is a snapshot: another context on this device -- a group with a duplicated device list rendering
-           in parallel threads, a second process -- may have claimed the same bytes in the meantime.  Smaller batches then: nothing
-           has been accumulated yet when the pool or the sample store cannot be allocated (they are allocated before the first
-           launch), so the call is simply made again with half the paths in flight. */
-        while (!err.empty() && err.find("out of memory") != std::string::npos && wl.max_paths > ((size_t) 1 << 20) && !ctx->film_reference) {
+           in parallel threads, a second process -- may have claimed the same bytes in the meantime.  Nothing has been accumulated
+           yet when the pool or the sample store cannot be allocated (they are allocated before the first launch), so the call is
+           simply made again with less: what this context holds is given back first (a pool that fitted while the sample store did
+           not must not survive the retry), then the bigger of the two is halved -- the POOL while it is, which leaves the batches,
+           hence the bits of the frame, as they were. */
+        while (!err.empty() && err.find("out of memory") != std::string::npos) {
             (void) hipGetLastError();
-            wl.max_paths /= 2;
+            wavefront_release_pool(ctx->wf);
+            film_release(ctx->film);
+            const bool pool_bigger = wl.max_paths * per_path >= wl.max_samples * per_sample || ctx->film_reference;
+            if (pool_bigger && wl.max_paths > ((size_t) 1 << 20)) wl.max_paths /= 2;
+            else if (ctx->film_reference) break;      /* (its one batch cannot shrink) */
+            else if (wl.max_samples > ((size_t) 1 << 20)) { wl.max_samples /= 2; wl.max_paths = std::min(wl.max_paths, wl.max_samples); }
+            else if (wl.max_paths > ((size_t) 1 << 20)) wl.max_paths /= 2;
+            else break;
             err = wavefront_render(*ctx->wf, ctx->film, ctx->dev, ctx->d_filter, wl, (float *) d_rgbw, s, wst);
         }
         if (!err.empty()) {

@@ -16,7 +16,9 @@ struct WfLaunch {
     int stack_depth;            /* traversal stack entries the tree needs: max_depth + 1 */
     bool count_traversal;
     bool time_kernels;          /* HIP events around every launch (ktimer.h) */
-    size_t max_paths;           /* paths in flight per batch */
+    size_t max_paths;           /* paths in flight: records of the state pool */
+    size_t max_samples;         /* camera samples per batch: what the film's sample store holds at a time (a batch bigger than max_paths
+                                   starts its samples pass by pass -- regeneration, wavefront.hip) */
     bool film_reference;        /* add the samples in the reference's order (film.h): needs the whole frame in ONE batch */
     const FilmBlockRows *film_share = nullptr;      /* reference order: the selected tiles are these block rows (tile_mod 1, tile_rem = their first tile) */
 };
@@ -36,8 +38,12 @@ struct WfStats {
 struct WfEngine;
 WfEngine *wavefront_create();
 void wavefront_destroy(WfEngine *);
-/* HBM bytes one path in flight costs (two state copies + hit record + its film sample): sizes max_paths */
+/* HBM bytes one path in flight costs (two state copies + hit record) and one camera sample of a batch costs in the film's
+   sample store (both halves of it): size max_paths and max_samples */
 size_t wavefront_bytes_per_path();
+size_t wavefront_bytes_per_sample();
+/* gives the engine's pool back to the device (an out-of-memory retry starts from nothing) */
+void wavefront_release_pool(WfEngine *engine);
 /* device bytes this context already holds for rendering (they are reusable, so they count as free) */
 size_t wavefront_held_bytes(const WfEngine *engine, const FilmStore &film);
 

@@ -36,6 +36,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 /* The laboratory -- perturbations of the node step and of wf_shade, the cycle profile of a wave -- lives in wf_experiments.h and is
@@ -69,7 +70,7 @@ namespace {
 constexpr int kB = 256;
 
 /* counters: path count and dynamic-chunk head per state copy (index + copy), overflow flag */
-enum { C_N = 0, C_HEAD = 2, C_OVERFLOW = 4, C_TAIL_HEAD = 5, C_COUNT = 8 };
+enum { C_N = 0, C_HEAD = 2, C_OVERFLOW = 4, C_TAIL_HEAD = 5, C_SAMPLE = 6, C_COUNT = 8 };      /* C_SAMPLE + copy: the batch's next camera sample (regeneration) */
 enum { S_CAM = 0, S_CLOSEST = 1, S_SHADOW = 2, S_NODES = 3, S_TRIS = 4, S_INVALID = 5, S_COUNT = 8 };
 /* census (COUNT builds, NORI_HIP_CENSUS): wave-level trips of wf_extend's loop and the lanes they used */
 enum { Z_TRIPS = 0, Z_INNER_TRIPS = 1, Z_INNER_LANES = 2, Z_LEAF_TRIPS = 3, Z_LEAF_LANES = 4, Z_REFILLS = 5, Z_REFILL_LANES = 6, Z_COUNT = 8 };
@@ -108,7 +109,29 @@ struct WfBatch {
     int32_t tile_w;
     int32_t inner_repeat;               /* wf_extend: node steps repeat while at least this many lanes are at inner nodes (65: never) */
     uint32_t flags;                     /* kBatch* */
+    uint32_t pool;                      /* paths a pass works on: the stored survivors + as many NEW camera samples of the batch as fill it up */
 };
+
+/* Regeneration (constant population).  A pass over state copy `cur` works on the n_s survivors the last wf_shade stored plus
+   n_fresh camera samples of the batch that have not been started yet -- path i >= n_f0 IS camera sample s0 + (i - n_f0): nothing of
+   it is stored, both kernels compute its first vertex (first_vertex) as the batch's first pass always did.  So a batch of any
+   size runs on a pool of bt.pool paths, every pass full until the batch's samples run out; with pool >= the batch's samples the
+   first pass starts them all and the schedule is the shrinking one of rounds 2 - 5.  Which pass a sample starts in is not
+   observable: its pcg32 stream is seeded by (pixel, sample), its radiance goes to the film store at its own index.
+   MODE of a kernel: kStoredOnly no path is new (the batch's samples have all been started: the kernel carries no camera code),
+   kFreshOnly the batch's first pass (no path is stored), kMixed both. */
+enum { kStoredOnly = 0, kFreshOnly = 1, kMixed = 2 };
+struct PassShape { uint32_t n_s, s0, n_fresh, n_f0, n; };      /* stored paths [0, n_s), new paths [n_f0, n): n_f0 = n_s rounded up to a wf_shade round */
+template <int MODE> __device__ __forceinline__ PassShape pass_shape(const uint32_t *ctr, int cur, const WfBatch &bt) {
+    PassShape ps;
+    ps.n_s = MODE == kFreshOnly ? 0u : ctr[C_N + cur];
+    ps.s0 = ctr[C_SAMPLE + cur];
+    ps.n_f0 = (ps.n_s + 255u) & ~255u;
+    const uint32_t total = bt.n_tiles * 256u * bt.n_spp;
+    ps.n_fresh = MODE == kStoredOnly ? 0u : min(total - ps.s0, bt.pool > ps.n_f0 ? bt.pool - ps.n_f0 : 0u);
+    ps.n = ps.n_fresh ? ps.n_f0 + ps.n_fresh : ps.n_s;
+    return ps;
+}
 constexpr uint32_t kBatchNoAsmLoop = 1u;       /* wf_extend: the compiler's node loop instead of the hand-written one (A/B, tests) */
 constexpr uint32_t kBatchCountQ = 2u;          /* wf_extend, COUNT builds: walk the 32-B node records (trav_inner_step_q, the C++ statement of the
                                                   hand-written loop) -- the node / triangle tests counted are those of the tree form the timed kernel walks */
@@ -443,8 +466,8 @@ __device__ __forceinline__ f4 hit_pack_here(const Hit *closest, bool shadow_occl
 /* BLOCK: threads per workgroup.  Every workgroup holds its own copy of the LDS image next to its stacks, so the bigger the
    workgroup the bigger the image can be: BVH2 trees run in workgroups of 1024 threads (two per CU: 2 x (68 KB of stacks +
    12 KB of image)), wide-node trees -- whose kernels need more than 64 registers, i.e. 5 or 6 waves per SIMD -- in workgroups of 256. */
-template <int STACK, bool SPILL, bool COUNT, bool FIRST, bool WIDE, bool ASM, int BLOCK>
-__global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
+template <int STACK, bool SPILL, bool COUNT, int MODE, bool WIDE, bool ASM, int BLOCK>
+__global__ __launch_bounds__(BLOCK, WIDE ? (MODE != kStoredOnly ? 5 : 7) : 8) void wf_extend(DevScene sc, WfBuf b, int cur, int thresholds, WfBatch bt) {
     const int refill_threshold = thresholds & 0xff, leaf_threshold = (thresholds >> 8) & 0xff;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename ExtendStack<STACK, SPILL, ASM, BLOCK>::type Stack;
@@ -458,10 +481,13 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
     const TopNodesP top_lds = top_nodes_pointer(top);
     const uint32_t image_address = lds_address(smem) + (uint32_t) (Stack::kLdsEntries * BLOCK * sizeof(int));      /* of top */
     const WfState S = b.st[cur];
-    const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
+    constexpr bool kFresh = MODE != kStoredOnly, kStored = MODE != kFreshOnly;
+    const PassShape shape = pass_shape<MODE>(b.ctr, cur, bt);
+    const uint32_t n = shape.n, n_s = shape.n_s;
     /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
-       reset them for the wf_shade that follows this kernel and for the next wf_extend */
-    if (blockIdx.x == 0 && threadIdx.x == 0) { b.ctr[C_N + (cur ^ 1)] = 0u; b.ctr[C_HEAD + (cur ^ 1)] = 0u; }
+       reset them for the wf_shade that follows this kernel and for the next wf_extend; the next pass starts its new camera
+       samples where this one stops */
+    if (blockIdx.x == 0 && threadIdx.x == 0) { b.ctr[C_N + (cur ^ 1)] = 0u; b.ctr[C_HEAD + (cur ^ 1)] = 0u; b.ctr[C_SAMPLE + (cur ^ 1)] = shape.s0 + shape.n_fresh; }
     const int lane = lane_id();
     Trav tv; trav_idle(tv);
     uint32_t rid = 0;            /* path << 2 | continuation pending << 1 | shadow ray occluded */
@@ -513,22 +539,21 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
             if (COUNT) { zc[Z_REFILLS]++; zc[Z_REFILL_LANES] += (uint32_t) nIdle; }
             const uint32_t avail = chunk_end - chunk_pos;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (fresh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) fresh, 0u));   /* set bits below this lane */
-            bool startedA = false, startedB = false;      /* this lane starts a closest-hit / a shadow query in this refill */
-            if (FIRST) {
-                if (!trav_active(tv) && rank < avail) {      /* path i = camera sample i of the batch */
-                    const uint32_t i = chunk_pos + rank;
-                    f2 ps; RayIn ray; Rng rng;
-                    if (first_vertex(sc, bt, i, ps, ray, rng)) {
-                        st_f2<1>(&b.samp_pos[i], ps);
-                        rid = i << 2;
-                        trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, false, stack, tv);
-                        startedA = true;
-                        unsaved = trav_active(tv);
-                        if (unsaved) tv.node = root_link;
-                        if (!trav_active(tv)) st_f4<1>(&b.hit[i], hit_pack_here(nullptr, false));
-                    }
+            bool startedA = false, startedB = false, startedCam = false;      /* this lane starts a closest-hit / a shadow query / a camera ray in this refill */
+            const bool take = !pend && !trav_active(tv) && rank < avail;      /* this lane takes path chunk_pos + rank */
+            if (kFresh && take && chunk_pos + rank >= shape.n_f0) {      /* a new path: camera sample s0 + (i - n_f0) of the batch */
+                const uint32_t i = chunk_pos + rank, sid = shape.s0 + (i - shape.n_f0);
+                f2 ps; RayIn ray; Rng rng;
+                if (first_vertex(sc, bt, sid, ps, ray, rng)) {
+                    st_f2<1>(&b.samp_pos[sid], ps);
+                    rid = i << 2;
+                    trav_begin<WIDE ? kLayoutWide : kLayoutBvh2>(sc, ray, false, stack, tv);
+                    startedA = startedCam = true;
+                    unsaved = trav_active(tv);
+                    if (unsaved) tv.node = root_link;
+                    if (!trav_active(tv)) st_f4<1>(&b.hit[i], hit_pack_here(nullptr, false));
                 }
-            } else if (pend || (!trav_active(tv) && rank < avail)) {
+            } else if (kStored && (pend || (take && chunk_pos + rank < n_s))) {      /* (indices in [n_s, n_f0) hold no path) */
                 const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
                 /* a fresh path: origin and both directions (the flags ride with the continuation direction) are requested
                    together -- one round trip to HBM instead of two (the direction a path needs first depends on its
@@ -559,8 +584,9 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
                 }
             }
             chunk_pos += min(avail, (uint32_t) __popcll(fresh));
-            { const uint32_t na = (uint32_t) __popcll(__ballot(startedA)); nClosest += na; if (FIRST) nCam += na; }
-            if (!FIRST) nShadow += (uint32_t) __popcll(__ballot(startedB));
+            nClosest += (uint32_t) __popcll(__ballot(startedA));
+            if (kFresh) nCam += (uint32_t) __popcll(__ballot(startedCam));
+            if (kStored) nShadow += (uint32_t) __popcll(__ballot(startedB));
         }
         if (__ballot(trav_active(tv)) == 0ull) {
             if (exhausted && __ballot((rid & 2u) != 0u) == 0ull) break;
@@ -614,7 +640,7 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
     if (lane == 0) {
         if (nClosest) atomicAdd(&b.stats[S_CLOSEST], (unsigned long long) nClosest);
         if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
-        if (FIRST && nCam) atomicAdd(&b.stats[S_CAM], (unsigned long long) nCam);
+        if (kFresh && nCam) atomicAdd(&b.stats[S_CAM], (unsigned long long) nCam);
         if (COUNT) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
         NORI_PROF_STORE
         if (COUNT && b.census) for (int k = 0; k < Z_COUNT; ++k) if (zc[k]) atomicAdd(&b.census[k], (unsigned long long) zc[k]);
@@ -627,6 +653,7 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (FIRST ? 5 : 7) : 8) void wf_extend(D
    chunks of <= kShadeChunk records with one atomic per chunk, sized by the survival rate it sees;
    what it leaves unused of its last chunk is marked empty (flags = 0) and dropped by the next pass. */
 constexpr int kSB = 256;      /* threads per wf_shade workgroup (128 / 64: slower, DESIGN_HISTORY.md) */
+static_assert(kSB == 256, "pass_shape starts the new paths of a pass at a multiple of 256");
 
 /* wf_shade's workgroup barriers wait for LDS only: what the compaction exchanges lives there.  (__syncthreads() is also a fence,
    i.e. s_waitcnt vmcnt(0): a wave then sits out the trip of its own state STORES to L2 in every round.) */
@@ -645,59 +672,60 @@ template <> struct ShadeTab<true> { typedef LdsTables type; static __device__ __
 /* MATSET (rt_path.h): the BSDF types the scene contains -- the kernel of an all-diffuse scene carries no mirror, dielectric or
    microfacet code (the all-diffuse kernel: 117 registers instead of 128; held to the 96 of five workgroups per CU it spills and is
    slower, profiles/r5_01_shade_matset_ab.txt) */
-template <int INTEG, bool FIRST, bool LDSTAB, int MATSET>
+template <int INTEG, int MODE, bool LDSTAB, int MATSET>
 __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
     NORI_LAB_SHADE_PAD
     const WfState S = b.st[cur], D = b.st[cur ^ 1];
     const uint32_t s_first = bt.s_first, n_spp = bt.n_spp;
     __shared__ uint4 s_tab[LDSTAB ? kShadeTabWords / 4 : 1];
     const typename ShadeTab<LDSTAB>::type tab = ShadeTab<LDSTAB>::make(sc, s_tab);      /* mesh / emitter tables: LDS instead of L2 round trips */
-    const uint32_t n = FIRST ? bt.n_tiles * 256u * bt.n_spp : b.ctr[C_N + cur];
+    constexpr bool kFresh = MODE != kStoredOnly, kStored = MODE != kFreshOnly;
+    const PassShape shape = pass_shape<MODE>(b.ctr, cur, bt);      /* the pass wf_extend just traced: the same counters */
+    const uint32_t n = shape.n, n_s = shape.n_s;
     const uint32_t rounds_total = (n + kSB - 1) / kSB;
     const uint32_t rounds_per_block = (rounds_total + gridDim.x - 1) / gridDim.x;
     const uint32_t r0 = blockIdx.x * rounds_per_block, r1 = min(rounds_total, r0 + rounds_per_block);
+    /* rounds below r_mid hold stored paths, rounds from r_mid on new ones (pass_shape: the new paths start at a multiple of kSB) */
+    const uint32_t r_mid = kStored ? min(r1, max(r0, shape.n_f0 / kSB)) : r0;
     __shared__ uint32_t s_wcnt[2][4], s_newbase;
     uint32_t out_base = 0u, out_used = 0u, out_len = 0u;     /* workgroup-uniform */
     bool overflow = false;
     const int wave = (int) (threadIdx.x >> 6), lane = lane_id();
     const uint32_t per_tile = 256u * n_spp;
-    constexpr bool kPf = !FIRST;
     uint32_t pf_sidx = 0u; f4 pf_d, pf_L, pf_h;
     pf_d.x = pf_d.y = pf_d.z = pf_d.w = 0.0f; pf_L = pf_h = pf_d;
-    if (kPf && r0 < r1 && r0 * kSB + threadIdx.x < n) {
-        const uint32_t i0 = r0 * kSB + threadIdx.x;
-        pf_d = ld_f4<2>(&S.dA[i0]); pf_sidx = ld_w<2>(&S.sidx[i0]); pf_L = ld_f4<2>(&S.L_pdf[i0]); pf_h = ld_f4<1>(&b.hit[i0]);
-    }
-    for (uint32_t r = r0; r < r1; ++r) {
+    /* One round: 256 paths, one vertex each.  FRESH rounds hold new paths -- camera sample s0 + (i - n_f0), nothing stored: the
+       first vertex is recomputed from the sample index --, the others stored ones, whose record head was requested a round ahead.
+       Two instantiations in two loops (a workgroup's range of rounds is stored rounds, then new ones): in ONE loop body the
+       camera code and the prefetched head compete for registers and the kernel spills. */
+    auto round = [&](auto fresh_tag, uint32_t r, uint32_t r_end) {
+        constexpr bool FRESH = decltype(fresh_tag)::value;
         const uint32_t i = r * kSB + threadIdx.x;
         bool survive = false;
         const uint32_t c_sidx = pf_sidx; const f4 c_d = pf_d, c_L = pf_L, c_h = pf_h;
-        if (kPf && r + 1u < r1 && i + kSB < n) {
+        if (!FRESH && r + 1u < r_end && i + kSB < n_s) {
             pf_d = ld_f4<2>(&S.dA[i + kSB]); pf_sidx = ld_w<2>(&S.sidx[i + kSB]); pf_L = ld_f4<2>(&S.L_pdf[i + kSB]); pf_h = ld_f4<1>(&b.hit[i + kSB]);
         }
         f4 n_o, n_dA, n_dB, n_T, n_L, n_Ld;
         uint32_t n_fl = 0u, sidx = 0u;
         unsigned long long n_rng = 0ull;
-        if (i < n) {
+        if (FRESH ? i < n : i < n_s) {
             /* the path's state: from HBM, or -- first vertex -- recomputed from the sample index */
             uint32_t fl; f4 L4, d4, t4; Rng rng0; rng0.state = 0; rng0.inc = 0;
-            if (FIRST) {
+            if (FRESH) {
                 f2 ps; RayIn cam;
-                fl = first_vertex(sc, bt, i, ps, cam, rng0) ? (F_HAS_A | (2u << 4)) : 0u;      /* prev_measure = discrete, depth 0 */
-                sidx = i;
+                sidx = shape.s0 + (i - shape.n_f0);
+                fl = first_vertex(sc, bt, sidx, ps, cam, rng0) ? (F_HAS_A | (2u << 4)) : 0u;      /* prev_measure = discrete, depth 0 */
                 L4.x = L4.y = L4.z = L4.w = 0.0f;                  /* L = 0, pdf_mat = 0 */
                 t4.x = t4.y = t4.z = t4.w = 1.0f;                  /* T = 1, eta = 1 */
                 d4.x = cam.d.x; d4.y = cam.d.y; d4.z = cam.d.z; d4.w = 0.0f;
             } else {
-                d4 = kPf ? c_d : ld_f4<2>(&S.dA[i]);               /* the continuation direction and, in its w, the flags (wf_records.h) */
+                d4 = c_d;               /* the continuation direction and, in its w, the flags (wf_records.h) */
                 fl = state_flags(d4);
             }
             if (fl & (F_HAS_A | F_HAS_B)) {
-                if (!FIRST) {
-                    if (kPf) { sidx = c_sidx; L4 = c_L; }
-                    else { sidx = ld_w<2>(&S.sidx[i]); L4 = ld_f4<2>(&S.L_pdf[i]); }
-                }
-                const f4 h = (FIRST || !kPf) ? ld_f4<1>(&b.hit[i]) : c_h;
+                if (!FRESH) { sidx = c_sidx; L4 = c_L; }
+                const f4 h = FRESH ? ld_f4<1>(&b.hit[i]) : c_h;
                 const uint32_t hw = __float_as_uint(h.w);
                 bool done = false;
                 NORI_LAB_SHADE_VERTEX
@@ -711,12 +739,14 @@ __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur
                 PathState st;
                 st.L = mk3(L4.x, L4.y, L4.z);
                 if (!done) {
-                    if (!FIRST) t4 = ld_f4<2>(&S.T_eta[i]);
+                    if (!FRESH) t4 = ld_f4<2>(&S.T_eta[i]);
                     Hit hit; bool found;
                     hit_unpack(sc, h, hit, found);
                     /* pcg32 stream of this camera sample: inc from the sample index, state from HBM */
                     const uint32_t sl = (sidx % per_tile) >> 8;
-                    vertex_unpack(st, fl, L4, t4, FIRST ? rng0.state : ld_w<2>(&S.rng[i]), ((uint64_t) (s_first + sl) << 1u) | 1u);
+                    uint64_t rng_state = rng0.state;
+                    if (!FRESH) rng_state = ld_w<2>(&S.rng[i]);
+                    vertex_unpack(st, fl, L4, t4, rng_state, ((uint64_t) (s_first + sl) << 1u) | 1u);
                     done = path_on_closest<INTEG, typename ShadeTab<LDSTAB>::type, MATSET>(sc, tab, st, hit, found, mk3(d4.x, d4.y, d4.z));
                     if (!done) {
                         survive = true;
@@ -760,7 +790,15 @@ __global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur
         }
         if (c > room) { out_base = new_base; out_used = c - room; out_len = want; }
         else out_used += c;
+    };
+    if (kStored) {
+        if (r0 < r_mid && r0 * kSB + threadIdx.x < n_s) {
+            const uint32_t i0 = r0 * kSB + threadIdx.x;
+            pf_d = ld_f4<2>(&S.dA[i0]); pf_sidx = ld_w<2>(&S.sidx[i0]); pf_L = ld_f4<2>(&S.L_pdf[i0]); pf_h = ld_f4<1>(&b.hit[i0]);
+        }
+        for (uint32_t r = r0; r < r_mid; ++r) round(std::false_type(), r, r_mid);
     }
+    if (kFresh) for (uint32_t r = r_mid; r < r1; ++r) round(std::true_type(), r, r1);
     /* what is left of the last chunk holds no path: flags 0 */
     for (uint32_t k = out_used + threadIdx.x; k < out_len; k += kSB) { f4 z; z.x = z.y = z.z = z.w = 0.0f; D.dA[out_base + k] = z; }
     if (overflow && threadIdx.x == 0) b.ctr[C_OVERFLOW] = 1u;
@@ -939,13 +977,13 @@ std::string ensure_pool(Pool &pool, size_t records) {
 constexpr int kExtendBlockBvh2 = 1024, kExtendBlockWide = kB;
 constexpr int kExtendWgsBvh2 = 2048 / kExtendBlockBvh2, kExtendWgsWide = 7, kExtendWgsWideFirst = 5;
 constexpr size_t kLdsPerCu = 160 * 1024;
-template <int STACK, bool SPILL, bool COUNT, bool FIRST>
+template <int STACK, bool SPILL, bool COUNT, int MODE>
 void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int grid, const WfBatch &bt, hipStream_t s) {
     const size_t image = (size_t) std::max(1u, sc.top_image_quads) * sizeof(f4);
     if (sc.wide) {
         /* wide trees push up to three children per step: always the spilling stack */
         const size_t lds = (size_t) LdsStackW<STACK, SPILL, kExtendBlockWide>::kLdsEntries * kExtendBlockWide * sizeof(int) + image;
-        if (SPILL) hipLaunchKernelGGL((wf_extend<STACK, true, COUNT, FIRST, true, false, kExtendBlockWide>), dim3(grid), dim3(kExtendBlockWide), lds, s, sc, b, cur, refill, bt);
+        if (SPILL) hipLaunchKernelGGL((wf_extend<STACK, true, COUNT, MODE, true, false, kExtendBlockWide>), dim3(grid), dim3(kExtendBlockWide), lds, s, sc, b, cur, refill, bt);
     } else {
         /* the hand-written node loop (bvh2q_node_loop_asm) walks the tree's 32-B records (rt_nodeq.h: trees without unbounded boxes),
            addresses them by 32-bit byte offsets (trees below 2^25 nodes -- a BVH2 tree has fewer nodes than triangles) and keeps its
@@ -956,17 +994,19 @@ void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int 
         const size_t lds = (use_asm ? (size_t) ExtendStack<STACK, SPILL, kAsm, kExtendBlockBvh2>::type::kLdsEntries : (size_t) LdsStackW<STACK, SPILL, kExtendBlockBvh2>::kLdsEntries) *
                                kExtendBlockBvh2 * sizeof(int) + (size_t) std::max(1u, image_q ? sc.top_image_q_quads : sc.top_image_quads) * sizeof(f4);
         if (use_asm)
-            hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST, false, kAsm, kExtendBlockBvh2>), dim3(grid), dim3(kExtendBlockBvh2), lds, s, sc, b, cur, refill, bt);
+            hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, MODE, false, kAsm, kExtendBlockBvh2>), dim3(grid), dim3(kExtendBlockBvh2), lds, s, sc, b, cur, refill, bt);
         else
-            hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, FIRST, false, false, kExtendBlockBvh2>), dim3(grid), dim3(kExtendBlockBvh2), lds, s, sc, b, cur, refill, bt);
+            hipLaunchKernelGGL((wf_extend<STACK, SPILL, COUNT, MODE, false, false, kExtendBlockBvh2>), dim3(grid), dim3(kExtendBlockBvh2), lds, s, sc, b, cur, refill, bt);
     }
 }
 
 /* lds_stack: entries kept in LDS (16 / 24 / 32); spill: the tree is deeper than that;
-   first: the batch's first pass (camera rays computed in the kernel) */
-void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int lds_stack, bool spill, bool count, bool first,
+   mode: kStoredOnly / kFreshOnly (the batch's first pass) / kMixed */
+void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int lds_stack, bool spill, bool count, int mode,
                        int grid, const WfBatch &bt, hipStream_t s) {
-#define G(S, P, C) if (first) launch_extend<S, P, C, true>(sc, b, cur, refill, grid, bt, s); else launch_extend<S, P, C, false>(sc, b, cur, refill, grid, bt, s)
+#define G(S, P, C) if (mode == kFreshOnly) launch_extend<S, P, C, kFreshOnly>(sc, b, cur, refill, grid, bt, s); \
+                   else if (mode == kMixed) launch_extend<S, P, C, kMixed>(sc, b, cur, refill, grid, bt, s); \
+                   else launch_extend<S, P, C, kStoredOnly>(sc, b, cur, refill, grid, bt, s)
 #define E(S, P) if (count) { G(S, P, true); } else { G(S, P, false); }
 #define F(S) if (spill) { E(S, true); } else { E(S, false); }
     if (lds_stack <= 16) { F(16); } else if (lds_stack <= 24) { F(24); } else { F(32); }
@@ -975,7 +1015,7 @@ void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, 
 #undef G
 }
 
-void launch_shade(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &bt, bool first, int grid_, hipStream_t s) {
+void launch_shade(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &bt, int mode, int grid_, hipStream_t s) {
     const dim3 grid(grid_ * (kB / kSB)), block(kSB);
     const bool lds_tables = shade_tables_fit(sc);
     /* the material set the kernel is compiled for: all-diffuse scenes (the Cornell box of the headline), scenes without a
@@ -987,7 +1027,7 @@ void launch_shade(const DevScene &sc, const WfBuf &b, int cur, const WfBatch &bt
                      else hipLaunchKernelGGL((wf_shade<I, F, false, M>), grid, block, 0, s, sc, b, cur, bt)
 #define SH2(I, F) if (matset == 1) { SH3(I, F, 1); } else if (matset == 7) { SH3(I, F, 7); } else { SH3(I, F, kAnyBsdf); }
 #define SH1(I, F) SH3(I, F, kAnyBsdf)
-#define SH(I, W) case I: if (first) { W(I, true); } else { W(I, false); } break;
+#define SH(I, W) case I: if (mode == kFreshOnly) { W(I, kFreshOnly); } else if (mode == kMixed) { W(I, kMixed); } else { W(I, kStoredOnly); } break;
         SH(0, SH1) SH(1, SH1) SH(2, SH1) SH(3, SH2) SH(4, SH2) SH(5, SH2) SH(6, SH2)
 #undef SH
 #undef SH1
@@ -1147,7 +1187,9 @@ bool wavefront_excursions(unsigned long long out[4], bool reset) {
 #endif
 }
 
-size_t wavefront_bytes_per_path() { return kStateBytesPerRecord + 2 * (sizeof(f2) + sizeof(P3)); }      /* (two halves of the sample store: tail overlap) */
+size_t wavefront_bytes_per_path() { return kStateBytesPerRecord; }
+size_t wavefront_bytes_per_sample() { return 2 * (sizeof(f2) + sizeof(P3)); }      /* (two halves of the sample store: tail overlap) */
+void wavefront_release_pool(WfEngine *e) { if (e) { e->pool.release(); e->tail.release(); } }
 
 size_t wavefront_held_bytes(const WfEngine *e, const FilmStore &film) {
     return (e ? e->pool.bytes : 0) + film.capacity * (sizeof(f2) + sizeof(P3));
@@ -1166,7 +1208,9 @@ struct Pipe {
     uint32_t tile_lo = 0, tile_hi = 0;      /* selected-tile ordinals owned by this pipe */
     uint32_t tiles_b = 0, spp_b = 0;        /* batch geometry */
     uint32_t t0 = 0, s0 = 0;                /* next batch */
-    bool active = false, finished = false, first = false;
+    bool active = false, finished = false;
+    int mode = kFreshOnly;                   /* of the next pass's kernels */
+    uint32_t batch_samples = 0;              /* camera samples of the current batch */
     uint32_t batch_rounds = 0;               /* host-loop rounds spent on the current batch */
     WfBatch bt;
     int cur = 0;
@@ -1214,8 +1258,10 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     if (split_cus > 0 && ensure_split_streams(eng, split_cus)) n_pipes = 2; else split_cus = 0;
     const bool split = split_cus > 0;
 
-    /* state budget per pipe; batch = a range of the pipe's tiles x as many samples per pixel as fit */
-    const size_t budget = std::max<size_t>(L.max_paths / n_pipes, 256);
+    /* per pipe: a batch = a range of the pipe's tiles x as many samples per pixel as the film's sample store may hold
+       (max_samples); the paths in flight -- the state pool -- are bounded separately (max_paths): a batch bigger than the pool
+       starts its samples pass by pass, in the slots its finished paths leave (regeneration, WfBatch::pool) */
+    const size_t budget = std::min<size_t>(std::max<size_t>(std::max(L.max_samples, L.max_paths) / n_pipes, 256), (size_t) 1 << 31);
     Pipe pipes[2];
     size_t need[2] = {0, 0};
     for (int k = 0; k < n_pipes; ++k) {
@@ -1249,10 +1295,12 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     }
     const bool overlap = tail_cus > 0;
     if (L.film_reference && (n_pipes != 1 || pipes[0].tiles_b != L.n_sel_tiles || pipes[0].spp_b != L.spp_count || L.tile_mod != 1))
-        return "wavefront: film_order = reference needs the whole frame in one batch (tile_mod 1, wavefront_paths >= pixels x samples)";
-    const size_t per_pipe = std::max(need[0], need[1]);
-    const size_t records = state_capacity(per_pipe);            /* per pipe, per state copy */
-    const int sh_grid = shade_grid(per_pipe);
+        return "wavefront: film_order = reference needs the whole frame in one batch (tile_mod 1, wavefront_samples >= pixels x samples)";
+    const size_t per_pipe = std::max(need[0], need[1]);         /* camera samples of a batch */
+    size_t pool_paths = std::min(per_pipe, std::max<size_t>(L.max_paths / n_pipes, 256));      /* paths in flight */
+    if (const char *e = getenv("NORI_HIP_WF_POOL")) pool_paths = std::min(per_pipe, (size_t) std::max(256ll, atoll(e)));      /* experiments */
+    const size_t records = state_capacity(pool_paths);          /* per pipe, per state copy */
+    const int sh_grid = shade_grid(pool_paths);
     if (records >= ((size_t) 1 << 30)) return "wavefront: wavefront_paths too large (state index is 30 bits)";
     std::string err = ensure_pool(g_pool, records * n_pipes);
     if (!err.empty()) return err;
@@ -1376,6 +1424,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     const bool census = getenv("NORI_HIP_CENSUS") != nullptr;
     bool use_finish = true;
     if (const char *e = getenv("NORI_HIP_WF_FINISH")) use_finish = atoi(e) != 0;
+    const bool force_mixed = getenv("NORI_HIP_WF_FORCE_MIXED") != nullptr && atoi(getenv("NORI_HIP_WF_FORCE_MIXED")) != 0;      /* A/B: the kMixed kernels on every pass but the first */
 
     KernelTimer timer(L.time_kernels);
     unsigned long long *d_census = nullptr;
@@ -1398,6 +1447,8 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
             P.bt.tile_mod = L.tile_mod; P.bt.tile_rem = L.tile_rem; P.bt.tiles_x = L.tiles_x; P.bt.tile_w = L.tile_w;
             P.bt.inner_repeat = inner_repeat;
             P.bt.flags = (no_asm_loop ? kBatchNoAsmLoop : 0u) | (count_q ? kBatchCountQ : 0u);
+            P.bt.pool = (uint32_t) pool_paths;
+            P.batch_samples = nt * 256u * ns;
             WF_TRY(hipMemsetAsync(P.b.ctr, 0, C_COUNT * sizeof(uint32_t), P.stream));
             if (split) WF_TRY(hipEventRecord(P.ev_shade, P.stream));      /* (and the film of the pipe's last batch, which read the sample store) */
             if (overlap) {      /* the sample store's halves alternate: the previous batch's tail and gather still use the other one */
@@ -1406,13 +1457,13 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 P.b.samp_pos = P.film.pos; P.b.samp_L = P.film.L;
             }
             stats.n_batches++;
-            P.cur = 0; P.first = true; P.active = true; any = true; P.batch_rounds = 0;
+            P.cur = 0; P.mode = kFreshOnly; P.active = true; any = true; P.batch_rounds = 0;
         }
         if (!any) break;
         /* the path count is read back every sync_every iterations, more often once it is small
            (the readback costs ~20 us, an iteration on a few paths ~100 us) */
         uint32_t n_max = 0;
-        for (int k = 0; k < n_pipes; ++k) if (pipes[k].active) n_max = std::max(n_max, pipes[k].first ? 0xffffffffu : pipes[k].h_ctr[C_N + pipes[k].cur]);
+        for (int k = 0; k < n_pipes; ++k) if (pipes[k].active) n_max = std::max(n_max, pipes[k].mode != kStoredOnly ? 0xffffffffu : pipes[k].h_ctr[C_N + pipes[k].cur]);
         const int iters = n_max > (16u << 20) ? sync_every : std::min(sync_every, 2);
         for (int it = 0; it < iters; ++it)
             for (int k = 0; k < n_pipes; ++k) {
@@ -1420,15 +1471,16 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 if (!P.active) continue;
                 if (split) WF_TRY(hipStreamWaitEvent(P.extend_stream, P.ev_shade, 0));
                 timer.begin(KC_TRACE, P.extend_stream);
-                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.first, P.first ? extend_grid_first : extend_grid, P.bt, P.extend_stream);
+                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.mode, P.mode != kStoredOnly ? extend_grid_first : extend_grid, P.bt, P.extend_stream);
                 WF_TRY(hipGetLastError());      /* a launch that did not fit (LDS, registers) must not pass for an empty pass */
                 timer.end(P.extend_stream);
                 if (split) { WF_TRY(hipEventRecord(P.ev_extend, P.extend_stream)); WF_TRY(hipStreamWaitEvent(P.stream, P.ev_extend, 0)); }
                 timer.begin(KC_SHADE, P.stream);
-                launch_shade(sc, P.b, P.cur, P.bt, P.first, sh_grid, P.stream);
+                launch_shade(sc, P.b, P.cur, P.bt, P.mode, sh_grid, P.stream);
                 timer.end(P.stream);
                 if (split) WF_TRY(hipEventRecord(P.ev_shade, P.stream));
-                P.first = false;
+                /* the first pass started min(pool, samples) camera samples: a batch that fits the pool has none left */
+                if (P.mode == kFreshOnly) P.mode = P.batch_samples <= P.bt.pool && !force_mixed ? kStoredOnly : kMixed;
                 P.cur ^= 1;
                 stats.n_launches += 2;
                 if (k == 0) stats.n_iterations++;
@@ -1440,7 +1492,10 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
         for (int k = 0; k < n_pipes; ++k) {
             Pipe &P = pipes[k];
             if (P.active && P.h_ctr[C_OVERFLOW] != 0) return "wavefront: path state pool overflow";
-            if (census && P.active) fprintf(stderr, "[wavefront] pipe %d iteration %u: %u path slots\n", k, stats.n_iterations, P.h_ctr[C_N + P.cur]);
+            /* camera samples of the batch no pass has started yet (the counter the next pass would read) */
+            const uint32_t samples_left = P.active ? P.batch_samples - std::min(P.batch_samples, P.h_ctr[C_SAMPLE + P.cur]) : 0u;
+            if (P.active && samples_left == 0u && P.mode == kMixed && !force_mixed) P.mode = kStoredOnly;
+            if (census && P.active) fprintf(stderr, "[wavefront] pipe %d iteration %u: %u path slots, %u samples to start\n", k, stats.n_iterations, P.h_ctr[C_N + P.cur], samples_left);
             /* the film gather of the batch whose tail ran beside this one: behind the tail, in front of everything that follows on
                this stream (gathers stay in batch order) */
             auto flush_pending = [&]() -> std::string {
@@ -1454,7 +1509,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 return std::string();
             };
             bool gather_deferred = false;
-            if (P.active && P.h_ctr[C_N + P.cur] != 0 && P.h_ctr[C_N + P.cur] <= (uint32_t) finish_paths && use_finish) {
+            if (P.active && samples_left == 0u && P.h_ctr[C_N + P.cur] != 0 && P.h_ctr[C_N + P.cur] <= (uint32_t) finish_paths && use_finish) {
                 const bool last_batch = P.s0 + P.bt.n_spp >= L.spp_count && P.t0 + P.bt.n_tiles >= P.tile_hi;
                 if (overlap && !last_batch) {
                     err = flush_pending();      /* (also: the previous tail is done with the side copy) */
@@ -1483,7 +1538,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 }
                 P.h_ctr[C_N + P.cur] = 0;
             }
-            if (!P.active || P.h_ctr[C_N + P.cur] != 0) continue;
+            if (!P.active || P.h_ctr[C_N + P.cur] != 0 || samples_left != 0u) continue;
             /* batch done: splat its samples (each pipe owns its tiles' accumulators) */
             if (!gather_deferred) {
                 err = flush_pending();

@@ -9,7 +9,7 @@
  *   -DNORI_EXP_SHADE=n   wf_shade: 1 = one more dense 16-B load per path, 2 = one more 16-B store per survivor, 3 = 64 more VALU
  *                        instructions per path, 4 = one more dependent 16-B gather from the shading records, 5 / 6 = LDS padding that
  *                        leaves 3 / 2 workgroups per CU instead of 4
- *   -DNORI_EXP_WIDE_SENS=n  the WIDE node step (rt_trace.h): 1 = one more load, 3 = 32 more VALU instructions
+ *   -DNORI_EXP_WIDE_SENS=n  the WIDE node step (rt_trace.h): 1 = one more load, 3 = 32 more VALU instructions, 5 = 64 idle cycles
  * Every hook is a macro used at exactly one place of wavefront.hip; the names of the variables they touch are the kernels'. */
 #pragma once
 
@@ -57,6 +57,8 @@
 /* ---- the WIDE node step (rt_trace.h, trav_wide_step): -DNORI_EXP_WIDE_SENS=1 one more load of the node's record, 3 = 32 more VALU instructions */
 #if defined(NORI_EXP_WIDE_SENS) && NORI_EXP_WIDE_SENS == 3
 #define NORI_LAB_WIDE_STEP { float x_ = q0.x; asm volatile(NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") : "+v"(x_)); q0.x = x_; }
+#elif defined(NORI_EXP_WIDE_SENS) && NORI_EXP_WIDE_SENS == 5
+#define NORI_LAB_WIDE_STEP asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 #elif defined(NORI_EXP_WIDE_SENS)
 #define NORI_LAB_WIDE_STEP if (!(tv.node & kTopBit)) { const f4 x_ = sc.nodes[(size_t) tv.node * kNodeQuads + 3]; asm volatile("" :: "v"(x_.x), "v"(x_.y), "v"(x_.z), "v"(x_.w)); }
 #endif
@@ -68,7 +70,7 @@
 #define NORI_LAB_SHADE_PAD
 #endif
 #if NORI_EXP_SHADE == 1
-#define NORI_LAB_SHADE_VERTEX if (!FIRST) { const f4 x = ld_f4<2>(&S.dB[i]); asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
+#define NORI_LAB_SHADE_VERTEX if (!FRESH) { const f4 x = ld_f4<2>(&S.dB[i]); asm volatile("" :: "v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
 #elif NORI_EXP_SHADE == 3
 #define NORI_LAB_SHADE_VERTEX { float x = h.x; asm volatile(NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") NORI_X16("v_mov_b32 %0, %0\n\t") : "+v"(x)); }
 #elif NORI_EXP_SHADE == 4

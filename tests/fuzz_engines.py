@@ -64,7 +64,8 @@ def one_round(seed, renderer_cls, oracle=False):
     mk = renderer_cls(0).upload(sc, builder=builder)
     wf = renderer_cls(0).upload(sc, builder=builder)
     wf.set_option("engine", "wavefront")
-    wf.set_option("wavefront_paths", int(rng.choice([256, 256 * 7, 1 << 14, 1 << 28])))
+    wf.set_option("wavefront_paths", int(rng.choice([256, 256 * 7, 1 << 14, 1 << 28])))        # the pool ...
+    wf.set_option("wavefront_samples", int(rng.choice([256, 256 * 7, 1 << 14, 1 << 28])))      # ... and the batch: smaller, equal or bigger (regeneration)
     env = {"NORI_HIP_WF_FINISH_PATHS": str(int(rng.choice([256, 4096, 1 << 19]))), "NORI_HIP_WF_SYNC_EVERY": str(int(rng.choice([1, 2, 6]))),
            "NORI_HIP_WF_NO_ASM_LOOP": "1"}      # counters compared on the megakernel's tree form, the 64-B nodes (the 32-B records test a little more)
     old = {k: os.environ.get(k) for k in env}

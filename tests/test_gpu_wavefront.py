@@ -16,6 +16,13 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 WALK_64B = {"NORI_HIP_WF_NO_ASM_LOOP": 1}      # wf_extend on the 64-B nodes (the compiler's loop), the megakernel's tree form
 
 
+def _budget(wf, n):
+    """Batches of n camera samples on a pool of n paths: every batch starts all its samples in its first pass (the shrinking
+    schedule).  wavefront_paths alone bounds the POOL: a batch bigger than it regenerates (test_regeneration_*)."""
+    wf.set_option("wavefront_paths", n)
+    wf.set_option("wavefront_samples", n)
+
+
 def _pair(renderer_factory, sc):
     mk = renderer_factory(sc)
     wf = renderer_factory(sc)
@@ -54,11 +61,11 @@ def test_wavefront_batching_and_splits(renderer_factory):
     mk, wf = _pair(renderer_factory, sc)
     whole, st = mk.render_host()
     for budget in (256 * 15 * 5, 256 * 4, 256):        # 5 spp per batch; 4 tiles per batch; 1 tile per batch
-        wf.set_option("wavefront_paths", budget)
+        _budget(wf, budget)
         b, sb = wf.render_host()
         np.testing.assert_allclose(b, whole, rtol=1e-4, atol=1e-5)
         assert sb["n_closest_rays"] == st["n_closest_rays"]
-    wf.set_option("wavefront_paths", 1 << 20)
+    _budget(wf, 1 << 20)
     parts = sum(wf.render_host(tile_mod=4, tile_rem=k)[0] for k in range(4))
     np.testing.assert_allclose(parts, whole, rtol=1e-4, atol=1e-5)
     parts = wf.render_host(spp_count=5, spp_begin=0)[0] + wf.render_host(spp_count=7, spp_begin=5)[0]
@@ -157,7 +164,7 @@ def test_cus_split_between_traversal_and_shading_give_the_same_frame(renderer_fa
             assert sr[k] == sb[k], (cus, k)
     # several batches per pipe (a small path budget), and the tail kernel off.  (The film adds a pixel's samples batch by batch:
     # the frame to compare with is the one of two pipes with the same budget on ONE stream.)
-    wf.set_option("wavefront_paths", 1 << 16)
+    _budget(wf, 1 << 16)
     ref2, sr2 = _with_env({"NORI_HIP_WF_PIPES": 2}, lambda: wf.render_host())
     for env in ({}, {"NORI_HIP_WF_FINISH": 0}, {"NORI_HIP_WF_SYNC_EVERY": 1}):
         b, sb = _with_env({"NORI_HIP_WF_SPLIT_CUS": 48, "NORI_HIP_WF_SPLIT_MIN": 0, **env}, lambda: wf.render_host())
@@ -174,7 +181,7 @@ def test_tail_of_a_batch_beside_the_next_batch_gives_the_same_frame(renderer_fac
     wf = renderer_factory(sc)
     wf.set_option("engine", "wavefront")
     for budget in (160 * 128 * 5, 256 * 12, 1 << 20):      # 3 sample batches of all tiles; tile batches; one batch (nothing to overlap)
-        wf.set_option("wavefront_paths", budget)
+        _budget(wf, budget)
         ref, sr = _with_env({"NORI_HIP_WF_TAIL_CUS": 0}, lambda: wf.render_host())
         assert sr["tail_cus"] == 0 and sr["tail_ms"] == 0.0
         for cus in (8, 32, 64):
@@ -196,17 +203,87 @@ def test_tail_of_a_batch_beside_the_next_batch_gives_the_same_frame(renderer_fac
     wf = renderer_factory(sc, builder=1)
     wf.set_option("engine", "wavefront")
     assert wf.accel_info()["max_depth"] + 1 > 16
-    wf.set_option("wavefront_paths", 80 * 56 * 2)
+    _budget(wf, 80 * 56 * 2)
     ref, sr = _with_env({"NORI_HIP_WF_TAIL_CUS": 0}, lambda: wf.render_host())
     b, sb = _with_env({"NORI_HIP_WF_TAIL_CUS": 16}, lambda: wf.render_host())
     assert np.array_equal(b, ref) and sb["tail_cus"] == 16
     assert sr["n_closest_rays"] == sb["n_closest_rays"] and sr["n_shadow_rays"] == sb["n_shadow_rays"]
 
 
+def test_regeneration_gives_the_bits_of_the_shrinking_schedule(renderer_factory):
+    """A batch bigger than the pool (wavefront_paths < its camera samples) starts its samples pass by pass: a pass works on the
+    stored survivors plus as many new camera samples as fill the pool (wavefront.hip, pass_shape), neither kernel stores the first
+    vertex of a new path.  Which pass a sample starts in is not observable -- pcg32 streams are per (pixel, sample), radiance goes to
+    the film store at the sample's own index, the film adds a pixel's samples batch by batch --: the frame and the ray counts of
+    the same batches on a pool that holds a whole batch, bit for bit, for any pool size and readback cadence."""
+    sc = scenes.cornell_box(160, 128, 12, "path_mis", sphere_bsdfs=[Bsdf("mirror"), Bsdf("dielectric")])
+    wf = renderer_factory(sc)
+    wf.set_option("engine", "wavefront")
+    n_samples = 160 * 128 * 12
+    ref, sr = wf.render_host()                                # one batch, every sample started in the first pass
+    # (node / triangle tests are compared on ONE tree form: wf_finish walks the 64-B nodes, and how many paths it ends depends on the pool)
+    ref64, sr64 = _with_env(WALK_64B, lambda: wf.render_host(count_traversal=True))
+    assert sr["n_camera_samples"] == n_samples and np.array_equal(ref64, ref)
+    wf.set_option("wavefront_samples", 1 << 30)               # the batch stays the frame whatever the pool
+    for pool in (256, 1000, 256 * 37, 1 << 16, n_samples - 256):
+        wf.set_option("wavefront_paths", pool)
+        for env in ({}, {"NORI_HIP_WF_SYNC_EVERY": 1}, {"NORI_HIP_WF_FINISH": 0}, {"NORI_HIP_WF_FORCE_MIXED": 1}, WALK_64B):
+            b, sb = _with_env(env, lambda: wf.render_host(count_traversal=env is WALK_64B))
+            assert np.array_equal(b, ref), (pool, env)
+            for k in ("n_camera_samples", "n_closest_rays", "n_shadow_rays", "n_invalid") + (("n_node_tests", "n_tri_tests") if env is WALK_64B else ()):
+                assert sr64[k] == sb[k], (pool, env, k, sr64[k], sb[k])
+    # the kMixed kernels on a batch that fits the pool (every pass after the first has nothing new to start): same bits
+    wf.set_option("wavefront_paths", 1 << 29)
+    b, sb = _with_env({"NORI_HIP_WF_FORCE_MIXED": 1}, lambda: wf.render_host())
+    assert np.array_equal(b, ref) and sb["n_shadow_rays"] == sr["n_shadow_rays"]
+    # several batches (3 sample batches of all tiles; tile batches), each regenerating, tails beside the next batch or not
+    for batch in (160 * 128 * 5, 256 * 12):
+        _budget(wf, batch)
+        ref2, sr2 = _with_env({"NORI_HIP_WF_TAIL_CUS": 0}, lambda: wf.render_host())
+        np.testing.assert_allclose(ref2, ref, rtol=1e-4, atol=1e-5)
+        for pool in (256, batch // 3):
+            wf.set_option("wavefront_paths", pool)
+            for cus in (0, 32):
+                b, sb = _with_env({"NORI_HIP_WF_TAIL_CUS": cus}, lambda: wf.render_host())
+                assert np.array_equal(b, ref2), (batch, pool, cus)
+                assert sb["tail_cus"] == cus
+                for k in ("n_camera_samples", "n_closest_rays", "n_shadow_rays"):
+                    assert sr2[k] == sb[k], (batch, pool, cus, k)
+    # reference film order: the whole frame is one batch whatever the pool and whatever wavefront_samples says
+    wf.set_option("wavefront_samples", 0)
+    wf.set_option("wavefront_paths", 1 << 29)
+    wf.set_option("film_order", "reference")
+    fr, _ = wf.render_host()
+    wf.set_option("wavefront_paths", 256 * 9)
+    assert np.array_equal(wf.render_host()[0], fr)
+
+
+def test_regeneration_on_wide_and_deep_trees(renderer_factory):
+    """The same through the other traversal kernels: wide (BVH4) nodes, and a tree deeper than the LDS stack (spill columns)."""
+    sc = scenes.soup_scene(30000, seed=3, width=80, height=56, integrator="path_mis")
+    sc.sample_count = 6
+    from nori_amd.scene import Mesh
+    v, f = scenes.quad((-3, 3, -3), (3, 3, -3), (3, 3, 3), (-3, 3, 3))
+    sc.meshes.append(Mesh(v, f, bsdf=Bsdf("diffuse", (0, 0, 0)), radiance=(5.0, 5.0, 5.0), name="light"))
+    for layout, builder in (("bvh4q", 0), ("bvh2", 1)):
+        from nori_amd.render import Renderer
+        wf = Renderer(0); wf.set_option("accel_layout", layout); wf.upload(sc, builder=builder); wf.set_option("engine", "wavefront")
+        assert wf.accel_info()["max_depth"] + 1 > 16 or layout == "bvh4q"
+        ref, sr = wf.render_host()
+        wf.set_option("wavefront_samples", 1 << 30)
+        for pool in (256 * 3, 80 * 56 * 2):
+            wf.set_option("wavefront_paths", pool)
+            b, sb = wf.render_host()
+            assert np.array_equal(b, ref), (layout, pool)
+            assert sr["n_closest_rays"] == sb["n_closest_rays"] and sr["n_shadow_rays"] == sb["n_shadow_rays"], (layout, pool)
+        wf.close()
+
+
 def test_out_of_memory_for_the_path_state_means_smaller_batches(renderer_factory):
     """The number of paths in flight is bounded by what hipMemGetInfo reports free -- a snapshot another context may have spent by the
-    time the pool is allocated.  The render call then halves its batches until the state fits (nori_hip.hip) instead of failing:
-    same frame as with the budget that fits from the start (same batches), and OUT_OF_MEMORY only when nothing fits."""
+    time the pool is allocated.  The render call then gives back what it holds and halves the POOL until the state fits
+    (nori_hip.hip) instead of failing: the batch -- hence the frame, bit for bit -- stays what it was (the paths of the batch
+    start pass by pass on the smaller pool), and OUT_OF_MEMORY only when nothing fits."""
     import torch
     sc = scenes.cornell_box(1024, 1024, 48, "path_mis")          # 50 M paths x 236 B = 11.9 GB of state + sample store in one batch
     wf = renderer_factory(sc)
@@ -223,8 +300,7 @@ def test_out_of_memory_for_the_path_state_means_smaller_batches(renderer_factory
         torch.cuda.empty_cache()
     wf2 = renderer_factory(sc)
     wf2.set_option("engine", "wavefront")
-    wf2.set_option("wavefront_paths", 1 << 24)       # what the halving arrives at: 2^29 -> 2^24 (16.7 M paths = 4 GB)
-    ref, sr = wf2.render_host()
+    ref, sr = wf2.render_host()                      # one batch, all its samples started in the first pass (12 GB of state)
     assert np.array_equal(got, ref)
     assert sr["n_closest_rays"] == st["n_closest_rays"] and sr["n_shadow_rays"] == st["n_shadow_rays"]
 
@@ -335,7 +411,7 @@ def test_contexts_own_their_buffers():
     B1, _ = b.render_host()
     A2, _ = a.render_host()
     assert np.array_equal(A1, A2)
-    b.set_option("wavefront_paths", 256 * 7)          # b regrows / rebatches its own pool; a is untouched
+    _budget(b, 256 * 7)          # b regrows / rebatches its own pool; a is untouched
     B2, _ = b.render_host()
     np.testing.assert_allclose(B2, B1, rtol=1e-4, atol=1e-5)
     assert np.array_equal(a.render_host()[0], A1)
@@ -410,7 +486,7 @@ def test_device_group_errors_and_one_rank_rccl(tmp_path):
     r = Renderer(0).upload(sc)
     lib = _capi.load_hip()
     import ctypes as C
-    for key, value in (("engine", "wavefront"), ("film_order", "reference"), ("accel_layout", "bvh4q"), ("wavefront_paths", "4096")):
+    for key, value in (("engine", "wavefront"), ("film_order", "reference"), ("accel_layout", "bvh4q"), ("wavefront_paths", "4096"), ("wavefront_samples", "65536")):
         r.set_option(key, value)
         buf = C.create_string_buffer(32)
         assert lib.nori_hip_get_option(r._h, key.encode(), buf, 32) == 0 and buf.value.decode() == value

@@ -13,7 +13,7 @@ e = Emu(sc); lib = emu_lib()
 lib.emu_wave_sim.restype = C.c_int
 COST = dict(node=51, leaf=100, refill=130, trip=50, pend=60)      # VALU instructions per wave-level event (ISA of the shipped kernel: the hand-written node loop on 32-B records; a trip includes the 24 of the ray's plane coefficients)
 def run(name, refill=32, leaf=16, inner=24, postpone=0, chunk=1024, sort=0, pend=0, pretest=0):
-    pol = (C.c_int * 8)(refill, leaf, inner, postpone, chunk, sort, pend, pretest)
+    pol = (C.c_int * 12)(refill, leaf, inner, postpone, chunk, sort, pend, pretest, 1, 0, 0, 0)      # [8..11]: tile stride, sort window, key kind, cell bits (emu_wave_sim)
     out = np.zeros((nl, 16), np.uint64)
     n = lib.emu_wave_sim(e._h, C.c_uint32(spp), C.c_uint32(nl), pol, out.ctypes.data_as(C.c_void_p))
     tot = out[:min(n, nl)].sum(axis=0).astype(np.float64)
