@@ -151,6 +151,25 @@ def measured_counters(workload: str, engine: str):
     return best
 
 
+def bound_evidence(workload: str):
+    """What binds wf_extend on this workload, MEASURED on this build (tools/collect_bound_evidence.sh -> tools/bound_evidence.py ->
+    profiles/*_bound_evidence.json): VALU busy from the dynamic instruction mix (an interval), and what one more load, 16 / 32 more
+    v_mov or 64 idle cycles per node step cost.  None if no file of this build names the workload."""
+    sha = device_source_sha()
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bound_evidence.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if d.get("device_source_sha") != sha:
+            continue
+        for cfg in d.get("configs", {}).values():
+            if cfg.get("workload") == workload:
+                best = (f, cfg)
+    return best
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -290,18 +309,31 @@ def main():
         # reads are gathers of node / leaf records plus the path state they stream -- known bytes, which the counter saw once
         # instead of twice.  `traffic_streaming_rule` = every read priced as a stream (rounds 1 - 4 reported that one).
         traffic_stream_rule = ctr[1].get("dominant_kernel_hbm_bytes") if ctr else None
-        traffic = ctr[1].get("dominant_kernel_hbm_bytes_gather_rule") if ctr else None
-        if traffic is not None:
+        traffic_counter = ctr[1].get("dominant_kernel_hbm_bytes_gather_rule") if ctr else None      # FETCH_SIZE x 1 + WRITE_SIZE: the counters alone
+        traffic_correction = None
+        if traffic_counter is not None:
             streamed_reads = rec_bytes - counted["n_closest_rays"] * 16 if engine == "wavefront" else 0      # (the 16-B hit records are stores)
-            traffic = int(traffic + max(0, streamed_reads) // 2)
+            traffic_correction = int(max(0, streamed_reads) // 2)      # MODELLED: the path state the kernel streams, which FETCH_SIZE counted at half
+            traffic = int(traffic_counter + traffic_correction)
         else:
             traffic = traffic_stream_rule
         fr_hbm_measured = traffic / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic else None
-        # which roof binds: the counters of this build if they are committed (share of SIMD time issuing VALU vs share of the
-        # HBM peak actually moved), else the structural rule: a cache-resident tree cannot be HBM bound
-        if cd.get("valu_busy_frac") is not None and fr_hbm_measured is not None:
-            bound = "valu" if cd["valu_busy_frac"] >= fr_hbm_measured else "hbm"
-            near_both = abs(cd["valu_busy_frac"] - fr_hbm_measured) < 0.2      # the kernel sits against both roofs: say so (roof["bound_detail"])
+        valu_model = cd.get("valu_busy_model", cd.get("valu_busy_frac"))
+        # which roof binds.  Measured evidence of THIS build first (profiles/*_bound_evidence.json: what one more load / 16 - 32 more
+        # v_mov / 64 idle cycles per node step cost, normalised by what they add): the memory side if a load costs more than the
+        # VALU instructions do, else the vector ALU.  Without it: the modelled VALU busy against the measured HBM share, and
+        # without counters the structural rule (a cache-resident tree cannot be HBM bound).
+        ev = bound_evidence(wl.name) if engine == "wavefront" else None
+        near_both = False
+        if ev:
+            v = ev[1]["variants"]
+            s_valu = sum(v["valu"]["sensitivity_lo_hi"]) / 2.0
+            s_mem = v["load"].get("sensitivity") or 0.0
+            bound = "hbm" if s_mem > s_valu else "valu"
+            near_both = abs(s_mem - s_valu) < 0.1
+        elif valu_model is not None and fr_hbm_measured is not None:
+            bound = "valu" if valu_model >= fr_hbm_measured else "hbm"
+            near_both = abs(valu_model - fr_hbm_measured) < 0.2      # the kernel sits against both roofs: say so (roof["bound_detail"])
         else:
             bound = "valu" if (cache_resident or fr_hbm > 1.0) else "hbm"
         roof = {"kernel": dom_name, "kernel_ms": round(t_ms, 3), "launches": int(trace_launches), "bound": bound,
@@ -312,15 +344,17 @@ def main():
                          "algorithmic_ops": int(ops),
                          "note": "VALU-issue bound (%s); ops = %d per node test + %d per triangle test + %d per ray (f32 vector operations as "
                                  "written in rt_trace.h), peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"
-                                 % ("BVH of %.1f MB is L2 / Infinity-Cache resident" % (info["total_bytes"] / 1e6) if cache_resident
-                                    else "counters: VALU busy %.2f of its cycles, HBM at %.2f of its peak" % (cd["valu_busy_frac"], fr_hbm_measured) if cd.get("valu_busy_frac") is not None and fr_hbm_measured is not None
+                                 % ("measured: " + ev[1]["verdict_from"] if ev
+                                    else "BVH of %.1f MB is L2 / Infinity-Cache resident" % (info["total_bytes"] / 1e6) if cache_resident
+                                    else "counters: VALU busy %.2f of its cycles (model), HBM at %.2f of its peak" % (valu_model, fr_hbm_measured) if valu_model is not None and fr_hbm_measured is not None
                                     else "algorithmic bytes exceed what HBM can deliver: part of them is cache-served" + (" (measured HBM traffic: %.2f of the peak -- about %.2f of what a copy reaches; this walk sits close to both roofs)" % (fr_hbm_measured, fr_hbm_measured / 0.79) if fr_hbm_measured is not None else ""),
                                     ops_node, OPS_TRI, OPS_RAY)})
         else:
             roof.update({"achieved": round(hbm_alg, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fr_hbm, 5),
                          "algorithmic_bytes": int(trav_bytes + rec_bytes),
                          "note": "algorithmic bytes per SURVEY 8(d): N_node x %d + N_tri x %d + ray / hit records; the BVH (%.0f MB) "
-                                 "exceeds L2 + Infinity Cache" % (node_record_bytes, info["tri_bytes"], info["total_bytes"] / 1e6)})
+                                 "exceeds L2 + Infinity Cache%s" % (node_record_bytes, info["tri_bytes"], info["total_bytes"] / 1e6,
+                                                                     "; measured: " + ev[1]["verdict_from"] if ev else "")})
         roof["valu_frac"], roof["hbm_algorithmic_frac"] = round(fr_valu, 5), round(fr_hbm, 5)
         # the three ways to price the same traversal work (all <= 1): `valu_frac` = textbook operation count (52 / 54 / 9) against
         # one lane-operation per lane per clock; `flop_frac` = the same count against the f32 FLOP peak (packed FMA: 4 flops
@@ -333,16 +367,29 @@ def main():
         roof["flop_frac"] = round(ops / (t_ms * 1e-3) / 1e12 / FLOP_PEAK_TFLOPS, 5)
         roof["issued_valu_instr"] = int(issued)
         roof["issued_frac"] = round(issued / (t_ms * 1e-3) / VALU_ISSUE_SLOTS, 5)
+        # `traffic` is an ESTIMATE: the counter figure (record gathers priced 1 : 1) + a modelled correction for the path state the
+        # kernel streams, which FETCH_SIZE counts at half; both parts beside it
         roof["traffic"] = traffic
+        if traffic_counter is not None:
+            roof["traffic_counter"], roof["traffic_stream_correction_modelled"] = traffic_counter, traffic_correction
         if traffic_stream_rule is not None and traffic_stream_rule != traffic:
             roof["traffic_streaming_rule"] = traffic_stream_rule
-        if cd.get("valu_busy_frac") is not None and fr_hbm_measured is not None:
+        if ev or (valu_model is not None and fr_hbm_measured is not None):
             roof["bound_detail"] = "valu+hbm" if near_both else bound
+        if ev:
+            c = ev[1]
+            roof["bound_evidence"] = {"source": os.path.relpath(ev[0], ROOT), "verdict": c["verdict"],
+                                      "valu_busy_measured_lo_hi": c["valu_busy_measured_lo_hi"], "valu_lanes_per_instr": c["valu_lanes_per_instr"],
+                                      "valu_sensitivity_lo_hi": c["variants"]["valu"]["sensitivity_lo_hi"], "vmem_read_sensitivity": c["variants"]["load"].get("sensitivity"),
+                                      "cost_of_64_idle_cycles_per_node_step": c["variants"]["idle"]["dt_over_t"],
+                                      "cost_of_more_valu_per_node_step": c["variants"]["valu"]["dt_over_t"], "cost_of_one_more_load_per_node_step": c["variants"]["load"]["dt_over_t"]}
         if ctr:
             roof["traffic_source"] = os.path.relpath(ctr[0], ROOT)
             if fr_hbm_measured is not None:
                 roof["hbm_measured_frac"] = round(fr_hbm_measured, 5)
-            for k in ("valu_busy_frac", "valu_cycles_per_instr", "valu_lanes_per_instr", "valu_useful_frac", "l2_hit_rate"):
+            if valu_model is not None:
+                roof["valu_busy_model"] = valu_model      # static instruction mix x cycles per class; the measured interval: bound_evidence
+            for k in ("valu_cycles_per_instr", "valu_lanes_per_instr", "valu_useful_frac", "l2_hit_rate"):
                 if k in cd:
                     roof[k] = cd[k]
         out = {

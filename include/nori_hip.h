@@ -32,6 +32,15 @@
 extern "C" {
 #endif
 
+/* The structs below that the LIBRARY writes (nori_render_stats, nori_accel_info) grow with the library: they carry no size
+ * field, the library fills sizeof(its own struct).  Header and library must therefore be of ONE version: a caller compares
+ * nori_hip_abi_version() -- what the loaded library was built from -- with the NORI_HIP_ABI_VERSION it was compiled against
+ * before its first call that passes such a struct, and refuses to go on if they differ (the host library and the Python
+ * bindings of this repository do).  Bumped whenever a struct of this header changes size or layout, an enum value changes
+ * meaning, or an entry point changes its signature. */
+#define NORI_HIP_ABI_VERSION 6      /* round 6: nori_render_stats as of round 5 (tail_ms, tail_cus); option "wavefront_samples" */
+int nori_hip_abi_version(void);
+
 /* ------------------------------------------------------------------ enums */
 
 typedef enum nori_status {

@@ -111,8 +111,11 @@ assert RAY_DTYPE.itemsize == 32 and ITS_DTYPE.itemsize == 104
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
 
+HIP_ABI_VERSION = 6      # NORI_HIP_ABI_VERSION of the include/nori_hip.h these ctypes structs mirror
+
 #: every symbol include/nori_hip.h declares -> (restype, argtypes)
 HIP_PROTOTYPES = {
+    "nori_hip_abi_version": (C.c_int, []),
     "nori_hip_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "nori_hip_destroy": (None, [_P]),
     "nori_hip_last_error": (C.c_char_p, [_P]),
@@ -177,7 +180,11 @@ def load_hip():
         if not os.path.exists(path):
             raise NoriError(f"{path} not found: build it with `python __graft_entry__.py` "
                             "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        _hip = bind(C.CDLL(path, mode=C.RTLD_GLOBAL), HIP_PROTOTYPES)
+        lib = bind(C.CDLL(path, mode=C.RTLD_GLOBAL), HIP_PROTOTYPES)
+        # the structs above mirror include/nori_hip.h of ONE version: a library built from another would write past them
+        if lib.nori_hip_abi_version() != HIP_ABI_VERSION:
+            raise NoriError(f"{path} reports ABI version {lib.nori_hip_abi_version()}, these bindings are written for {HIP_ABI_VERSION} (include/nori_hip.h): rebuild")
+        _hip = lib
     return _hip
 
 

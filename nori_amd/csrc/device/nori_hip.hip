@@ -500,6 +500,8 @@ struct DeviceGuard {
 
 extern "C" {
 
+int nori_hip_abi_version(void) { return NORI_HIP_ABI_VERSION; }
+
 int nori_hip_create(int device, nori_hip_ctx **out) {
     if (!out) return NORI_ERR_INVALID_ARGUMENT;
     *out = nullptr;

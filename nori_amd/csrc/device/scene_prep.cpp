@@ -436,6 +436,37 @@ static void build_tree_spatial(const HostScene &sc, const std::vector<Box> &boxe
    hold are taken out of the tree one batch at a time and their two subtrees re-inserted where the tree's SAH cost grows least
    (branch-and-bound search from the root).  Leaves stay as they are (their triangles, their order); node 0 stays the root.
    depth_limit: no leaf may end up deeper (the traversal stack; for small trees the LDS-only stack of wf_extend). */
+/* Stack entries a walk of the WIDE form of this tree can need (build_bvh_sah's collapse: every node adopts grandchildren -- the
+   inner child of largest area first -- until it has four children; three pushes per wide level).  The same adoption rule as the
+   flattening below, depths only: what decides whether an optimised tree is still walkable before it replaces the one that was. */
+static uint32_t wide_stack_depth(const std::vector<BuildNode> &bn) {
+    if (bn.empty() || bn[0].left < 0) return 0;
+    uint32_t wideDepth = 0;
+    std::vector<std::pair<int32_t, uint32_t>> todo;      /* (build node, wide depth) */
+    todo.emplace_back(0, 0u);
+    while (!todo.empty()) {
+        const int32_t b = todo.back().first; const uint32_t depth = todo.back().second; todo.pop_back();
+        int32_t kid[4] = {bn[b].left, bn[b].right, -1, -1}; int n = 2;
+        while (n < 4) {
+            int best = -1; float bestArea = -1.0f;
+            for (int k = 0; k < n; ++k) {
+                if (bn[kid[k]].left < 0) continue;
+                float a = bn[kid[k]].box.area();
+                if (!(a < kInf)) a = kInf;
+                if (a > bestArea) { bestArea = a; best = k; }
+            }
+            if (best < 0) break;
+            const int32_t c = kid[best];
+            kid[best] = bn[c].left; kid[n++] = bn[c].right;
+        }
+        for (int k = 0; k < n; ++k) {
+            if (bn[kid[k]].left < 0) wideDepth = std::max(wideDepth, depth + 1);
+            else todo.emplace_back(kid[k], depth + 1);
+        }
+    }
+    return 3 * wideDepth;
+}
+
 static void optimize_tree_reinsertion(std::vector<BuildNode> &bn, uint32_t depth_limit, int passes, float batch_frac) {
     const int n = (int) bn.size();
     if (n < 7) return;
@@ -836,11 +867,16 @@ std::string build_bvh_sah(const HostScene &sc, uint32_t max_depth_limit, HostBvh
             for (const BuildNode &nd : bn) if (nd.left < 0) deepest = std::max(deepest, nd.depth);
             const double before = innerArea();
             std::vector<BuildNode> kept = bn;
-            /* depth: what the tree has, at least the 15 levels wf_extend's LDS-only stack holds, never beyond the traversal stack */
+            /* depth: what the tree has, at least the 15 levels wf_extend's LDS-only stack holds, never beyond the traversal stack.
+               A wide (BVH4) layout is walked with three pushes per wide level, and which BVH2 levels disappear in the collapse
+               follows the boxes' areas: the optimised tree is kept only if its wide form is still within the stack -- a tree
+               that was walkable before the optimisation stays walkable (the one that was is kept otherwise). */
             optimize_tree_reinsertion(bn, std::min(std::max(deepest, 15u), max_depth_limit - 1), passes, 0.02f);
             const double after = innerArea();
-            if (timing) fprintf(stderr, "[sah] re-insertion: inner area %.6g -> %.6g (%+.1f %%)%s\n", before, after, 100.0 * (after / before - 1.0), after <= 0.98 * before ? "" : " -- not kept");
-            if (!(after <= 0.98 * before)) bn.swap(kept);
+            const bool too_deep = wide && wide_stack_depth(bn) + 1 > max_depth_limit && wide_stack_depth(kept) + 1 <= max_depth_limit;
+            if (timing) fprintf(stderr, "[sah] re-insertion: inner area %.6g -> %.6g (%+.1f %%)%s\n", before, after, 100.0 * (after / before - 1.0),
+                                too_deep ? " -- its wide form is deeper than the traversal stack: not kept" : after <= 0.98 * before ? "" : " -- not kept");
+            if (!(after <= 0.98 * before) || too_deep) bn.swap(kept);
             lap("reinsert");
         }
     }

@@ -411,6 +411,8 @@ __device__ __forceinline__ bool bvh2q_node_loop_asm(int &node_io, uint32_t &stac
         "v_add_u32 %[sp], %[stride], %[sp]\n\t" \
         "s_andn2_b64 exec, %[inner], %[u]\n\t" \
         "v_subrev_u32 %[sp], %[stride], %[sp]\n\t" \
+        /* (the pop requested at the START of the step, with the node's record -- its link is dead by then -- so that no LDS trip ends \
+           the step: bit-identical and no faster, headline 41.4 against 41.7 ms, profiles/r6_04_early_pop_ab.txt) */ \
         "ds_read_b32 %[node], %[sp]\n\t" \
         "s_mov_b64 exec, %[all]\n\t" \
         "s_waitcnt lgkmcnt(0)\n\t" \
@@ -672,8 +674,11 @@ template <> struct ShadeTab<true> { typedef LdsTables type; static __device__ __
 /* MATSET (rt_path.h): the BSDF types the scene contains -- the kernel of an all-diffuse scene carries no mirror, dielectric or
    microfacet code (the all-diffuse kernel: 117 registers instead of 128; held to the 96 of five workgroups per CU it spills and is
    slower, profiles/r5_01_shade_matset_ab.txt) */
+#ifndef NORI_SHADE_WGS
+#define NORI_SHADE_WGS 4      /* workgroups per SIMD wf_shade is compiled for (variant builds: 5, 6) */
+#endif
 template <int INTEG, int MODE, bool LDSTAB, int MATSET>
-__global__ __launch_bounds__(kSB, 4) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
+__global__ __launch_bounds__(kSB, NORI_SHADE_WGS) void wf_shade(DevScene sc, WfBuf b, int cur, WfBatch bt) {
     NORI_LAB_SHADE_PAD
     const WfState S = b.st[cur], D = b.st[cur ^ 1];
     const uint32_t s_first = bt.s_first, n_spp = bt.n_spp;

@@ -20,6 +20,10 @@ Device::Device(int device) {
         device = e ? std::atoi(e) : 0;
     }
     m_device = device;
+    /* the structs the library fills carry no size field: header and library must be of one version (include/nori_hip.h) */
+    if (nori_hip_abi_version() != NORI_HIP_ABI_VERSION)
+        throw NoriException("libnori_hip reports ABI version %i, this host was compiled against %i (include/nori_hip.h): rebuild both",
+                            nori_hip_abi_version(), NORI_HIP_ABI_VERSION);
     int rc = nori_hip_create(device, &m_ctx);
     if (rc != NORI_OK)
         throw NoriException("Unable to create a HIP context on device %i: %s (the MI355X path has no CPU fallback)",

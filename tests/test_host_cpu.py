@@ -27,6 +27,10 @@ def test_hip_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) == set(_capi.HIP_PROTOTYPES)
+    # one version of header, library and bindings (the structs the library fills carry no size field)
+    import re
+    declared = int(re.search(r"#define NORI_HIP_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "nori_hip.h")).read()).group(1))
+    assert lib.nori_hip_abi_version() == declared == _capi.HIP_ABI_VERSION
 
 
 def test_host_library_exports_every_declared_symbol():

@@ -4,10 +4,11 @@ reads for `roofline.traffic` and the VALU-issue evidence.   usage: python tools/
 Derived per kernel (MI355X_MICROARCH.md: SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles; FETCH_SIZE reads half of a wide
 coalesced stream on gfx950 -> doubled; counters are summed over the chip):
   elapsed_cycles       GRBM_GUI_ACTIVE / 8 XCDs                         (cross-check: SQ_BUSY_CYCLES / 32 shader engines)
-  valu_busy_frac       SQ_INSTS_VALU x cycles_per_instr / (1024 SIMDs x elapsed_cycles)   share of SIMD time the VALU is occupied.
+  valu_busy_model      SQ_INSTS_VALU x cycles_per_instr / (1024 SIMDs x elapsed_cycles)   share of SIMD time the VALU is occupied -- a MODEL:
                        SQ_ACTIVE_INST_VALU counts one unit per instruction, not its cycles (profiles/r3_valu_counter_calibration.txt);
                        cycles_per_instr = the kernel's instruction mix x the measured cycles per class (tools/valu_mix.py ->
-                       profiles/*_valu_mix.json; 3.3 when no mix is on file).  <= 1 for any kernel that really runs.
+                       profiles/*_valu_mix.json; 3.3 when no mix is on file), every instruction of the kernel text weighted equally; not
+                       clamped.  The measured counterpart (dynamic mix by class, sensitivities) is tools/bound_evidence.py.
   valu_lanes_per_instr SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU                  active lanes per VALU instruction (of 64)
   valu_useful_frac     valu_busy_frac x lanes / 64                                  share of VALU lane-cycles doing work
   hbm_bytes            (2 x FETCH_SIZE + WRITE_SIZE) x 1024 -- the guide's rule, calibrated on wide coalesced streams (film_gather).
@@ -74,11 +75,13 @@ def derive(c, kernel=None):
     if el > 0 and insts is not None:
         cyc = MIX.get(kernel, {}).get("cycles_per_instr", 3.3)
         out["valu_cycles_per_instr"] = cyc
-        out["valu_busy_frac"] = round(min(1.0, insts * cyc / (1024.0 * el)), 4)
+        # a MODEL (static instruction mix x cycles per class), not clamped: above 1 it says the model overprices the mix
+        # (the measured counterpart: tools/bound_evidence.py, valu_busy_measured_lo_hi)
+        out["valu_busy_model"] = round(insts * cyc / (1024.0 * el), 4)
     if c.get("SQ_ACTIVE_INST_VALU"):
         out["valu_lanes_per_instr"] = round(c.get("SQ_THREAD_CYCLES_VALU", 0.0) / c["SQ_ACTIVE_INST_VALU"], 2)
-    if "valu_busy_frac" in out and "valu_lanes_per_instr" in out:
-        out["valu_useful_frac"] = round(out["valu_busy_frac"] * out["valu_lanes_per_instr"] / 64.0, 4)
+    if "valu_busy_model" in out and "valu_lanes_per_instr" in out:
+        out["valu_useful_frac"] = round(min(1.0, out["valu_busy_model"]) * out["valu_lanes_per_instr"] / 64.0, 4)
     if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
         out["hbm_bytes"] = int((2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024)
         out["hbm_bytes_gather_rule"] = int((c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024)
