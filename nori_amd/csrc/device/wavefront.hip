@@ -818,7 +818,8 @@ __global__ __launch_bounds__(kSB, NORI_SHADE_WGS) void wf_shade(DevScene sc, WfB
    is no faster, profiles/r4_04_tail_per_vertex_ab.txt.  Nor does walking through
    the LDS image of the hot records help here -- pa5 table, 64 spp: 44.9 against 42.0 ms of shade time, a 1/8 share of the Cornell
    box 3.99 against 3.56: 2048 workgroups each copy 12 KB for a few hundred paths, and the C++ form of the 32-B node step pays 24
-   instructions per step for the ray's plane coefficients.) */
+   instructions per step for the ray's plane coefficients.  Round 6, on the small persistent grid, through the image of the 64-B nodes:
+   bit-identical and no faster either -- a path inside the glass sphere walks the BOTTOM of the tree --, profiles/r6_06_finish_image_ab.txt.) */
 /* The lanes of a small persistent grid pull paths one by one -- a lane whose path has ended takes the next unclaimed one at the top
    of the vertex loop (one atomic per wave and refill), so a wave's lanes stay busy while paths are left and all of them are at the
    same stage of a vertex.  (Round 4's form -- one lane per path, a grid of finish_paths lanes -- ran at 6.5 of 64 lanes: pa5 table
