@@ -446,8 +446,9 @@ int nori_hip_develop(nori_hip_ctx *ctx, const void *d_rgbw, void *d_rgb,
  * sample indices each.  Merges: NORI_MERGE_REDUCE = ncclReduce(sum) of the whole frames, NORI_MERGE_GATHER (tile split,
  * tile columns divisible by the device count) = every device sends only the column strips its tiles touched.
  * A device list that names a device more than once is served without RCCL (peer copies) -- for tests on one GPU; so is a
- * node whose librccl cannot be loaded (nori_hip_group_warning says so).  A fresh RCCL group proves its communicators with
- * a small reduce of a known pattern before nori_hip_group_create returns.  With film_order = reference on its contexts a
+ * node whose librccl cannot be loaded (nori_hip_group_warning says so).  A fresh RCCL group proves its communicators before
+ * nori_hip_group_create returns, on a buffer the size of a 2052^2 frame (67 MB): a sum-reduce of a known pattern, then the
+ * gather merge's grouped ncclSend / ncclRecv, both checked on the device.  With film_order = reference on its contexts a
  * group hands out rows of 32x32 blocks instead (whatever `split` says), merges the blocks' accumulators (a reduce of disjoint
  * arrays: exact) and adds them into the frame in BlockGenerator's order on the first device: the frame has the bits of the
  * one-device frame for any number of devices.  NORI_SEED_NORI_BLOCK renders whole frames on one device: a group of more

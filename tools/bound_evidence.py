@@ -1,5 +1,5 @@
 """What binds wf_extend, from measurements only (review of round 5, item 2)  ->  profiles/<tag>_bound_evidence.{json,txt}
-   python tools/bound_evidence.py <dir with the csv / txt files of tools/r6_gpu_calls/r6_run2.sh + r6_run3.sh> <tag>
+   python tools/bound_evidence.py <dir with the csv / txt files tools/collect_bound_evidence.sh wrote> <tag> [output dir, default profiles/]
 
 Two independent measurements per configuration (hl = the headline, c5 = the 10 M-triangle terrain):
  (1) VALU busy from the DYNAMIC instruction mix: rocprofv3 counts the VALU instructions a kernel executed by class
@@ -19,6 +19,7 @@ import collections, csv, json, os, re, sys
 
 d, tag = sys.argv[1], sys.argv[2]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT_DIR = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles")
 CLK_GHZ = 2.4
 CLASSES = ["FMA_F32", "ADD_F32", "MUL_F32", "TRANS_F32", "INT32", "INT64", "CVT"]
 
@@ -132,6 +133,11 @@ for short, wl in (("hl", "pa4-cbox-path_mis"), ("c5", "c5-terrain-10m")):
         why = ("64 idle cycles per node step cost %.1f %% of wf_extend, as much as %d more v_mov (%.1f %%): a wave's own instruction chain, not the SIMD's VALU throughput "
                "(VALU sensitivity %.2f of 1, busy %.2f - %.2f by the dynamic mix), sets the pace -- 8 waves per SIMD (the hardware's maximum) behave like %s"
                % (100 * idle_cost, per_step, 100 * sens["valu"]["dt_over_t"], sv, lo, hi, sens["idle"].get("effective_waves_per_simd")))
+    elif abs(sm - sv) < 0.1:
+        verdict = "valu + vector-memory issue"
+        why = ("throughput-bound on two resources at once: %d more v_mov per node step cost %.1f %% (sensitivity %.2f of 1), one more load (+%.1f %% of the kernel's read instructions) %.1f %% "
+               "(sensitivity %.2f), 64 idle cycles %.1f %% (absorbed: the waves hide latency); VALU busy %.2f - %.2f by the dynamic mix"
+               % (per_step, 100 * sens["valu"]["dt_over_t"], sv, 100 * sens["load"]["added_share_of_vmem_rd"], 100 * sens["load"]["dt_over_t"], sm, 100 * idle_cost, lo, hi))
     elif sm > sv:
         verdict = "vector-memory issue"
         why = ("one more load per node step (+%.1f %% of the kernel's read instructions) costs %.1f %% (sensitivity %.2f), %d more v_mov %.1f %% (sensitivity %.2f), 64 idle cycles %.1f %%: "
@@ -150,6 +156,6 @@ for short, wl in (("hl", "pa4-cbox-path_mis"), ("c5", "c5-terrain-10m")):
               f"   + 64 idle cycles per node step: {sens['idle']['dt_over_t'] * 100:+.1f} % ({sens['idle'].get('ms_if_latency_bound_at_8_waves_per_simd')} ms if latency bound with 8 waves per SIMD to choose from)",
               (f"   without the LDS image: {cfg['no_lds_image_trace_ms']} ms" if "no_lds_image_trace_ms" in cfg else ""),
               f"   => bound: {verdict} -- {why}"]
-json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_bound_evidence.json"), "w"), indent=1)
-open(os.path.join(ROOT, "profiles", f"{tag}_bound_evidence.txt"), "w").write(__doc__ + "\n" + "\n".join(l for l in lines if l) + "\n")
+json.dump(out, open(os.path.join(OUT_DIR, f"{tag}_bound_evidence.json"), "w"), indent=1)
+open(os.path.join(OUT_DIR, f"{tag}_bound_evidence.txt"), "w").write(__doc__ + "\n" + "\n".join(l for l in lines if l) + "\n")
 print("\n".join(l for l in lines if l))
