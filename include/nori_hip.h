@@ -319,8 +319,9 @@ int nori_hip_debug_excursions(nori_hip_ctx *ctx, unsigned long long out[4], int 
  *   "wavefront_samples" camera samples per batch: what the film's sample store holds at a time, 20 B each (twice when a call
  *                     has several batches).  "0" (default): as many as wavefront_paths -- a batch starts all its samples in its
  *                     first pass, the fastest schedule.  A batch bigger than the pool starts its samples pass by pass in the
- *                     slots finished paths leave (regeneration): same frame, bit for bit, ~15 % slower traversal; it is what
- *                     lets an out-of-memory retry shrink the pool and keep the frame, and film_order = reference run on any pool
+ *                     slots finished paths leave (regeneration): same frame, bit for bit, at +2 .. 4 % for half to a quarter of the
+ *                     pool (more below that); it is what lets an out-of-memory retry shrink the pool and keep the frame, and
+ *                     film_order = reference run on any pool
  *   "accel_layout"    node layout of the NEXT nori_hip_build_accel: "bvh2" (64-B node = two full-precision child
  *                     boxes; the wavefront engine walks a second, 32-B form of them, see nori_accel_info) | "bvh4q"
  *                     (64-B node = four child boxes quantised to 8 bits: half the node fetches, for trees that do

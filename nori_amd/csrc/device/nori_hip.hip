@@ -416,7 +416,7 @@ struct nori_hip_ctx {
        bigger batches are cheaper: the table scene at 2048^2 x 1024 spp is 8 batches instead of the 16 of 2^28 */
     size_t wavefront_paths = (size_t) 1 << 29;
     /* camera samples per batch (0: as many as the pool holds paths -- every batch starts all its samples in its first pass, the
-       fastest schedule: profiles/r6_01_pool_sweep.txt): 20 B each in the film's sample store, twice when a call has several
+       fastest schedule: profiles/r6_12_pool_sweep_two_launches.txt): 20 B each in the film's sample store, twice when a call has several
        batches.  A batch bigger than the pool starts its samples pass by pass in the slots finished paths leave (regeneration,
        wavefront.hip): the pool bounds the STATE, this bounds the film store.  What it is for: a context short of memory keeps its
        batches -- hence the bits of its frame -- on a smaller pool (the out-of-memory retry below), and film_order = reference,

@@ -70,7 +70,7 @@ namespace {
 constexpr int kB = 256;
 
 /* counters: path count and dynamic-chunk head per state copy (index + copy), overflow flag */
-enum { C_N = 0, C_HEAD = 2, C_OVERFLOW = 4, C_TAIL_HEAD = 5, C_SAMPLE = 6, C_COUNT = 8 };      /* C_SAMPLE + copy: the batch's next camera sample (regeneration) */
+enum { C_N = 0, C_HEAD = 2, C_OVERFLOW = 4, C_TAIL_HEAD = 5, C_SAMPLE = 6, C_HEAD_FRESH = 8, C_COUNT = 12 };      /* C_SAMPLE + copy: the batch's next camera sample (regeneration); C_HEAD_FRESH + copy: chunk head of the launch that traces a pass's NEW paths */
 enum { S_CAM = 0, S_CLOSEST = 1, S_SHADOW = 2, S_NODES = 3, S_TRIS = 4, S_INVALID = 5, S_COUNT = 8 };
 /* census (COUNT builds, NORI_HIP_CENSUS): wave-level trips of wf_extend's loop and the lanes they used */
 enum { Z_TRIPS = 0, Z_INNER_TRIPS = 1, Z_INNER_LANES = 2, Z_LEAF_TRIPS = 3, Z_LEAF_LANES = 4, Z_REFILLS = 5, Z_REFILL_LANES = 6, Z_COUNT = 8 };
@@ -118,13 +118,16 @@ struct WfBatch {
    size runs on a pool of bt.pool paths, every pass full until the batch's samples run out; with pool >= the batch's samples the
    first pass starts them all and the schedule is the shrinking one of rounds 2 - 5.  Which pass a sample starts in is not
    observable: its pcg32 stream is seeded by (pixel, sample), its radiance goes to the film store at its own index.
-   MODE of a kernel: kStoredOnly no path is new (the batch's samples have all been started: the kernel carries no camera code),
-   kFreshOnly the batch's first pass (no path is stored), kMixed both. */
+   MODE of a kernel: kStoredOnly it works on the stored paths [0, n_s) and carries no camera code; kFreshOnly on the new paths [n_f0, n) and
+   reads no state; kMixed (wf_shade only) on both.  wf_extend exists in the two pure forms only -- one kernel with both refills needs 80 B of scratch
+   and runs 17 % slower (profiles/r6_01_pool_sweep.txt, "mixed kernels") --: a pass that holds stored AND new paths is traced by TWO launches, the
+   stored paths first, then the new ones, each with its own chunk counter; a batch's first pass has only the second, its passes after the last sample
+   only the first. */
 enum { kStoredOnly = 0, kFreshOnly = 1, kMixed = 2 };
 struct PassShape { uint32_t n_s, s0, n_fresh, n_f0, n; };      /* stored paths [0, n_s), new paths [n_f0, n): n_f0 = n_s rounded up to a wf_shade round */
 template <int MODE> __device__ __forceinline__ PassShape pass_shape(const uint32_t *ctr, int cur, const WfBatch &bt) {
     PassShape ps;
-    ps.n_s = MODE == kFreshOnly ? 0u : ctr[C_N + cur];
+    ps.n_s = ctr[C_N + cur];      /* (zero in a batch's first pass: the counters are cleared when it starts) */
     ps.s0 = ctr[C_SAMPLE + cur];
     ps.n_f0 = (ps.n_s + 255u) & ~255u;
     const uint32_t total = bt.n_tiles * 256u * bt.n_spp;
@@ -483,13 +486,19 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (MODE != kStoredOnly ? 5 : 7) : 8) vo
     const TopNodesP top_lds = top_nodes_pointer(top);
     const uint32_t image_address = lds_address(smem) + (uint32_t) (Stack::kLdsEntries * BLOCK * sizeof(int));      /* of top */
     const WfState S = b.st[cur];
-    constexpr bool kFresh = MODE != kStoredOnly, kStored = MODE != kFreshOnly;
+    static_assert(MODE == kStoredOnly || MODE == kFreshOnly, "wf_extend: stored paths and new paths are traced by separate launches");
+    constexpr bool kFresh = MODE == kFreshOnly, kStored = MODE == kStoredOnly;
     const PassShape shape = pass_shape<MODE>(b.ctr, cur, bt);
-    const uint32_t n = shape.n, n_s = shape.n_s;
+    /* this launch's paths: the stored ones, indices [0, n_s), or the new ones, indices first + [0, n_fresh) */
+    const uint32_t n = kFresh ? shape.n_fresh : shape.n_s, first = kFresh ? shape.n_f0 : 0u;
     /* the other copy's counters are free by now (its paths were consumed by the previous wf_shade):
        reset them for the wf_shade that follows this kernel and for the next wf_extend; the next pass starts its new camera
-       samples where this one stops */
-    if (blockIdx.x == 0 && threadIdx.x == 0) { b.ctr[C_N + (cur ^ 1)] = 0u; b.ctr[C_HEAD + (cur ^ 1)] = 0u; b.ctr[C_SAMPLE + (cur ^ 1)] = shape.s0 + shape.n_fresh; }
+       samples where this one stops (a pass's stored-path launch passes the counter on unchanged, the launch of the new paths --
+       behind it on the stream -- adds what it starts) */
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        b.ctr[C_N + (cur ^ 1)] = 0u; b.ctr[C_HEAD + (cur ^ 1)] = 0u; b.ctr[C_HEAD_FRESH + (cur ^ 1)] = 0u;
+        b.ctr[C_SAMPLE + (cur ^ 1)] = shape.s0 + shape.n_fresh;
+    }
     const int lane = lane_id();
     Trav tv; trav_idle(tv);
     uint32_t rid = 0;            /* path << 2 | continuation pending << 1 | shadow ray occluded */
@@ -523,7 +532,7 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (MODE != kStoredOnly ? 5 : 7) : 8) vo
             if (!exhausted && chunk_pos >= chunk_end) {
                 uint32_t base = n;
                 if (dyn0 < n) {
-                    if (lane == 0) base = dyn0 + atomicAdd(&b.ctr[C_HEAD + cur], kChunk);
+                    if (lane == 0) base = dyn0 + atomicAdd(&b.ctr[(kFresh ? C_HEAD_FRESH : C_HEAD) + cur], kChunk);
                     base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
                 }
                 chunk_pos = base; chunk_end = min(base + kChunk, n);
@@ -543,8 +552,8 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (MODE != kStoredOnly ? 5 : 7) : 8) vo
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t) (fresh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) fresh, 0u));   /* set bits below this lane */
             bool startedA = false, startedB = false, startedCam = false;      /* this lane starts a closest-hit / a shadow query / a camera ray in this refill */
             const bool take = !pend && !trav_active(tv) && rank < avail;      /* this lane takes path chunk_pos + rank */
-            if (kFresh && take && chunk_pos + rank >= shape.n_f0) {      /* a new path: camera sample s0 + (i - n_f0) of the batch */
-                const uint32_t i = chunk_pos + rank, sid = shape.s0 + (i - shape.n_f0);
+            if (kFresh && take) {      /* a new path: camera sample s0 + (i - n_f0) of the batch */
+                const uint32_t i = first + chunk_pos + rank, sid = shape.s0 + chunk_pos + rank;
                 f2 ps; RayIn ray; Rng rng;
                 if (first_vertex(sc, bt, sid, ps, ray, rng)) {
                     st_f2<1>(&b.samp_pos[sid], ps);
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (MODE != kStoredOnly ? 5 : 7) : 8) vo
                     if (unsaved) tv.node = root_link;
                     if (!trav_active(tv)) st_f4<1>(&b.hit[i], hit_pack_here(nullptr, false));
                 }
-            } else if (kStored && (pend || (take && chunk_pos + rank < n_s))) {      /* (indices in [n_s, n_f0) hold no path) */
+            } else if (kStored && (pend || take)) {
                 const uint32_t i = pend ? (rid >> 2) : chunk_pos + rank;
                 /* a fresh path: origin and both directions (the flags ride with the continuation direction) are requested
                    together -- one round trip to HBM instead of two (the direction a path needs first depends on its
@@ -637,12 +646,35 @@ __global__ __launch_bounds__(BLOCK, WIDE ? (MODE != kStoredOnly ? 5 : 7) : 8) vo
        when no continuation ray is left): a path with a shadow ray only ends on it (tv.any); otherwise the closest hit
        + the shadow answer */
     if (unsaved) st_f4<1>(&b.hit[rid >> 2], tv.any ? hit_pack_here(nullptr, tv.hit.tri != kNoHit) : hit_pack_here(&tv.hit, (rid & 1u) != 0u));
-    /* counters: one atomic per wave */
-    if (COUNT) for (int off = 32; off > 0; off >>= 1) { tc.nodes += (uint32_t) __shfl_down((int) tc.nodes, off); tc.tris += (uint32_t) __shfl_down((int) tc.tris, off); }
+    /* The ray counters: one atomic per WORKGROUP and counter.  One per wave -- 8192 waves x 2 - 3 atomics into one cache line, which takes
+       ~90 of them per microsecond -- was a floor of ~0.18 ms under every launch whose waves end together: the small passes of a batch's tail,
+       every pass of one device's share of eight.  The waves' stacks are free by now: the first words of the workgroup's LDS collect the sums. */
+#ifdef NORI_LAB_WAVE_COUNTERS      /* A/B (variant builds): the counters per wave, as rounds 1 - 5 had them */
     if (lane == 0) {
         if (nClosest) atomicAdd(&b.stats[S_CLOSEST], (unsigned long long) nClosest);
         if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
         if (kFresh && nCam) atomicAdd(&b.stats[S_CAM], (unsigned long long) nCam);
+    }
+#else
+    __syncthreads();
+    uint32_t *s_sum = reinterpret_cast<uint32_t *>(smem);
+    if (threadIdx.x < 4u) s_sum[threadIdx.x] = 0u;
+    __syncthreads();
+    if (lane == 0) {
+        if (nClosest) atomicAdd(&s_sum[0], nClosest);
+        if (nShadow) atomicAdd(&s_sum[1], nShadow);
+        if (kFresh && nCam) atomicAdd(&s_sum[2], nCam);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_sum[0]) atomicAdd(&b.stats[S_CLOSEST], (unsigned long long) s_sum[0]);
+        if (s_sum[1]) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) s_sum[1]);
+        if (kFresh && s_sum[2]) atomicAdd(&b.stats[S_CAM], (unsigned long long) s_sum[2]);
+    }
+#endif
+    /* (counting builds: per wave, they are not timed) */
+    if (COUNT) for (int off = 32; off > 0; off >>= 1) { tc.nodes += (uint32_t) __shfl_down((int) tc.nodes, off); tc.tris += (uint32_t) __shfl_down((int) tc.tris, off); }
+    if (lane == 0) {
         if (COUNT) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
         NORI_PROF_STORE
         if (COUNT && b.census) for (int k = 0; k < Z_COUNT; ++k) if (zc[k]) atomicAdd(&b.census[k], (unsigned long long) zc[k]);
@@ -894,10 +926,21 @@ __global__ __launch_bounds__(kB) void wf_finish(DevScene sc, WfBuf b, int cur, W
         nShadow += (uint32_t) __shfl_down((int) nShadow, off);
         tc.nodes += (uint32_t) __shfl_down((int) tc.nodes, off); tc.tris += (uint32_t) __shfl_down((int) tc.tris, off);
     }
+    /* one atomic per workgroup and counter (as wf_extend) */
+    __shared__ uint32_t s_sum[4];
+    __syncthreads();
+    if (threadIdx.x < 4u) s_sum[threadIdx.x] = 0u;
+    __syncthreads();
     if (lane_id() == 0) {
-        if (nClosest) atomicAdd(&b.stats[S_CLOSEST], (unsigned long long) nClosest);
-        if (nShadow) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) nShadow);
-        if (count) { atomicAdd(&b.stats[S_NODES], (unsigned long long) tc.nodes); atomicAdd(&b.stats[S_TRIS], (unsigned long long) tc.tris); }
+        if (nClosest) atomicAdd(&s_sum[0], nClosest);
+        if (nShadow) atomicAdd(&s_sum[1], nShadow);
+        if (count) { atomicAdd(&s_sum[2], tc.nodes); atomicAdd(&s_sum[3], tc.tris); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_sum[0]) atomicAdd(&b.stats[S_CLOSEST], (unsigned long long) s_sum[0]);
+        if (s_sum[1]) atomicAdd(&b.stats[S_SHADOW], (unsigned long long) s_sum[1]);
+        if (count) { atomicAdd(&b.stats[S_NODES], (unsigned long long) s_sum[2]); atomicAdd(&b.stats[S_TRIS], (unsigned long long) s_sum[3]); }
     }
 }
 
@@ -1007,11 +1050,10 @@ void launch_extend(const DevScene &sc, const WfBuf &b, int cur, int refill, int 
 }
 
 /* lds_stack: entries kept in LDS (16 / 24 / 32); spill: the tree is deeper than that;
-   mode: kStoredOnly / kFreshOnly (the batch's first pass) / kMixed */
+   mode: kStoredOnly (the pass's stored paths) / kFreshOnly (its new ones) */
 void launch_extend_dyn(const DevScene &sc, const WfBuf &b, int cur, int refill, int lds_stack, bool spill, bool count, int mode,
                        int grid, const WfBatch &bt, hipStream_t s) {
 #define G(S, P, C) if (mode == kFreshOnly) launch_extend<S, P, C, kFreshOnly>(sc, b, cur, refill, grid, bt, s); \
-                   else if (mode == kMixed) launch_extend<S, P, C, kMixed>(sc, b, cur, refill, grid, bt, s); \
                    else launch_extend<S, P, C, kStoredOnly>(sc, b, cur, refill, grid, bt, s)
 #define E(S, P) if (count) { G(S, P, true); } else { G(S, P, false); }
 #define F(S) if (spill) { E(S, true); } else { E(S, false); }
@@ -1430,7 +1472,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
     const bool census = getenv("NORI_HIP_CENSUS") != nullptr;
     bool use_finish = true;
     if (const char *e = getenv("NORI_HIP_WF_FINISH")) use_finish = atoi(e) != 0;
-    const bool force_mixed = getenv("NORI_HIP_WF_FORCE_MIXED") != nullptr && atoi(getenv("NORI_HIP_WF_FORCE_MIXED")) != 0;      /* A/B: the kMixed kernels on every pass but the first */
+    const bool force_mixed = getenv("NORI_HIP_WF_FORCE_MIXED") != nullptr && atoi(getenv("NORI_HIP_WF_FORCE_MIXED")) != 0;      /* A/B, tests: every pass but the first as a pass that may hold new paths (both wf_extend launches, the kMixed wf_shade) */
 
     KernelTimer timer(L.time_kernels);
     unsigned long long *d_census = nullptr;
@@ -1476,10 +1518,21 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 Pipe &P = pipes[k];
                 if (!P.active) continue;
                 if (split) WF_TRY(hipStreamWaitEvent(P.extend_stream, P.ev_shade, 0));
-                timer.begin(KC_TRACE, P.extend_stream);
-                launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, P.mode, P.mode != kStoredOnly ? extend_grid_first : extend_grid, P.bt, P.extend_stream);
-                WF_TRY(hipGetLastError());      /* a launch that did not fit (LDS, registers) must not pass for an empty pass */
-                timer.end(P.extend_stream);
+                /* the pass's stored paths, then its new ones (pass_shape): two launches of the two pure kernels */
+                if (P.mode != kFreshOnly) {
+                    timer.begin(KC_TRACE, P.extend_stream);
+                    launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, kStoredOnly, extend_grid, P.bt, P.extend_stream);
+                    WF_TRY(hipGetLastError());      /* a launch that did not fit (LDS, registers) must not pass for an empty pass */
+                    timer.end(P.extend_stream);
+                    stats.n_launches++;
+                }
+                if (P.mode != kStoredOnly) {
+                    timer.begin(KC_TRACE, P.extend_stream);
+                    launch_extend_dyn(sc, P.b, P.cur, thresholds, lds_stack, spill, L.count_traversal, kFreshOnly, extend_grid_first, P.bt, P.extend_stream);
+                    WF_TRY(hipGetLastError());
+                    timer.end(P.extend_stream);
+                    stats.n_launches++;
+                }
                 if (split) { WF_TRY(hipEventRecord(P.ev_extend, P.extend_stream)); WF_TRY(hipStreamWaitEvent(P.stream, P.ev_extend, 0)); }
                 timer.begin(KC_SHADE, P.stream);
                 launch_shade(sc, P.b, P.cur, P.bt, P.mode, sh_grid, P.stream);
@@ -1488,7 +1541,7 @@ std::string wavefront_render(WfEngine &eng, FilmStore &film_store, const DevScen
                 /* the first pass started min(pool, samples) camera samples: a batch that fits the pool has none left */
                 if (P.mode == kFreshOnly) P.mode = P.batch_samples <= P.bt.pool && !force_mixed ? kStoredOnly : kMixed;
                 P.cur ^= 1;
-                stats.n_launches += 2;
+                stats.n_launches++;
                 if (k == 0) stats.n_iterations++;
             }
         for (int k = 0; k < n_pipes; ++k)

@@ -51,9 +51,10 @@ def test_the_production_traversal_kernels_keep_their_register_budget(wavefront_k
     # wide trees: 7 waves per SIMD (5 in the first pass) -- wavefront_render sizes the persistent grids for that
     k = _find(rows, "wf_extend<16, true, false, 0, true, false, 256>")
     assert k["vgpr"] <= 72 and k["scratch"] == 0, k      # 7 waves per SIMD
-    for mode in (1, 2):                                   # the first pass / stored and new paths mixed (regeneration)
-        k = _find(rows, f"wf_extend<16, true, false, {mode}, true, false, 256>")
-        assert k["vgpr"] <= 96 and k["scratch"] == 0, k
+    k = _find(rows, "wf_extend<16, true, false, 1, true, false, 256>")      # MODE 1: a pass's NEW paths (the first pass; regeneration)
+    assert k["vgpr"] <= 96 and k["scratch"] == 0, k
+    # stored and new paths are traced by separate launches of the two pure kernels: no wf_extend carries both refills
+    assert not [n for n in rows if n.startswith("void wf_extend<") and n.split(",")[3].strip() == "2"]
 
 
 def test_the_shading_kernels_do_not_spill(wavefront_kernels):

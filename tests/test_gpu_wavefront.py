@@ -232,7 +232,7 @@ def test_regeneration_gives_the_bits_of_the_shrinking_schedule(renderer_factory)
             assert np.array_equal(b, ref), (pool, env)
             for k in ("n_camera_samples", "n_closest_rays", "n_shadow_rays", "n_invalid") + (("n_node_tests", "n_tri_tests") if env is WALK_64B else ()):
                 assert sr64[k] == sb[k], (pool, env, k, sr64[k], sb[k])
-    # the kMixed kernels on a batch that fits the pool (every pass after the first has nothing new to start): same bits
+    # every pass after the first traced as one that may hold new paths (both wf_extend launches, the kMixed wf_shade) on a batch that fits the pool: same bits
     wf.set_option("wavefront_paths", 1 << 29)
     b, sb = _with_env({"NORI_HIP_WF_FORCE_MIXED": 1}, lambda: wf.render_host())
     assert np.array_equal(b, ref) and sb["n_shadow_rays"] == sr["n_shadow_rays"]

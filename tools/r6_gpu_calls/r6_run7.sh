@@ -12,3 +12,7 @@ timeout 600 bash tools/profile_round.sh r6_10_c1 c1-bunny-normals lite megakerne
 timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/r6_10_pytest_gpu.txt 2>&1; tail -3 gpurun_out/r6_10_pytest_gpu.txt
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/r6_10_smoke.txt 2>&1; tail -2 gpurun_out/r6_10_smoke.txt
 timeout 600 python bench.py > gpurun_out/r6_10_bench_default.json 2> gpurun_out/r6_10_bench_default.err; tail -c 600 gpurun_out/r6_10_bench_default.json
+# (run again after the two-launch form of regeneration: same tag, the files of the first run replaced)
+{ echo "== python tests/fuzz_intersect.py --seconds 120 --seed 700"; timeout 400 python tests/fuzz_intersect.py --seconds 120 --seed 700 2>&1 | tail -3
+  echo "== python tests/fuzz_engines.py --seconds 240 --seed 7000"; timeout 600 python tests/fuzz_engines.py --seconds 240 --seed 7000 2>&1 | tail -3; } > gpurun_out/r6_10_fuzz_final_build.txt 2>&1
+cat gpurun_out/r6_10_fuzz_final_build.txt
