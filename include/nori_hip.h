@@ -119,11 +119,13 @@ typedef enum nori_seed_mode {
 typedef enum nori_accel_builder {
     NORI_ACCEL_HOST_SAH = 0,   /* binned SAH on the host, uploaded            */
     NORI_ACCEL_GPU_LBVH = 1,   /* built on the device: Morton order + radix tree (1.5 ms per million triangles)   */
-    NORI_ACCEL_AUTO = 2,       /* HOST_SAH up to 2^22 triangles (best trees, ~0.25 s per million triangles on 16 cores),
-                                  GPU_PLOC above (78 ms instead of 2.4 s for 10 M triangles; traversal ~10 % slower) */
+    NORI_ACCEL_AUTO = 2,       /* HOST_SAH below 2^20 triangles (spatial splits; 30 - 90 ms), GPU_PLOC from there on (142 ms
+                                  instead of 2.4 s for 10 M triangles; traversal within 1.5 % of the host tree's) */
     NORI_ACCEL_GPU_PLOC = 3    /* built on the device: Morton order + nearest-neighbour clustering (PLOC, 3 ms per million
-                                  triangles) + two sweeps of treelet restructuring (a wave per treelet, 2 - 3 ms per million
-                                  triangles and sweep); never worse than the radix tree, up to 20 % faster to traverse */
+                                  triangles) + treelet restructuring (a wave per treelet, 2 - 3 ms per million triangles and
+                                  sweep) + parallel re-insertion (1 ms per million candidates); never worse than the radix
+                                  tree, up to 25 % faster to traverse; Cornell box and terrain: within 1.5 % of HOST_SAH,
+                                  scenes that need spatial splits (pa5 table): 34 % behind */
 } nori_accel_builder;
 
 /* ------------------------------------------------------ scene description */

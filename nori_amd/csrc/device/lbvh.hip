@@ -42,6 +42,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -208,6 +210,46 @@ __global__ __launch_bounds__(64 * kTreeletWaves) void k_treelet_wave(PlocNodes n
         if (__ballot(active) == 0ull) break;
     }
 }
+/* ---- parallel re-insertion (lbvh_steps.h): one thread per candidate slot of the iteration's residue class ---- */
+__global__ void k_reins_leaf_boxes(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, float pad0, ReinsData rd) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) tri_leaf_box(pos, idx, order[k], pad0, rd.lmn[k], rd.lmx[k]);
+}
+__global__ void k_reins_search(PlocNodes nodes, TreeletData td, ReinsData rd, uint32_t n_inner, uint32_t n_slots, uint32_t phase, uint32_t stride) {
+    const uint32_t slot = phase + (blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    if (slot >= n_slots) return;
+    reins_search(nodes, td, rd, n_inner, slot);
+    (void) reins_locks(nodes, rd, n_inner, slot, true);      /* (marks do not change what the others' searches read) */
+}
+__global__ void k_reins_check(PlocNodes nodes, ReinsData rd, uint32_t n_inner, uint32_t n_slots, uint32_t phase, uint32_t stride, uint32_t *moved) {
+    const uint32_t slot = phase + (blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    if (slot >= n_slots) return;
+    const bool win = reins_locks(nodes, rd, n_inner, slot, false);
+    rd.win[slot] = win ? 1u : 0u;
+    if (win) atomicAdd(moved, 1u);
+}
+__global__ void k_reins_apply(PlocNodes nodes, ReinsData rd, uint32_t n_inner, uint32_t n_slots, uint32_t phase, uint32_t stride) {
+    const uint32_t slot = phase + (blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    if (slot < n_slots && rd.win[slot]) reins_apply(nodes, rd, n_inner, slot);
+}
+/* bottom-up from every triangle; the second arrival at a node computes it (the hand-over of k_treelet_wave: agent-scope accesses,
+   the arriving thread's stores acknowledged before it counts itself in) */
+__global__ void k_reins_refit(PlocNodes nodes, TreeletData td, ReinsData rd, TreeletParams tp, uint32_t *visits, uint32_t n) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t root_id = n - 2u;
+    uint32_t p = nodes.parent_prim[k];
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t before = __hip_atomic_fetch_add(&visits[p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::: "memory");
+        if (before == 0u) return;
+        reins_refit_node(nodes, td, rd, tp, p);
+        if (p == root_id) return;
+        p = nodes.parent_node[p];
+    }
+}
+
 __global__ void k_ploc_leaf_positions(PlocNodes nodes, uint32_t n, const uint32_t *order, uint32_t *leaf_pos, uint32_t *order_out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
@@ -291,9 +333,9 @@ __global__ void k_emit_pairs(const f4 *pos, const uint32_t *idx, const uint32_t 
     if (cnt) emit_leaf_pairs(pos, idx, tri_mesh, order, k, cnt, out + (size_t) (pair_start[k] + pair_base) * kPairQuads);
 }
 
-__global__ void k_depth(const uint32_t *parent_inner, const uint32_t *parent_leaf, uint32_t n, unsigned int *max_depth) {
+__global__ void k_depth(const uint32_t *parent_inner, const uint32_t *parent_leaf, const uint32_t *keep, uint32_t n, unsigned int *max_depth) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) atomicMax(max_depth, leaf_depth(parent_inner, parent_leaf, k));
+    if (k < n) atomicMax(max_depth, leaf_depth(parent_inner, parent_leaf, keep, k));
 }
 
 struct Buf {
@@ -324,6 +366,16 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     LB_TRY(hipEventRecord(e0, 0));
 
     if (n == 0) return "lbvh: empty scene";
+    /* NORI_HIP_BUILD_TIMING: milliseconds per phase on stderr (a device synchronisation per lap: not for timed builds) */
+    const bool timing = getenv("NORI_HIP_BUILD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t_lap = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void) hipDeviceSynchronize();
+        const std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[lbvh] %-28s %8.2f ms\n", what, std::chrono::duration<float, std::milli>(t - t_lap).count());
+        t_lap = t;
+    };
     const int B = 256;
     const uint32_t gridN = (n + B - 1) / B;
 
@@ -400,6 +452,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
             }
             if (node_base != n - 1u) return "lbvh: PLOC node count";
             out.ploc_iterations = iterations;
+            lap("sort + PLOC");
             {   /* treelet restructuring (lbvh_steps.h): one launch per sweep, a thread per triangle climbing the tree */
                 /* two sweeps (NORI_HIP_TREELET_SWEEPS overrides).  Round 3 ran none above 2^20 triangles: a sweep cost 340 ms on the
                    10 M-triangle terrain.  Round 4 (profiles/r4_09_treelet_wave.txt): a wave per treelet took that to 198 ms -- and showed
@@ -409,9 +462,12 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
                    10 M triangles, PLOC + 0 / 1 / 2 / 3 / 5 sweeps: build 29 / 49 / 78 / 106 / 162 ms, wf_extend (64 spp) 33.4 / 33.0 / 32.5 /
                    32.4 / 32.5 ms (host SAH tree, built in 2.4 s: 29.4).  328 k-triangle AO scene: wf_extend 12.0 ms against the host
                    tree's 11.8; Cornell box, BVH2: node tests per ray 9.31 -> 8.49 (host SAH: 8.77). */
-                int sweeps = 2;
-                if (const char *e = getenv("NORI_HIP_TREELET_SWEEPS")) sweeps = std::max(0, atoi(e));
-                if (sweeps > 0) {
+                /* [r6] then parallel re-insertion (lbvh_steps.h); how many of each: build_tuning (lbvh.h).  Node tests per ray of a small
+                   render, PLOC + 2 sweeps against + 8 iterations + 1 sweep (tools/reinsert_probe.py, the steps on the CPU): Cornell box 8.56 ->
+                   8.32 (host SAH tree 8.79), pa5 table 11.46 -> 10.89 (9.63, with spatial splits), terrain of 200 k triangles 27.8 -> 26.0 (24.6) */
+                const BuildTuning rp = build_tuning(n);
+                const int sweeps = rp.sweeps;
+                if (sweeps > 0 || rp.iterations > 0) {
                     Buf t_mn, t_mx, t_cost, t_visits;
                     LB_TRY(t_mn.alloc((size_t) n * 16)); LB_TRY(t_mx.alloc((size_t) n * 16)); LB_TRY(t_cost.alloc((size_t) n * 4)); LB_TRY(t_visits.alloc((size_t) n * 4));
                     TreeletData td{t_mn.as<f4>(), t_mx.as<f4>(), t_cost.as<float>()};
@@ -438,11 +494,48 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
                     LB_TRY(hipMemcpy(t_pairs.p, pairs.data(), pairs.size() * sizeof(TreeletPair), hipMemcpyHostToDevice));
                     tab.pairs = t_pairs.as<TreeletPair>();
                     const bool serial = getenv("NORI_HIP_TREELET_SERIAL") != nullptr && atoi(getenv("NORI_HIP_TREELET_SERIAL")) != 0;      /* one thread per treelet (A/B, tests) */
-                    for (int sw = 0; sw < sweeps; ++sw) {
-                        LB_TRY(hipMemsetAsync(t_visits.p, 0, (size_t) n * 4, 0));
+                    auto sweep = [&]() -> hipError_t {
+                        hipError_t e = hipMemsetAsync(t_visits.p, 0, (size_t) n * 4, 0);
+                        if (e != hipSuccess) return e;
                         if (serial) hipLaunchKernelGGL(k_treelet, dim3((n + 63) / 64), dim3(64), 0, 0, pn, td, dev.positions, dev.indices, order, pad, tp, t_visits.as<uint32_t>(), n);
                         else hipLaunchKernelGGL(k_treelet_wave, dim3((n + 64 * kTreeletWaves - 1) / (64 * kTreeletWaves)), dim3(64 * kTreeletWaves), 0, 0, pn, td, dev.positions, dev.indices, order, pad, tp,
                                                 tab, t_visits.as<uint32_t>(), n);
+                        return hipGetLastError();
+                    };
+                    for (int sw = 0; sw < sweeps; ++sw) LB_TRY(sweep());
+                    lap("treelet sweeps");
+                    if (rp.iterations > 0) {
+                        const uint32_t n_inner = n - 1u, n_slots = 2u * n - 1u;
+                        Buf r_lmn, r_lmx, r_lock, r_key, r_target, r_pivot, r_win, r_moved;
+                        LB_TRY(r_lmn.alloc((size_t) n * 16)); LB_TRY(r_lmx.alloc((size_t) n * 16));
+                        LB_TRY(r_lock.alloc((size_t) n_slots * 8)); LB_TRY(r_key.alloc((size_t) n_slots * 8));
+                        LB_TRY(r_target.alloc((size_t) n_slots * 4)); LB_TRY(r_pivot.alloc((size_t) n_slots * 4)); LB_TRY(r_win.alloc((size_t) n_slots * 4));
+                        LB_TRY(r_moved.alloc(4)); LB_TRY(hipMemsetAsync(r_moved.p, 0, 4, 0));
+                        ReinsData rd{r_lmn.as<f4>(), r_lmx.as<f4>(), r_lock.as<unsigned long long>(), r_key.as<unsigned long long>(), r_target.as<uint32_t>(), r_pivot.as<uint32_t>(), r_win.as<uint32_t>()};
+                        hipLaunchKernelGGL(k_reins_leaf_boxes, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, order, n, pad, rd);
+                        auto refit = [&]() -> hipError_t {
+                            hipError_t e = hipMemsetAsync(t_visits.p, 0, (size_t) n * 4, 0);
+                            if (e != hipSuccess) return e;
+                            hipLaunchKernelGGL(k_reins_refit, dim3(gridN), dim3(B), 0, 0, pn, td, rd, tp, t_visits.as<uint32_t>(), n);
+                            return hipGetLastError();
+                        };
+                        LB_TRY(refit());      /* (boxes, counts and costs of ALL nodes: with no sweep before, nothing has computed them yet) */
+                        lap("re-insertion: boxes + refit");
+                        for (int it = 0; it < rp.iterations; ++it) {
+                            const uint32_t phase = (uint32_t) it % rp.stride, cands = (n_slots - phase + rp.stride - 1u) / rp.stride;
+                            const dim3 g((cands + 63u) / 64u);      /* one wave per workgroup: a long search holds up 63 others, not 255 */
+                            LB_TRY(hipMemsetAsync(r_lock.p, 0, (size_t) n_slots * 8, 0));
+                            hipLaunchKernelGGL(k_reins_search, g, dim3(64), 0, 0, pn, td, rd, n_inner, n_slots, phase, rp.stride);
+                            lap("re-insertion: search + mark");
+                            hipLaunchKernelGGL(k_reins_check, g, dim3(64), 0, 0, pn, rd, n_inner, n_slots, phase, rp.stride, r_moved.as<uint32_t>());
+                            hipLaunchKernelGGL(k_reins_apply, g, dim3(64), 0, 0, pn, rd, n_inner, n_slots, phase, rp.stride);
+                            lap("re-insertion: check + move");
+                            LB_TRY(refit());
+                            lap("re-insertion: refit");
+                        }
+                        LB_TRY(hipMemcpy(&out.reinserted, r_moved.p, 4, hipMemcpyDeviceToHost));
+                        for (int sw = 0; sw < rp.sweeps_after; ++sw) LB_TRY(sweep());
+                        lap("sweeps after");
                     }
                     LB_TRY(hipGetLastError());
                     LB_TRY(hipDeviceSynchronize());      /* the buffers go out of scope here */
@@ -555,12 +648,13 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
                            collapse.as<uint32_t>(), pair_start.as<uint32_t>(), keep.as<uint32_t>(), node_index.as<uint32_t>(), d_nodes);
         /* 8. depth */
         Buf md; LB_TRY(md.alloc(4)); LB_TRY(hipMemset(md.p, 0, 4));
-        hipLaunchKernelGGL(k_depth, dim3(gridN), dim3(B), 0, 0, pin.as<uint32_t>(), plf.as<uint32_t>(), n, md.as<unsigned int>());
+        hipLaunchKernelGGL(k_depth, dim3(gridN), dim3(B), 0, 0, pin.as<uint32_t>(), plf.as<uint32_t>(), keep.as<uint32_t>(), n, md.as<unsigned int>());
         unsigned int depth = 0;
         LB_TRY(hipMemcpy(&depth, md.p, 4, hipMemcpyDeviceToHost));
         out.root = 0; out.n_nodes = n_nodes; out.n_leaves = 0; out.max_depth = depth;
         LB_TRY(hipGetLastError());
     }
+    lap("leaves, boxes, emission");
     LB_TRY(hipEventRecord(e1, 0));
     LB_TRY(hipEventSynchronize(e1));
     LB_TRY(hipEventElapsedTime(&out.build_ms, e0, e1));

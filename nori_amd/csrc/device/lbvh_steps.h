@@ -415,6 +415,180 @@ NORI_HD void treelet_climb(const PlocNodes &nodes, const TreeletData &td, const 
     }
 }
 
+/* ---- parallel re-insertion (Meister & Bittner 2018) of the PLOC tree ----
+ * The treelet sweeps repair what is wrong INSIDE seven-leaf neighbourhoods; what PLOC's Morton-local merges got wrong across
+ * the tree -- a subtree that belongs under a node far away in the key order -- they cannot reach.  Re-insertion can: take a
+ * subtree x (an inner node or a single triangle) out of the tree together with its parent p -- x's sibling moves up into p's
+ * place -- and hang it, under p again, beside the node y where the sum of the inner nodes' areas (the tree's SAH cost) shrinks
+ * most.  With p_0 = p, p_1, ... the ancestors of x, s_k the other child of p_k and R_k the union of B(s_0 .. s_k) (= the box of
+ * p_k once x is gone; B(p_k) = R_k u B(x) exactly), the gain of moving x beside a node y of subtree(s_k) is
+ *     A(p_0) + sum_{0 < i < k} (A(p_i) - A(R_i))  -  A(x u y)  -  sum_{y' above y, up to s_k} (A(y' u x) - A(y'))
+ * -- the ancestors from p_k up have x below them before and after -- and  A(p_0) + sum_{0 < i < k} (..) - A(R_k)  beside the
+ * shrunken p_k itself.  reins_search climbs from p to the root and walks every subtree(s_k) without a stack (parent links),
+ * pruned by what the best place found so far gains.  All candidates of an iteration search the SAME tree; then
+ *   reins_lock     a candidate marks every node whose links its move changes or whose position it relies on -- x, p, s_0, p_1, y,
+ *                  y's parent and the nodes from y up to below p_k -- with (gain, x) by a 64-bit maximum
+ *   reins_check    it wins if all its marks stand.  The winners' node sets are disjoint, and no winner moves into a subtree
+ *                  that another winner moves (it would have marked that subtree's root, which the other marks as its x): the
+ *                  moves commute and the result is a tree, whatever the order they are applied in
+ *   reins_apply    relinks (two child links, three parent links, p's children)
+ *   reins_refit    boxes, triangle counts and subtree costs bottom-up, as a sweep's climb does.
+ * The root keeps its id (the last node): neither it nor its children move, nothing is hung above it.  Subtrees with an
+ * unbounded box (numerically collinear triangles) stay where they are. */
+struct ReinsData {
+    f4 *lmn, *lmx;                 /* the triangles' padded boxes, by position in the builder's order */
+    unsigned long long *lock;      /* [2 n - 1] by slot: inner node id, or n - 1 + position of a triangle */
+    unsigned long long *key;       /* [2 n - 1] the candidate's (gain bits << 32 | slot), 0 = no move */
+    uint32_t *target, *pivot;      /* [2 n - 1] y and p_k (kNoParent: y is an ancestor of x, the move goes beside the shrunken y) */
+    uint32_t *win;                 /* [2 n - 1] */
+};
+NORI_HD uint32_t reins_slot(uint32_t id, uint32_t n_inner) { return (id & kLeafBit) ? n_inner + (id & ~kLeafBit) : id; }
+NORI_HD uint32_t reins_id(uint32_t slot, uint32_t n_inner) { return slot < n_inner ? slot : (kLeafBit | (slot - n_inner)); }
+NORI_HD uint32_t reins_parent(const PlocNodes &nd, uint32_t id) { return (id & kLeafBit) ? nd.parent_prim[id & ~kLeafBit] : nd.parent_node[id]; }
+NORI_HD void reins_box(const TreeletData &td, const ReinsData &rd, uint32_t id, f3 &mn, f3 &mx) {
+    if (id & kLeafBit) { mn = xyz(rd.lmn[id & ~kLeafBit]); mx = xyz(rd.lmx[id & ~kLeafBit]); }
+    else { mn = xyz(td.nmn[id]); mx = xyz(td.nmx[id]); }
+}
+NORI_HD float reins_union_area(f3 amn, f3 amx, f3 bmn, f3 bmx) {
+    return half_area(mk3(fminf(amn.x, bmn.x), fminf(amn.y, bmn.y), fminf(amn.z, bmn.z)), mk3(fmaxf(amx.x, bmx.x), fmaxf(amx.y, bmx.y), fmaxf(amx.z, bmx.z)));
+}
+
+/* the best place for the subtree in `slot`: key[slot] = 0 (stay) or (gain, slot), target[slot] = y, pivot[slot] = p_k */
+NORI_HD void reins_search(const PlocNodes &nd, const TreeletData &td, const ReinsData &rd, uint32_t n_inner, uint32_t slot) {
+    const uint32_t root = n_inner - 1u, x = reins_id(slot, n_inner);
+    rd.key[slot] = 0ull;
+    if (x == root) return;
+    const uint32_t p0 = reins_parent(nd, x);
+    if (p0 == root) return;
+    f3 xmn, xmx, bmn, bmx;
+    reins_box(td, rd, x, xmn, xmx);
+    if (!(xmx.x < kBoxInf)) return;
+    const float ax = half_area(xmn, xmx);
+    reins_box(td, rd, p0, bmn, bmx);
+    const float ap0 = half_area(bmn, bmx);
+    if (!(ap0 < kInf)) return;
+    float base = ap0, best = 1e-6f * ap0, best_base = 0.0f;
+    uint32_t best_y = kNoParent, best_pivot = kNoParent;
+    uint32_t prev = x, piv = p0;
+    f3 rmn = mk3(kInf), rmx = mk3(-kInf);
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {
+        const uint32_t l = nd.left[piv], s = l == prev ? nd.right[piv] : l;
+        {   /* subtree(s), left to right; growth = what the nodes above y (within the subtree) grow by when x hangs below them */
+            uint32_t y = s; float growth = 0.0f; bool down = true;
+            for (uint32_t steps = 0; steps < (1u << 26); ++steps) {
+                if (down) {
+                    reins_box(td, rd, y, bmn, bmx);
+                    const float direct = reins_union_area(xmn, xmx, bmn, bmx), gain = base - growth - direct;
+                    if (gain > best && !(piv == p0 && y == s)) { best = gain; best_base = base; best_y = y; best_pivot = piv; }
+                    const float below = growth + (direct - half_area(bmn, bmx));
+                    if (!(y & kLeafBit) && base - below - ax > best) { growth = below; y = nd.left[y]; continue; }
+                    down = false;
+                }
+                if (y == s) break;
+                const uint32_t par = reins_parent(nd, y);
+                if (nd.left[par] == y) { y = nd.right[par]; down = true; }
+                else {
+                    y = par;
+                    reins_box(td, rd, y, bmn, bmx);
+                    growth -= reins_union_area(xmn, xmx, bmn, bmx) - half_area(bmn, bmx);
+                }
+            }
+        }
+        reins_box(td, rd, s, bmn, bmx);
+        rmn = mk3(fminf(rmn.x, bmn.x), fminf(rmn.y, bmn.y), fminf(rmn.z, bmn.z)); rmx = mk3(fmaxf(rmx.x, bmx.x), fmaxf(rmx.y, bmx.y), fmaxf(rmx.z, bmx.z));
+        if (piv == root) break;
+        if (piv != p0) {
+            const float ar = half_area(rmn, rmx), gain = base - ar;      /* beside the shrunken p_k */
+            if (gain > best) { best = gain; best_base = base; best_y = piv; best_pivot = kNoParent; }
+            reins_box(td, rd, piv, bmn, bmx);
+            base += half_area(bmn, bmx) - ar;
+        }
+        prev = piv; piv = nd.parent_node[piv];
+    }
+    if (best_y == kNoParent) return;
+    if (best_pivot != kNoParent) {      /* the walk's running sum drifts: the gain again, from y upwards */
+        reins_box(td, rd, best_y, bmn, bmx);
+        float g = best_base - reins_union_area(xmn, xmx, bmn, bmx);
+        for (uint32_t c = reins_parent(nd, best_y), guard = 0; c != best_pivot && guard < 4096u; c = nd.parent_node[c], ++guard) {
+            reins_box(td, rd, c, bmn, bmx);
+            g -= reins_union_area(xmn, xmx, bmn, bmx) - half_area(bmn, bmx);
+        }
+        best = g;
+        if (!(best > 1e-6f * ap0)) return;
+    }
+    rd.target[slot] = best_y; rd.pivot[slot] = best_pivot;
+    rd.key[slot] = ((unsigned long long) f2u(best) << 32) | slot;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void reins_mark(unsigned long long *lock, unsigned long long key) { atomicMax(lock, key); }
+#else
+NORI_HD void reins_mark(unsigned long long *lock, unsigned long long key) { if (*lock < key) *lock = key; }
+#endif
+/* the nodes a move depends on: marked (acquire) or checked -- false as soon as one mark is another candidate's */
+NORI_HD bool reins_locks(const PlocNodes &nd, const ReinsData &rd, uint32_t n_inner, uint32_t slot, bool acquire) {
+    const unsigned long long key = rd.key[slot];
+    if (key == 0ull) return false;
+    const uint32_t x = reins_id(slot, n_inner), y = rd.target[slot], pivot = rd.pivot[slot];
+    const uint32_t p0 = reins_parent(nd, x), g = nd.parent_node[p0];
+    const uint32_t s0 = nd.left[p0] == x ? nd.right[p0] : nd.left[p0];
+#define NORI_REINS_TOUCH(id) do { unsigned long long *lk = &rd.lock[reins_slot(id, n_inner)]; if (acquire) reins_mark(lk, key); else if (*lk != key) return false; } while (0)
+    NORI_REINS_TOUCH(x); NORI_REINS_TOUCH(p0); NORI_REINS_TOUCH(s0); NORI_REINS_TOUCH(g);
+    if (pivot == kNoParent) { NORI_REINS_TOUCH(y); NORI_REINS_TOUCH(nd.parent_node[y]); return true; }
+    uint32_t c = y;
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {
+        NORI_REINS_TOUCH(c);
+        const uint32_t par = reins_parent(nd, c);
+        if (par == pivot) break;
+        c = par;
+    }
+    NORI_REINS_TOUCH(reins_parent(nd, y));
+#undef NORI_REINS_TOUCH
+    return true;
+}
+NORI_HD void reins_set_parent(const PlocNodes &nd, uint32_t child, uint32_t parent) {
+    if (child & kLeafBit) nd.parent_prim[child & ~kLeafBit] = parent; else nd.parent_node[child] = parent;
+}
+/* a winner's move: x's sibling takes p's place, p takes y's place and holds (x, y) */
+NORI_HD void reins_apply(const PlocNodes &nd, const ReinsData &rd, uint32_t n_inner, uint32_t slot) {
+    const uint32_t x = reins_id(slot, n_inner), y = rd.target[slot];
+    const uint32_t p0 = reins_parent(nd, x), g = nd.parent_node[p0];
+    const uint32_t s0 = nd.left[p0] == x ? nd.right[p0] : nd.left[p0];
+    if (nd.left[g] == p0) nd.left[g] = s0; else nd.right[g] = s0;
+    reins_set_parent(nd, s0, g);
+    const uint32_t q = reins_parent(nd, y);      /* (after the step above: y may be p's parent or its sibling) */
+    if (nd.left[q] == y) nd.left[q] = p0; else nd.right[q] = p0;
+    nd.parent_node[p0] = q;
+    nd.left[p0] = x; nd.right[p0] = y;
+    reins_set_parent(nd, y, p0);
+}
+/* node `id` from its children: box, triangles below, SAH cost of the subtree (as treelet_form / treelet_rewire keep them) */
+NORI_HD void reins_refit_node(const PlocNodes &nd, const TreeletData &td, const ReinsData &rd, TreeletParams tp, uint32_t id) {
+    const uint32_t c[2] = {coh_ld(&nd.left[id]), coh_ld(&nd.right[id])};
+    f3 mn[2], mx[2]; float cost[2]; uint32_t cnt[2];
+    for (int i = 0; i < 2; ++i) {
+        if (c[i] & kLeafBit) { mn[i] = xyz(rd.lmn[c[i] & ~kLeafBit]); mx[i] = xyz(rd.lmx[c[i] & ~kLeafBit]); cnt[i] = 1u; cost[i] = tp.c_tri * half_area(mn[i], mx[i]); }
+        else { mn[i] = xyz(coh_ld4(&td.nmn[c[i]])); mx[i] = xyz(coh_ld4(&td.nmx[c[i]])); cnt[i] = coh_ld(&nd.count[c[i]]); cost[i] = coh_ld(&td.cost[c[i]]); }
+    }
+    const f3 bmn = mk3(fminf(mn[0].x, mn[1].x), fminf(mn[0].y, mn[1].y), fminf(mn[0].z, mn[1].z));
+    const f3 bmx = mk3(fmaxf(mx[0].x, mx[1].x), fmaxf(mx[0].y, mx[1].y), fmaxf(mx[0].z, mx[1].z));
+    f4 a, b; a.x = bmn.x; a.y = bmn.y; a.z = bmn.z; a.w = 0.0f; b.x = bmx.x; b.y = bmx.y; b.z = bmx.z; b.w = 0.0f;
+    const bool bounded = bmx.x < kBoxInf;
+    coh_st4(&td.nmn[id], a); coh_st4(&td.nmx[id], b);
+    coh_st(&td.cost[id], bounded ? tp.c_node * half_area(bmn, bmx) + (cost[0] + cost[1]) : 1e30f);
+    coh_st(&nd.count[id], cnt[0] + cnt[1]);
+}
+/* CPU form of the climb from the triangle at position k (the device's: k_reins_refit, lbvh.hip) */
+NORI_HD void reins_refit_climb(const PlocNodes &nd, const TreeletData &td, const ReinsData &rd, TreeletParams tp, uint32_t *visits, uint32_t root_id, uint32_t k) {
+    uint32_t p = nd.parent_prim[k];
+    for (uint32_t guard = 0; guard < 4096u; ++guard) {
+        if (visits[p]++ == 0u) return;
+        reins_refit_node(nd, td, rd, tp, p);
+        if (p == root_id) return;
+        p = nd.parent_node[p];
+    }
+}
+
 /* min / max segment tree over the boxes in the builder's order: leaves at [N + k], node i = union of 2 i, 2 i + 1 */
 NORI_HD void seg_tree_combine(uint32_t i, f4 *tmin, f4 *tmax) {
     const f4 a = tmin[2 * i], b = tmin[2 * i + 1], c = tmax[2 * i], d = tmax[2 * i + 1];
@@ -566,10 +740,15 @@ NORI_HD void emit_wide_node(const RadixNode *nodes, const f4 *tmin, const f4 *tm
     }
     wide_pack(n, mn, mx, link, q);
 }
-/* nodes on the way from the triangle at position k to the root */
-NORI_HD uint32_t leaf_depth(const uint32_t *parent_inner, const uint32_t *parent_leaf, uint32_t k) {
-    uint32_t depth = 1u, p = parent_leaf[k];
-    while (p != 0u && p != kNoParent && depth < 4096u) { p = parent_inner[p]; ++depth; }
+/* nodes of the emitted tree on the way from the triangle at position k to the root (keep[]: mark_leaves -- the nodes inside a
+   collapsed subtree are not nodes of the tree: counting them priced the Cornell box's tree two levels deeper than it is) */
+NORI_HD uint32_t leaf_depth(const uint32_t *parent_inner, const uint32_t *parent_leaf, const uint32_t *keep, uint32_t k) {
+    uint32_t depth = 0u, p = parent_leaf[k];
+    for (uint32_t guard = 0; p != kNoParent && guard < 4096u; ++guard) {
+        depth += keep[p] ? 1u : 0u;
+        if (p == 0u) break;
+        p = parent_inner[p];
+    }
     return depth;
 }
 

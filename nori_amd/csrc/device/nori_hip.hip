@@ -576,7 +576,10 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
 int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     if (!ctx) return NORI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) { ctx->error = "build_accel: no scene uploaded"; return NORI_ERR_NOT_READY; }
-    if (builder == NORI_ACCEL_AUTO) builder = ctx->dev.n_triangles > (1u << 22) ? NORI_ACCEL_GPU_PLOC : NORI_ACCEL_HOST_SAH;
+    /* auto: from 2^20 triangles (where the tree is emitted as wide nodes) the device's builder -- with re-insertion its tree traces within
+       1.5 % of the host's on the 10 M-triangle terrain and is built in 142 ms instead of 2.4 s (profiles/r6_16_c5_build_matrix.txt); below, the
+       host's: 30 - 90 ms, and spatial splits, which the device does not have, are worth 34 % of wf_extend on the pa5 table scene */
+    if (builder == NORI_ACCEL_AUTO) builder = ctx->dev.n_triangles >= (1u << 20) ? NORI_ACCEL_GPU_PLOC : NORI_ACCEL_HOST_SAH;
     if (builder != NORI_ACCEL_HOST_SAH && builder != NORI_ACCEL_GPU_LBVH && builder != NORI_ACCEL_GPU_PLOC) { ctx->error = "build_accel: unknown builder"; return NORI_ERR_INVALID_ARGUMENT; }
     DeviceGuard g(ctx->device);
     free_pool(ctx->allocs_accel);
@@ -626,6 +629,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
         if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.tris, &ctx->dev.tris))) return rc;
         ctx->lbvh_bytes = 0;
     }
+    if (const char *e = getenv("NORI_HIP_LAB_DEPTH_ADD")) ctx->bvh.max_depth += (uint32_t) std::max(0, atoi(e));      /* experiments: a tree priced as if it were deeper (the spilling stack, the smaller LDS image) */
     ctx->dev.root = ctx->bvh.root;
     ctx->dev.wide = ctx->bvh.wide ? 1u : 0u;
     ctx->dev.top_image = nullptr; ctx->dev.top_image_quads = 0u;

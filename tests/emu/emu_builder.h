@@ -14,12 +14,14 @@
 #include <string>
 #include <vector>
 
+#include <cstdio>
+#include "../../nori_amd/csrc/device/lbvh.h"
 #include "../../nori_amd/csrc/device/lbvh_steps.h"
 #include "../../nori_amd/csrc/device/scene_prep.h"
 
 namespace nrt {
 
-struct EmuBuilderStats { uint32_t ploc_iterations = 0; float sah_cost = 0.0f; };
+struct EmuBuilderStats { uint32_t ploc_iterations = 0, reinserted = 0; float sah_cost = 0.0f; };
 
 inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint32_t ploc_radius, HostBvh &out, EmuBuilderStats *stats = nullptr) {
     out = HostBvh();
@@ -92,15 +94,47 @@ inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint3
             if (node_base != n - 1u) return "PLOC node count";
             if (stats) stats->ploc_iterations = iterations;
             {   /* treelet restructuring (lbvh_steps.h), as build_bvh_lbvh_device runs it */
-                int sweeps = n <= (1u << 20) ? 2 : 0;
-                if (const char *e = std::getenv("NORI_HIP_TREELET_SWEEPS")) sweeps = std::max(0, atoi(e));
+                const BuildTuning rp = build_tuning(n);
+                const int sweeps = rp.sweeps;
                 std::vector<f4> nmn(n), nmx(n); std::vector<float> ncost(n);
                 TreeletData td{nmn.data(), nmx.data(), ncost.data()};
                 TreeletParams tp; tp.c_node = 1.0f; tp.c_tri = 1.0f;
                 std::vector<uint32_t> visits(n);
-                for (int sw = 0; sw < sweeps; ++sw) {
+                auto sweep = [&] {
                     std::fill(visits.begin(), visits.end(), 0u);
                     for (uint32_t k = 0; k < n; ++k) treelet_climb(pn, td, pos, idx, order.data(), pad, tp, visits.data(), n - 2u, k);
+                };
+                for (int sw = 0; sw < sweeps; ++sw) sweep();
+                /* parallel re-insertion (lbvh_steps.h), as build_bvh_lbvh_device runs it: every iteration the candidates of one
+                   residue class search the same tree, mark, check, the winners move, the tree is refitted */
+                if (rp.iterations > 0) {
+                    const uint32_t n_inner = n - 1u, n_slots = 2u * n - 1u;
+                    std::vector<f4> lmn(n), lmx(n);
+                    std::vector<unsigned long long> lock(n_slots), key(n_slots);
+                    std::vector<uint32_t> target(n_slots), pivot(n_slots), win(n_slots);
+                    ReinsData rd{lmn.data(), lmx.data(), lock.data(), key.data(), target.data(), pivot.data(), win.data()};
+                    for (uint32_t k = 0; k < n; ++k) tri_leaf_box(pos, idx, order[k], pad, lmn[k], lmx[k]);
+                    auto refit = [&] {
+                        std::fill(visits.begin(), visits.end(), 0u);
+                        for (uint32_t k = 0; k < n; ++k) reins_refit_climb(pn, td, rd, tp, visits.data(), n - 2u, k);
+                    };
+                    refit();
+                    uint32_t moved_total = 0;
+                    for (int it = 0; it < rp.iterations; ++it) {
+                        const uint32_t phase = (uint32_t) it % rp.stride;
+                        std::fill(lock.begin(), lock.end(), 0ull);
+                        std::fill(key.begin(), key.end(), 0ull);
+                        for (uint32_t sl = phase; sl < n_slots; sl += rp.stride) reins_search(pn, td, rd, n_inner, sl);
+                        for (uint32_t sl = phase; sl < n_slots; sl += rp.stride) (void) reins_locks(pn, rd, n_inner, sl, true);
+                        for (uint32_t sl = phase; sl < n_slots; sl += rp.stride) win[sl] = reins_locks(pn, rd, n_inner, sl, false) ? 1u : 0u;
+                        uint32_t moved = 0;
+                        for (uint32_t sl = phase; sl < n_slots; sl += rp.stride) if (win[sl]) { reins_apply(pn, rd, n_inner, sl); ++moved; }
+                        refit();
+                        moved_total += moved;
+                        if (std::getenv("NORI_HIP_BUILD_TIMING")) fprintf(stderr, "[reinsert] iteration %d: %u moved, root cost %.6g\n", it, moved, (double) ncost[n - 2u]);
+                    }
+                    if (stats) stats->reinserted = moved_total;
+                    for (int sw = 0; sw < rp.sweeps_after; ++sw) sweep();
                 }
             }
             for (uint32_t k = 0; k < n; ++k) { leaf_pos[k] = ploc_first_position(pn, n - 1u, kLeafBit | k); order2[leaf_pos[k]] = order[k]; }
@@ -187,7 +221,7 @@ inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint3
             if (keep[i]) emit_node(rnodes.data(), i, tmin.data(), tmax.data(), N, collapse.data(), pair_start.data(), node_index.data(),
                                    out.nodes.data() + (size_t) node_index[i] * kNodeQuads);
         uint32_t depth = 0;
-        for (uint32_t k = 0; k < n; ++k) depth = std::max(depth, leaf_depth(pin.data(), plf.data(), k));
+        for (uint32_t k = 0; k < n; ++k) depth = std::max(depth, leaf_depth(pin.data(), plf.data(), keep.data(), k));
         out.root = 0; out.n_nodes = n_nodes; out.n_leaves = 0; out.max_depth = depth;
     }
     if (stats) out.sah_cost = stats->sah_cost;

@@ -177,6 +177,20 @@ def test_tree_invariants_after_spatial_splits_and_reinsertion(monkeypatch):
         assert counts["default"]["sah_cost"] <= counts["plain"]["sah_cost"]
 
 
+@pytest.mark.parametrize("builder,env", [("lbvh", {}), ("ploc", {"NORI_HIP_REINSERT_ITERS": "0"}), ("ploc", {}), ("ploc", {"NORI_HIP_REINSERT_ITERS": "12", "NORI_HIP_REINSERT_STRIDE": "1"})])
+def test_tree_invariants_of_the_device_builders_trees(builder, env):
+    """The same structural check on what the DEVICE builders' steps emit (lbvh_steps.h run as loops, tests/emu/emu_builder.h): radix tree,
+    PLOC + sweeps, and after parallel re-insertion -- every winner's move relinks five nodes while others move elsewhere in the same
+    iteration; a torn tree would leave a node unreachable, reached twice, or a leaf range uncovered."""
+    from nori_amd.scene import Scene
+    table = Scene.load_npz(os.path.join(os.path.dirname(__file__), "golden", "pa5-table_mis.npz"))
+    table.camera.width = table.camera.height = 16; table.sample_count = 1
+    for sc, n_tris in ((_objects_on_planes(), 5006), (_mixed_soup(23, coincident=False), 3060), (table, 22766)):
+        e = _with_env(dict(env, NORI_EMU_BUILDER=builder, NORI_HIP_ACCEL_LAYOUT="bvh2"), lambda: Emu(sc))
+        leaves = _check_bvh2_invariants(e, n_tris)
+        assert leaves == e.accel_info()["n_nodes"] + 1
+
+
 def _objects_on_planes():
     """Small objects between planes many times their size -- the pa5 table scene's proportions."""
     from nori_amd.scene import Mesh
@@ -558,7 +572,7 @@ def test_treelet_sweeps_improve_the_ploc_tree():
     ref = Oracle(sc).intersect(rays)
     nodes = {}
     for sweeps in (0, 1, 2):
-        e = _with_env({"NORI_EMU_BUILDER": "ploc", "NORI_HIP_ACCEL_LAYOUT": "bvh2", "NORI_HIP_TREELET_SWEEPS": str(sweeps)}, lambda: Emu(sc))
+        e = _with_env({"NORI_EMU_BUILDER": "ploc", "NORI_HIP_ACCEL_LAYOUT": "bvh2", "NORI_HIP_TREELET_SWEEPS": str(sweeps), "NORI_HIP_REINSERT_ITERS": "0"}, lambda: Emu(sc))
         got = e.intersect(rays)
         assert all(np.array_equal(ref[k], got[k], equal_nan=ref[k].dtype.kind == "f") for k in ref.dtype.names), sweeps
         _, st = e.render_host(count_traversal=True)
@@ -569,6 +583,29 @@ def test_treelet_sweeps_improve_the_ploc_tree():
     sah = st["n_node_tests"] / (st["n_closest_rays"] + st["n_shadow_rays"])
     assert nodes[1] < 0.95 * nodes[0] and nodes[2] <= nodes[1] * 1.01, nodes
     assert nodes[2] < 1.02 * sah, (nodes, sah)
+
+
+@pytest.mark.parametrize("stride", [1, 3])
+def test_reinsertion_improves_the_ploc_tree(stride):
+    """Parallel re-insertion after PLOC and its sweeps (lbvh_steps.h: every candidate searches the same tree for the place where the
+    inner nodes' areas shrink most, marks what its move touches, the winners move, the tree is refitted): fewer node tests per ray than
+    without, on the Cornell box, the pa5 table and a patch of terrain; the same hits as the brute-force scan after every number of
+    iterations -- a move that tore the tree would lose triangles -- also with only every third slot a candidate per iteration."""
+    from nori_amd import workloads
+    for name, kw, need in (("pa4-cbox-path_mis", {}, 0.985), ("c4-table-mis", {}, 0.97), ("c5-terrain-10m", {"triangles": 20000}, 0.97)):
+        sc = workloads.load(name, width=32, height=32, spp=2, **kw).scene
+        rays = scenes.random_rays(3000, seed=33)
+        ref = Oracle(sc).intersect(rays)
+        nodes = {}
+        for iters in (0, 1, 8):
+            e = _with_env({"NORI_EMU_BUILDER": "ploc", "NORI_HIP_ACCEL_LAYOUT": "bvh2", "NORI_HIP_REINSERT_ITERS": str(iters * stride), "NORI_HIP_REINSERT_STRIDE": str(stride)},
+                          lambda: Emu(sc))
+            got = e.intersect(rays)
+            assert all(np.array_equal(ref[k], got[k], equal_nan=ref[k].dtype.kind == "f") for k in ref.dtype.names), (name, iters)
+            _, st = e.render_host(count_traversal=True)
+            nodes[iters] = st["n_node_tests"] / (st["n_closest_rays"] + st["n_shadow_rays"])
+            e.close()
+        assert nodes[8] < need * nodes[0] and nodes[8] < nodes[1] * 1.005, (name, nodes)
 
 
 # ---------------------------------------------------------------- 32-B node records (rt_nodeq.h) and wf_extend's leaf step
