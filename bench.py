@@ -75,7 +75,7 @@ def parse_args(argv=None):
     ap.add_argument("--engine", default="auto", choices=["auto", "megakernel", "wavefront"])
     ap.add_argument("--builder", default="auto", choices=["host", "lbvh", "auto", "ploc"],
                     help="nori_accel_builder: binned SAH with spatial splits on the host, or on the device: radix tree, PLOC + treelet sweeps + "
-                         "parallel re-insertion; auto (default) = host below 2^20 triangles, PLOC from there on (accel.builder / build_ms are in the line)")
+                         "parallel re-insertion; auto (default) = the device's builder (accel.builder / build_ms are in the line)")
     ap.add_argument("--emulate", action="store_true",
                     help="TEST ONLY (tests/test_distributed_cpu.py): run the same sharding / merge / reporting code on CPU "
                          "ranks (gloo) with the emulated device headers standing in for the GPU; never a fallback")
@@ -411,8 +411,8 @@ def main():
                      "tail_beside_ms": round(float(last.get("tail_ms", 0.0)), 3), "tail_cus": int(last.get("tail_cus", 0)),
                      "hbm_measured_bytes": (ctr[1].get("pass_hbm_bytes") if ctr else None)},
             "accel": dict({k: (round(v, 3) if isinstance(v, float) else v) for k, v in info.items()},
-                          # auto (nori_hip_build_accel): the device's PLOC builder from 2^20 triangles, the host's SAH builder below
-                          builder=args.builder if args.builder != "auto" else ("ploc" if info["n_triangles"] >= (1 << 20) else "host"), builder_asked=args.builder),
+                          # auto (nori_hip_build_accel): the device's builder (PLOC), the host's SAH builder as its fall-back
+                          builder=args.builder if args.builder != "auto" else ("ploc" if info["built_on_device"] else "host"), builder_asked=args.builder),
         }
         if world > 1 or merge_ms:
             out["ranks"] = [{"rank": k, "ms_per_step": round(float(v[0]), 3), "kernel_ms": round(float(v[1]), 3), "merge_ms": round(float(v[2]), 3),

@@ -38,7 +38,7 @@ extern "C" {
  * before its first call that passes such a struct, and refuses to go on if they differ (the host library and the Python
  * bindings of this repository do).  Bumped whenever a struct of this header changes size or layout, an enum value changes
  * meaning, or an entry point changes its signature. */
-#define NORI_HIP_ABI_VERSION 6      /* round 6: nori_render_stats as of round 5 (tail_ms, tail_cus); option "wavefront_samples" */
+#define NORI_HIP_ABI_VERSION 7      /* round 6: nori_render_stats as of round 5 (tail_ms, tail_cus); option "wavefront_samples"; nori_accel_info: built_on_device, n_references */
 int nori_hip_abi_version(void);
 
 /* ------------------------------------------------------------------ enums */
@@ -119,13 +119,13 @@ typedef enum nori_seed_mode {
 typedef enum nori_accel_builder {
     NORI_ACCEL_HOST_SAH = 0,   /* binned SAH on the host, uploaded            */
     NORI_ACCEL_GPU_LBVH = 1,   /* built on the device: Morton order + radix tree (1.5 ms per million triangles)   */
-    NORI_ACCEL_AUTO = 2,       /* HOST_SAH below 2^20 triangles (spatial splits; 30 - 90 ms), GPU_PLOC from there on (142 ms
-                                  instead of 2.4 s for 10 M triangles; traversal within 1.5 % of the host tree's) */
-    NORI_ACCEL_GPU_PLOC = 3    /* built on the device: Morton order + nearest-neighbour clustering (PLOC, 3 ms per million
-                                  triangles) + treelet restructuring (a wave per treelet, 2 - 3 ms per million triangles and
-                                  sweep) + parallel re-insertion (1 ms per million candidates); never worse than the radix
-                                  tree, up to 25 % faster to traverse; Cornell box and terrain: within 1.5 % of HOST_SAH,
-                                  scenes that need spatial splits (pa5 table): 34 % behind */
+    NORI_ACCEL_AUTO = 2,       /* GPU_PLOC; HOST_SAH if the device's tree comes out deeper than the traversal stack */
+    NORI_ACCEL_GPU_PLOC = 3    /* built on the device: triangles whose boxes are several times the scene's typical one and hold other
+                                  geometry enter as several parts (spatial splits up front), Morton order, nearest-neighbour
+                                  clustering (PLOC, 3 ms per million triangles), treelet restructuring (a wave per treelet, 2 - 3 ms
+                                  per million triangles and sweep), parallel re-insertion (1 ms per million candidates).
+                                  wf_extend against HOST_SAH's tree: Cornell box +0.8 %, pa5 table +0.7 %, AO scene +-1 %, terrain of
+                                  10 M triangles +2.7 %; built in 19 / 28 / 33 / 144 ms against 30 / 56 / 90 / 2 400 */
 } nori_accel_builder;
 
 /* ------------------------------------------------------ scene description */
@@ -282,6 +282,9 @@ typedef struct nori_accel_info {
     uint32_t node_records_32b;  /* 1: the tree also exists as 32-B node records (two children's boxes as 16-bit planes on one
                                 grid + the links), which the wavefront engine's hand-written node loop walks when the tree's
                                 traversal stack fits LDS (depth <= 16); BVH2 trees without unbounded boxes only */
+    uint32_t built_on_device;   /* 1: the tree was built by HIP kernels (lbvh.hip), 0: by the host's SAH builder and uploaded */
+    uint32_t n_references;      /* device builder: (triangle, box) references the tree holds -- the triangles, plus the parts of those that
+                                   were split; 0: built on the host */
 } nori_accel_info;
 
 typedef struct nori_hip_ctx nori_hip_ctx;

@@ -91,7 +91,7 @@ class AccelInfo(C.Structure):
     _fields_ = [("n_triangles", C.c_uint32), ("n_nodes", C.c_uint32), ("n_leaves", C.c_uint32),
                 ("max_depth", C.c_uint32), ("node_bytes", C.c_uint32), ("tri_bytes", C.c_uint32),
                 ("total_bytes", C.c_uint64), ("build_ms", C.c_float), ("sah_cost", C.c_float),
-                ("node_children", C.c_uint32), ("node_records_32b", C.c_uint32)]
+                ("node_children", C.c_uint32), ("node_records_32b", C.c_uint32), ("built_on_device", C.c_uint32), ("n_references", C.c_uint32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -111,7 +111,7 @@ assert RAY_DTYPE.itemsize == 32 and ITS_DTYPE.itemsize == 104
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
 
-HIP_ABI_VERSION = 6      # NORI_HIP_ABI_VERSION of the include/nori_hip.h these ctypes structs mirror
+HIP_ABI_VERSION = 7      # NORI_HIP_ABI_VERSION of the include/nori_hip.h these ctypes structs mirror
 
 #: every symbol include/nori_hip.h declares -> (restype, argtypes)
 HIP_PROTOTYPES = {

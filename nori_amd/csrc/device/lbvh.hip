@@ -81,16 +81,53 @@ __global__ void k_scene_bounds(const f4 *pos, const uint32_t *idx, uint32_t n, u
     else if (threadIdx.x < 6) atomicMax(&bounds[threadIdx.x], s[threadIdx.x]);
 }
 
-__global__ void k_morton(const f4 *pos, const uint32_t *idx, uint32_t n, f3 smin, f3 sinv, unsigned long long *keys, uint32_t *vals) {
+/* ---- references (lbvh_steps.h): which triangles enter the tree as several parts, and the parts ---- */
+/* priorities; their bit patterns summed (the scene's typical priority: lbvh.h, split_scale_D) */
+__global__ void k_split_priority(const f4 *pos, const uint32_t *idx, uint32_t n, f3 smin, f3 sinv, float *prio, unsigned long long *sums) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const float p = t < n ? split_priority(pos, idx, t, smin, sinv) : 0.0f;
+    if (t < n) prio[t] = p;
+    unsigned long long bits = p > 0.0f ? (unsigned long long) __float_as_uint(p) : 0ull, have = p > 0.0f ? 1ull : 0ull;
+    for (int off = 32; off > 0; off >>= 1) { bits += __shfl_down(bits, off); have += __shfl_down(have, off); }
+    if ((threadIdx.x & 63u) == 0u && have) { atomicAdd(&sums[0], bits); atomicAdd(&sums[1], have); }
+}
+__global__ void k_split_grid(const f4 *pos, const uint32_t *idx, uint32_t n, f3 smin, f3 sinv, uint32_t *cells) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n || tri_unbounded(pos, idx, t)) return;
+    f3 mn, mx; tri_box(pos, idx, t, mn, mx);
+    atomicAdd(&cells[split_grid_cell(mn, mx, smin, sinv)], 1u);
+}
+/* cuts a triangle may take at most: what else lies in its box (sat: the summed-volume table of k_split_grid's counts) */
+__global__ void k_split_limit(const f4 *pos, const uint32_t *idx, uint32_t n, f3 smin, f3 sinv, const float *prio, const uint32_t *sat, uint32_t cap, uint32_t inside, uint32_t *limit) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    vals[t] = t;
-    /* numerically collinear triangles (rt_types.h, tri_box_pad) sort behind everything else: bit 63 makes
-       the root split them from the spatial hierarchy */
-    if (tri_unbounded(pos, idx, t)) { keys[t] = 0x8000000000000000ull; return; }
-    f3 mn, mx; tri_box(pos, idx, t, mn, mx);
-    keys[t] = morton63(mn, mx, smin, sinv);
+    uint32_t l = cap;
+    if (inside > 0u && prio[t] > 0.0f) { f3 mn, mx; tri_box(pos, idx, t, mn, mx); l = min(cap, split_inside(sat, mn, mx, smin, sinv) / inside); }
+    limit[t] = l;
 }
+__global__ void k_split_total(const float *prio, const uint32_t *limit, uint32_t n, float D, unsigned long long *total) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = t < n ? (unsigned long long) split_count(prio[t], D, limit[t]) : 0ull;
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if ((threadIdx.x & 63u) == 0u && c) atomicAdd(total, c);
+}
+/* references per triangle (write = false) / the references themselves at their place ref_first[t] */
+__global__ void k_split_emit(const f4 *pos, const uint32_t *idx, uint32_t n, const float *prio, const uint32_t *limit, float D, float pad0, f3 smin, f3 sinv,
+                             bool write, uint32_t *count, const uint32_t *ref_first, RefOut out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t cuts = prio ? split_count(prio[t], D, limit[t]) : 0u;
+    const uint32_t c = split_emit(pos, idx, t, cuts, pad0, smin, sinv, write, out, write ? ref_first[t] : 0u);
+    if (!write) count[t] = c;
+}
+/* the sorted references: triangle and padded box by position */
+__global__ void k_refs_gather(const uint32_t *sorted_ref, uint32_t n, RefOut refs, uint32_t *tri, f4 *lmn, f4 *lmx) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t r = sorted_ref[k];
+    tri[k] = refs.tri[r]; lmn[k] = refs.mn[r]; lmx[k] = refs.mx[r];
+}
+__global__ void k_iota(uint32_t *v, uint32_t n) { const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; if (k < n) v[k] = k; }
 
 __global__ void k_hierarchy(const unsigned long long *keys, int n, RadixNode *nodes, uint32_t *parent_inner, uint32_t *parent_leaf) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -99,10 +136,10 @@ __global__ void k_hierarchy(const unsigned long long *keys, int n, RadixNode *no
 }
 
 /* ---- PLOC ---- */
-__global__ void k_ploc_init(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, float pad0, PlocClusters c) {
+__global__ void k_ploc_init(const f4 *lmn, const f4 *lmx, uint32_t n, PlocClusters c) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
-    f4 mn, mx; tri_leaf_box(pos, idx, order[k], pad0, mn, mx);
+    f4 mn = lmn[k], mx = lmx[k];
     mn.w = __uint_as_float(kLeafBit | k); mx.w = __uint_as_float(1u);
     c.mn[k] = mn; c.mx[k] = mx;
 }
@@ -124,10 +161,9 @@ __global__ void k_ploc_apply(PlocClusters in, PlocClusters out, PlocNodes nodes,
     const unsigned long long f = flags[i], r = incl[i] - f;      /* exclusive ranks */
     ploc_apply(in, out, nodes, nearest, i, (uint32_t) (f >> 32), (uint32_t) f & 1u, (uint32_t) (r >> 32), (uint32_t) r, node_base);
 }
-__global__ void k_treelet(PlocNodes nodes, TreeletData td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad, TreeletParams tp,
-                          uint32_t *visits, uint32_t n) {
+__global__ void k_treelet(PlocNodes nodes, TreeletData td, TreeletParams tp, uint32_t *visits, uint32_t n) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) treelet_climb(nodes, td, pos, idx, order, pad, tp, visits, n - 2u, k);
+    if (k < n) treelet_climb(nodes, td, tp, visits, n - 2u, k);
 }
 
 /* ---- a WAVE per treelet (Karras & Aila's layout, for 64 lanes).  One thread per treelet spends a sweep in 1.1 KB of scratch per
@@ -151,9 +187,8 @@ struct TreeletShared {
     int go;
 };
 
-__device__ void treelet_optimize_wave(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
-                                      TreeletParams tp, const TreeletTable &tab, uint32_t id, TreeletShared &sh, int lane) {
-    if (lane == 0) sh.go = treelet_form(nodes, td, pos, idx, order, pad, tp, id, sh.w) ? 1 : 0;
+__device__ void treelet_optimize_wave(const PlocNodes &nodes, const TreeletData &td, TreeletParams tp, const TreeletTable &tab, uint32_t id, TreeletShared &sh, int lane) {
+    if (lane == 0) sh.go = treelet_form(nodes, td, tp, id, sh.w) ? 1 : 0;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
     if (!sh.go) return;                                    /* wave-uniform */
     const int k = sh.w.k, full = (1 << k) - 1;
@@ -183,8 +218,7 @@ __device__ void treelet_optimize_wave(const PlocNodes &nodes, const TreeletData 
 }
 
 constexpr int kTreeletWaves = 4;      /* per workgroup */
-__global__ __launch_bounds__(64 * kTreeletWaves) void k_treelet_wave(PlocNodes nodes, TreeletData td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
-                                                                     TreeletParams tp, TreeletTable tab, uint32_t *visits, uint32_t n) {
+__global__ __launch_bounds__(64 * kTreeletWaves) void k_treelet_wave(PlocNodes nodes, TreeletData td, TreeletParams tp, TreeletTable tab, uint32_t *visits, uint32_t n) {
     __shared__ TreeletShared s_sh[kTreeletWaves];
     TreeletShared &sh = s_sh[threadIdx.x >> 6];
     const int lane = (int) (threadIdx.x & 63u);
@@ -204,17 +238,13 @@ __global__ __launch_bounds__(64 * kTreeletWaves) void k_treelet_wave(PlocNodes n
         }
         for (unsigned long long pend = __ballot(second); pend != 0ull; pend &= pend - 1ull) {
             const uint32_t id = (uint32_t) __shfl((int) p, __ffsll((long long) pend) - 1);
-            treelet_optimize_wave(nodes, td, pos, idx, order, pad, tp, tab, id, sh, lane);
+            treelet_optimize_wave(nodes, td, tp, tab, id, sh, lane);
         }
         if (active) { if (p == root_id) active = false; else p = coh_ld(&nodes.parent_node[p]); }      /* (the node's own parent is not touched by its treelet) */
         if (__ballot(active) == 0ull) break;
     }
 }
 /* ---- parallel re-insertion (lbvh_steps.h): one thread per candidate slot of the iteration's residue class ---- */
-__global__ void k_reins_leaf_boxes(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, float pad0, ReinsData rd) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < n) tri_leaf_box(pos, idx, order[k], pad0, rd.lmn[k], rd.lmx[k]);
-}
 __global__ void k_reins_search(PlocNodes nodes, TreeletData td, ReinsData rd, uint32_t n_inner, uint32_t n_slots, uint32_t phase, uint32_t stride) {
     const uint32_t slot = phase + (blockIdx.x * blockDim.x + threadIdx.x) * stride;
     if (slot >= n_slots) return;
@@ -250,11 +280,11 @@ __global__ void k_reins_refit(PlocNodes nodes, TreeletData td, ReinsData rd, Tre
     }
 }
 
-__global__ void k_ploc_leaf_positions(PlocNodes nodes, uint32_t n, const uint32_t *order, uint32_t *leaf_pos, uint32_t *order_out) {
+__global__ void k_ploc_leaf_positions(PlocNodes nodes, uint32_t n, const uint32_t *order, const f4 *lmn, const f4 *lmx, uint32_t *leaf_pos, uint32_t *order_out, f4 *lmn_out, f4 *lmx_out) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint32_t p = ploc_first_position(nodes, n - 1u, kLeafBit | k);
-    leaf_pos[k] = p; order_out[p] = order[k];
+    leaf_pos[k] = p; order_out[p] = order[k]; lmn_out[p] = lmn[k]; lmx_out[p] = lmx[k];
 }
 __global__ void k_ploc_finish(PlocNodes nodes, uint32_t n_nodes, const uint32_t *leaf_pos, RadixNode *out, uint32_t *parent_inner, uint32_t *parent_leaf) {
     const uint32_t id = blockIdx.x * blockDim.x + threadIdx.x;
@@ -263,11 +293,11 @@ __global__ void k_ploc_finish(PlocNodes nodes, uint32_t n_nodes, const uint32_t 
 }
 
 /* segment tree over the padded triangle boxes in the builder's order: entries [N + k] */
-__global__ void k_leaf_boxes(const f4 *pos, const uint32_t *idx, const uint32_t *order, uint32_t n, uint32_t N, float pad0, f4 *tmin, f4 *tmax) {
+__global__ void k_leaf_boxes(const f4 *lmn, const f4 *lmx, uint32_t n, uint32_t N, f4 *tmin, f4 *tmax) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     f4 mn4, mx4;
-    if (k < n) tri_leaf_box(pos, idx, order[k], pad0, mn4, mx4);
+    if (k < n) { mn4 = lmn[k]; mx4 = lmx[k]; mn4.w = mx4.w = 0.0f; }
     else { mn4.x = mn4.y = mn4.z = kInf; mx4.x = mx4.y = mx4.z = -kInf; mn4.w = mx4.w = 0.0f; }
     tmin[N + k] = mn4; tmax[N + k] = mx4;
 }
@@ -356,7 +386,8 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     out = LbvhDeviceResult();
     if (dev.n_triangles <= 4) wide = false;                  /* a single leaf: no nodes at all */
     const uint32_t pair_base = wide ? 1u : 0u;               /* wide trees reserve pair 0 as the all-zero pair of unused slots */
-    const uint32_t n = dev.n_triangles;
+    const uint32_t n_tris = dev.n_triangles;
+    uint32_t n = n_tris;                                     /* from step 2 on: the REFERENCES the tree is built over */
     struct Events {      /* released on every return path */
         hipEvent_t a = nullptr, b = nullptr;
         ~Events() { if (a) (void) hipEventDestroy(a); if (b) (void) hipEventDestroy(b); }
@@ -377,7 +408,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
         t_lap = t;
     };
     const int B = 256;
-    const uint32_t gridN = (n + B - 1) / B;
+    uint32_t gridN = (n + B - 1) / B;
 
     /* 1. scene bounds */
     Buf bounds; LB_TRY(bounds.alloc(6 * sizeof(unsigned int)));
@@ -391,19 +422,91 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
     const float pad = box_pad_rel() * sqrtf(ex * ex + ey * ey + ez * ez) + 1e-30f;    /* as scene_prep.cpp */
     const f3 sinv = mk3(ex > 0 ? 1.0f / ex : 0.0f, ey > 0 ? 1.0f / ey : 0.0f, ez > 0 ? 1.0f / ez : 0.0f);
 
-    /* 7 first: the triangle records only need the sorted order; tiny scenes are one leaf */
-    Buf keys_a, keys_b, vals_a, vals_b;
-    LB_TRY(keys_a.alloc((size_t) n * 8)); LB_TRY(keys_b.alloc((size_t) n * 8));
+    /* 2. references (lbvh_steps.h): every triangle once, or -- where a box is several times what is typical for the scene and holds other
+       geometry -- as several parts */
+    const SplitTuning stn = split_tuning(n_tris);
+    Buf s_prio, s_limit, s_count, s_first, r_tri, r_mn, r_mx, r_key;
+    float split_D = 0.0f;
+    if (stn.budget > 0.0f && ploc_radius != 0u) {      /* (the radix tree splits space by the keys' bits: parts of one triangle would only deepen it) */
+        Buf sums, cells, sat;
+        LB_TRY(s_prio.alloc((size_t) n_tris * 4)); LB_TRY(s_limit.alloc((size_t) n_tris * 4));
+        LB_TRY(sums.alloc(3 * 8)); LB_TRY(hipMemset(sums.p, 0, 3 * 8));
+        hipLaunchKernelGGL(k_split_priority, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n_tris, smin, sinv, s_prio.as<float>(), sums.as<unsigned long long>());
+        unsigned long long hs[2] = {0ull, 0ull};
+        LB_TRY(hipMemcpy(hs, sums.p, 16, hipMemcpyDeviceToHost));
+        const float D_scale = split_scale_D(hs[0], hs[1], stn.scale);
+        if (hs[1] > 0ull && D_scale > 0.0f) {
+            if (stn.inside > 0u) {
+                const int G = kSplitGrid, G1 = kSplitGrid + 1;
+                std::vector<uint32_t> h_cells((size_t) G * G * G), h_sat((size_t) G1 * G1 * G1, 0u);
+                LB_TRY(cells.alloc(h_cells.size() * 4)); LB_TRY(hipMemset(cells.p, 0, h_cells.size() * 4));
+                hipLaunchKernelGGL(k_split_grid, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n_tris, smin, sinv, cells.as<uint32_t>());
+                LB_TRY(hipMemcpy(h_cells.data(), cells.p, h_cells.size() * 4, hipMemcpyDeviceToHost));
+                split_sat(h_cells.data(), h_sat.data());
+                LB_TRY(sat.alloc(h_sat.size() * 4));
+                LB_TRY(hipMemcpy(sat.p, h_sat.data(), h_sat.size() * 4, hipMemcpyHostToDevice));
+            }
+            hipLaunchKernelGGL(k_split_limit, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n_tris, smin, sinv, s_prio.as<float>(), sat.as<uint32_t>(), stn.cap, stn.inside, s_limit.as<uint32_t>());
+            std::string total_err;
+            auto total = [&](float D) -> unsigned long long {
+                unsigned long long h = 0ull;
+                if (hipMemsetAsync(sums.as<unsigned long long>() + 2, 0, 8, 0) != hipSuccess) total_err = "lbvh: split total";
+                hipLaunchKernelGGL(k_split_total, dim3(gridN), dim3(B), 0, 0, s_prio.as<float>(), s_limit.as<uint32_t>(), n_tris, D, sums.as<unsigned long long>() + 2);
+                if (hipMemcpy(&h, sums.as<unsigned long long>() + 2, 8, hipMemcpyDeviceToHost) != hipSuccess) total_err = "lbvh: split total";
+                return h;
+            };
+            split_D = split_choose_D(total, (unsigned long long) ((double) stn.budget * (double) n_tris), D_scale);
+            if (split_D > 0.0f && total(split_D) == 0ull) split_D = 0.0f;      /* nothing to cut (a mesh of like-sized triangles): the references are the triangles */
+            if (!total_err.empty()) return total_err;
+        }
+    }
+    {
+        const bool cutting = split_D > 0.0f;
+        RefOut none{nullptr, nullptr, nullptr, nullptr};
+        uint32_t m = n_tris;
+        if (cutting) {
+            LB_TRY(s_count.alloc((size_t) n_tris * 4)); LB_TRY(s_first.alloc((size_t) n_tris * 4));
+            hipLaunchKernelGGL(k_split_emit, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n_tris, s_prio.as<float>(), s_limit.as<uint32_t>(), split_D, pad, smin, sinv,
+                               false, s_count.as<uint32_t>(), (const uint32_t *) nullptr, none);
+            size_t scan_bytes = 0;
+            LB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, s_count.as<uint32_t>(), s_first.as<uint32_t>(), (int) n_tris));
+            Buf scan_tmp; LB_TRY(scan_tmp.alloc(scan_bytes));
+            LB_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp.p, scan_bytes, s_count.as<uint32_t>(), s_first.as<uint32_t>(), (int) n_tris));
+            uint32_t last[2] = {0u, 0u};
+            LB_TRY(hipMemcpy(&last[0], s_first.as<uint32_t>() + (n_tris - 1), 4, hipMemcpyDeviceToHost));
+            LB_TRY(hipMemcpy(&last[1], s_count.as<uint32_t>() + (n_tris - 1), 4, hipMemcpyDeviceToHost));
+            m = last[0] + last[1];
+        } else {
+            LB_TRY(s_first.alloc((size_t) n_tris * 4));
+            hipLaunchKernelGGL(k_iota, dim3(gridN), dim3(B), 0, 0, s_first.as<uint32_t>(), n_tris);
+        }
+        LB_TRY(r_tri.alloc((size_t) m * 4)); LB_TRY(r_mn.alloc((size_t) m * 16)); LB_TRY(r_mx.alloc((size_t) m * 16)); LB_TRY(r_key.alloc((size_t) m * 8));
+        const RefOut refs{r_tri.as<uint32_t>(), r_mn.as<f4>(), r_mx.as<f4>(), r_key.as<unsigned long long>()};
+        hipLaunchKernelGGL(k_split_emit, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n_tris, cutting ? s_prio.as<float>() : (const float *) nullptr, s_limit.as<uint32_t>(), split_D, pad, smin, sinv,
+                           true, (uint32_t *) nullptr, s_first.as<uint32_t>(), refs);
+        LB_TRY(hipGetLastError());
+        n = m; gridN = (n + B - 1) / B;
+        out.n_refs = m;
+    }
+    lap("references");
+
+    /* 3. sorted by Morton key; then by position: the reference's triangle (order) and padded box (lmn / lmx) */
+    Buf keys_b, vals_a, vals_b, o_tri, o_tri2, l_mn, l_mx, l_mn2, l_mx2;
+    LB_TRY(keys_b.alloc((size_t) n * 8));
     LB_TRY(vals_a.alloc((size_t) n * 4)); LB_TRY(vals_b.alloc((size_t) n * 4));
-    hipLaunchKernelGGL(k_morton, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, n, smin, sinv, keys_a.as<unsigned long long>(), vals_a.as<uint32_t>());
+    LB_TRY(o_tri.alloc((size_t) n * 4)); LB_TRY(l_mn.alloc((size_t) n * 16)); LB_TRY(l_mx.alloc((size_t) n * 16));
+    hipLaunchKernelGGL(k_iota, dim3(gridN), dim3(B), 0, 0, vals_a.as<uint32_t>(), n);
     size_t temp_bytes = 0;
-    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(),
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, r_key.as<unsigned long long>(), keys_b.as<unsigned long long>(),
                                               vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), (int) n, 0, 64));
     Buf temp; LB_TRY(temp.alloc(temp_bytes));
-    LB_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, keys_a.as<unsigned long long>(), keys_b.as<unsigned long long>(),
+    LB_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, temp_bytes, r_key.as<unsigned long long>(), keys_b.as<unsigned long long>(),
                                               vals_a.as<uint32_t>(), vals_b.as<uint32_t>(), (int) n, 0, 64));
+    hipLaunchKernelGGL(k_refs_gather, dim3(gridN), dim3(B), 0, 0, vals_b.as<uint32_t>(), n, RefOut{r_tri.as<uint32_t>(), r_mn.as<f4>(), r_mx.as<f4>(), r_key.as<unsigned long long>()},
+                       o_tri.as<uint32_t>(), l_mn.as<f4>(), l_mx.as<f4>());
     const unsigned long long *keys = keys_b.as<unsigned long long>();
-    const uint32_t *order = vals_b.as<uint32_t>();      /* position in the builder's order -> global triangle */
+    const uint32_t *order = o_tri.as<uint32_t>();      /* position in the builder's order -> global triangle */
+    const f4 *lmn = l_mn.as<f4>(), *lmx = l_mx.as<f4>();
 
     /* leaves: start positions, triangle counts, pair counts -> first pair of every leaf */
     Buf leaf_cnt, leaf_pairs, pair_start, rnodes, pin, plf, keep, node_index, collapse, tmin, tmax;
@@ -432,7 +535,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
             LB_TRY(scan_tmp.alloc(scan_bytes));
             PlocClusters ca{ca_mn.as<f4>(), ca_mx.as<f4>()}, cb{cb_mn.as<f4>(), cb_mx.as<f4>()};
             PlocNodes pn{nl.as<uint32_t>(), nr.as<uint32_t>(), nc.as<uint32_t>(), npn.as<uint32_t>(), npp.as<uint32_t>()};
-            hipLaunchKernelGGL(k_ploc_init, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, order, n, pad, ca);
+            hipLaunchKernelGGL(k_ploc_init, dim3(gridN), dim3(B), 0, 0, lmn, lmx, n, ca);
             uint32_t m = n, node_base = 0u, iterations = 0u;
             while (m > 1u) {
                 const dim3 g((m + B - 1) / B);
@@ -470,7 +573,7 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
                 if (sweeps > 0 || rp.iterations > 0) {
                     Buf t_mn, t_mx, t_cost, t_visits;
                     LB_TRY(t_mn.alloc((size_t) n * 16)); LB_TRY(t_mx.alloc((size_t) n * 16)); LB_TRY(t_cost.alloc((size_t) n * 4)); LB_TRY(t_visits.alloc((size_t) n * 4));
-                    TreeletData td{t_mn.as<f4>(), t_mx.as<f4>(), t_cost.as<float>()};
+                    TreeletData td{t_mn.as<f4>(), t_mx.as<f4>(), t_cost.as<float>(), lmn, lmx};
                     TreeletParams tp; tp.c_node = 1.0f; tp.c_tri = 1.0f;
                     /* the (subset, partition) pairs of the dynamic programme for 3 .. 7 leaves, by subset size, partitions in the serial
                        loop's order (treelet_first_partition / treelet_next_partition): 1 388 pairs */
@@ -497,22 +600,19 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
                     auto sweep = [&]() -> hipError_t {
                         hipError_t e = hipMemsetAsync(t_visits.p, 0, (size_t) n * 4, 0);
                         if (e != hipSuccess) return e;
-                        if (serial) hipLaunchKernelGGL(k_treelet, dim3((n + 63) / 64), dim3(64), 0, 0, pn, td, dev.positions, dev.indices, order, pad, tp, t_visits.as<uint32_t>(), n);
-                        else hipLaunchKernelGGL(k_treelet_wave, dim3((n + 64 * kTreeletWaves - 1) / (64 * kTreeletWaves)), dim3(64 * kTreeletWaves), 0, 0, pn, td, dev.positions, dev.indices, order, pad, tp,
-                                                tab, t_visits.as<uint32_t>(), n);
+                        if (serial) hipLaunchKernelGGL(k_treelet, dim3((n + 63) / 64), dim3(64), 0, 0, pn, td, tp, t_visits.as<uint32_t>(), n);
+                        else hipLaunchKernelGGL(k_treelet_wave, dim3((n + 64 * kTreeletWaves - 1) / (64 * kTreeletWaves)), dim3(64 * kTreeletWaves), 0, 0, pn, td, tp, tab, t_visits.as<uint32_t>(), n);
                         return hipGetLastError();
                     };
                     for (int sw = 0; sw < sweeps; ++sw) LB_TRY(sweep());
                     lap("treelet sweeps");
                     if (rp.iterations > 0) {
                         const uint32_t n_inner = n - 1u, n_slots = 2u * n - 1u;
-                        Buf r_lmn, r_lmx, r_lock, r_key, r_target, r_pivot, r_win, r_moved;
-                        LB_TRY(r_lmn.alloc((size_t) n * 16)); LB_TRY(r_lmx.alloc((size_t) n * 16));
-                        LB_TRY(r_lock.alloc((size_t) n_slots * 8)); LB_TRY(r_key.alloc((size_t) n_slots * 8));
+                        Buf r_lock, r_rkey, r_target, r_pivot, r_win, r_moved;
+                        LB_TRY(r_lock.alloc((size_t) n_slots * 8)); LB_TRY(r_rkey.alloc((size_t) n_slots * 8));
                         LB_TRY(r_target.alloc((size_t) n_slots * 4)); LB_TRY(r_pivot.alloc((size_t) n_slots * 4)); LB_TRY(r_win.alloc((size_t) n_slots * 4));
                         LB_TRY(r_moved.alloc(4)); LB_TRY(hipMemsetAsync(r_moved.p, 0, 4, 0));
-                        ReinsData rd{r_lmn.as<f4>(), r_lmx.as<f4>(), r_lock.as<unsigned long long>(), r_key.as<unsigned long long>(), r_target.as<uint32_t>(), r_pivot.as<uint32_t>(), r_win.as<uint32_t>()};
-                        hipLaunchKernelGGL(k_reins_leaf_boxes, dim3(gridN), dim3(B), 0, 0, dev.positions, dev.indices, order, n, pad, rd);
+                        ReinsData rd{r_lock.as<unsigned long long>(), r_rkey.as<unsigned long long>(), r_target.as<uint32_t>(), r_pivot.as<uint32_t>(), r_win.as<uint32_t>()};
                         auto refit = [&]() -> hipError_t {
                             hipError_t e = hipMemsetAsync(t_visits.p, 0, (size_t) n * 4, 0);
                             if (e != hipSuccess) return e;
@@ -542,15 +642,16 @@ std::string build_bvh_lbvh_device(const DevScene &dev, const uint32_t *d_tri_mes
                 }
             }
             /* the order of the tree's leaves, left to right: every node covers a contiguous range of it */
-            hipLaunchKernelGGL(k_ploc_leaf_positions, dim3(gridN), dim3(B), 0, 0, pn, n, order, leaf_pos.as<uint32_t>(), vals_a.as<uint32_t>());
+            LB_TRY(o_tri2.alloc((size_t) n * 4)); LB_TRY(l_mn2.alloc((size_t) n * 16)); LB_TRY(l_mx2.alloc((size_t) n * 16));
+            hipLaunchKernelGGL(k_ploc_leaf_positions, dim3(gridN), dim3(B), 0, 0, pn, n, order, lmn, lmx, leaf_pos.as<uint32_t>(), o_tri2.as<uint32_t>(), l_mn2.as<f4>(), l_mx2.as<f4>());
             hipLaunchKernelGGL(k_ploc_finish, dim3(gridN), dim3(B), 0, 0, pn, n - 1u, leaf_pos.as<uint32_t>(), rnodes.as<RadixNode>(), pin.as<uint32_t>(), plf.as<uint32_t>());
             LB_TRY(hipDeviceSynchronize());
-            order = vals_a.as<uint32_t>();
+            order = o_tri2.as<uint32_t>(); lmn = l_mn2.as<f4>(); lmx = l_mx2.as<f4>();
         }
         /* 5. segment tree of boxes */
         N = 1; while (N < n) N <<= 1;
         LB_TRY(tmin.alloc((size_t) 2 * N * sizeof(f4))); LB_TRY(tmax.alloc((size_t) 2 * N * sizeof(f4)));
-        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, dev.positions, dev.indices, order, n, N, pad, tmin.as<f4>(), tmax.as<f4>());
+        hipLaunchKernelGGL(k_leaf_boxes, dim3((N + B - 1) / B), dim3(B), 0, 0, lmn, lmx, n, N, tmin.as<f4>(), tmax.as<f4>());
         for (uint32_t first = N >> 1; first >= 1; first >>= 1) {
             hipLaunchKernelGGL(k_tree_level, dim3((first + B - 1) / B), dim3(B), 0, 0, first, first, tmin.as<f4>(), tmax.as<f4>());
             if (first == 1) break;

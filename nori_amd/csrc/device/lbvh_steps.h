@@ -217,6 +217,191 @@ NORI_HD void tri_leaf_box(const f4 *pos, const uint32_t *idx, uint32_t g, float 
     mn4.x = mn.x - pad; mn4.y = mn.y - pad; mn4.z = mn.z - pad; mx4.x = mx.x + pad; mx4.y = mx.y + pad; mx4.z = mx.z + pad;
     mn4.w = mx4.w = 0.0f;
 }
+/* ---- references: triangles split before the tree is built (after Karras & Aila 2013, section 4) ----
+ * The builders cluster REFERENCES -- (triangle, box) -- and a triangle may enter as several, each with the box of the part of the
+ * triangle inside one cell; the same triangle then hangs in several leaves (as under the host builder's spatial splits: a leaf whose
+ * part the ray misses is not visited, the hit is the scan's either way).  Which triangles, and how often:
+ *   split_priority   p = (2^-level V^(2/3))^(1/3), V = the VOLUME of the triangle's box in units of the scene box, level = that of the
+ *                    coarsest plane of the Morton grid that crosses the box.  Karras & Aila weigh the box's area beyond what a finely
+ *                    split triangle's boxes would have; that also cuts every large axis-parallel triangle -- floors, walls, table tops --
+ *                    whose parts are flat boxes the size of many objects: a clustering builder stacks them into a subtree of their own
+ *                    that every ray along the floor walks (pa5 table, node tests per ray 10.8 -> 15.1 for triangle tests 8.3 -> 5.1;
+ *                    with the volume 9.8 and 5.0: profiles/r6_20_split_cpu_counts.txt).  A flat box overlaps nothing: cutting it
+ *                    saves a triangle test at the price of node tests.  A box with volume holds other geometry in its empty part
+ *   split_count      min(limit, floor(D p)): D = one cut per `scale` typical priorities of the scene (lbvh.h, split_scale_D), lowered
+ *                    if the counts exceed the budget; limit = what split_inside finds in the box
+ *   split_emit       the triangle's <= 1 + count references: a part is cut by the coarsest grid plane that crosses its box -- parts of
+ *                    different triangles end on the same planes, so the clustering finds them side by side -- and hands its
+ *                    remaining cuts to the halves in proportion to their boxes' areas.
+ * A part's box is the box of (triangle clipped to the part's cell) evaluated in binary64, rounded outwards, padded as the whole
+ * triangle's is (tri_leaf_box): every point of the triangle lies in some cell, hence in some part's box.  A triangle with no cut
+ * keeps exactly the box and the Morton key it had without this step: where nothing is cut the builders' trees are what they were. */
+struct RefOut { uint32_t *tri; f4 *mn, *mx; unsigned long long *key; };      /* by reference: triangle, padded box, Morton key */
+constexpr int kSplitMaxParts = 64;
+
+/* level (0 = the plane through the middle of the scene box) and position of the coarsest Morton-grid plane strictly inside
+   (lo, hi) of an axis whose scene extent is [s0, s0 + 1 / sinv]; false: none down to the grid's 21 bits */
+NORI_HD bool split_plane_axis(float lo, float hi, float s0, float sinv, int &level, float &pos) {
+    if (!(hi > lo) || !(sinv > 0.0f)) return false;
+    const double a = ((double) lo - (double) s0) * (double) sinv, b = ((double) hi - (double) s0) * (double) sinv;
+    for (int l = 0; l < 21; ++l) {
+        const double cells = (double) (2u << l);                 /* planes at odd multiples of 2^-(l+1) */
+        const double k = floor(a * cells) + 1.0;                 /* first grid line above a at this resolution */
+        /* (lines at even multiples belong to coarser levels: they were tried before) */
+        if (k / cells < b) {
+            const double x = (double) s0 + (k / cells) / (double) sinv;
+            const float xf = (float) x;
+            if (xf > lo && xf < hi) { level = l; pos = xf; return true; }
+        }
+    }
+    return false;
+}
+NORI_HD bool split_plane(f3 mn, f3 mx, f3 smin, f3 sinv, int &axis, int &level, float &pos) {
+    const float lo[3] = {mn.x, mn.y, mn.z}, hi[3] = {mx.x, mx.y, mx.z}, s0[3] = {smin.x, smin.y, smin.z}, si[3] = {sinv.x, sinv.y, sinv.z};
+    bool found = false; float bestExtent = 0.0f;
+    level = 0;
+    for (int ax = 0; ax < 3; ++ax) {
+        int l = 0; float p = 0.0f;
+        if (!split_plane_axis(lo[ax], hi[ax], s0[ax], si[ax], l, p)) continue;
+        const float extent = (hi[ax] - lo[ax]) * si[ax];
+        if (!found || l < level || (l == level && extent > bestExtent)) { found = true; axis = ax; level = l; pos = p; bestExtent = extent; }
+    }
+    return found;
+}
+/* cube root by additions, multiplications and divisions only (a seed from the bit pattern, four Newton steps): the same bits from the
+   host compiler's and the device compiler's arithmetic, which the libraries' cbrtf do not promise -- the CPU harness and the device must
+   count the same cuts */
+NORI_HD float split_cbrt(float x) {
+    if (!(x > 0.0f) || !(x < kInf)) return 0.0f;
+    float y = u2f(f2u(x) / 3u + 0x2a514067u);
+    for (int k = 0; k < 4; ++k) y = (2.0f * y + x / (y * y)) * (1.0f / 3.0f);
+    return y;
+}
+NORI_HD float split_priority(const f4 *pos, const uint32_t *idx, uint32_t t, f3 smin, f3 sinv) {
+    if (tri_unbounded(pos, idx, t)) return 0.0f;
+    f3 mn, mx; tri_box(pos, idx, t, mn, mx);
+    int axis, level; float where;
+    if (!split_plane(mn, mx, smin, sinv, axis, level, where)) return 0.0f;
+    /* in units of the scene box, so that the scale of the counts does not depend on the scene's */
+    const f3 e = mk3((mx.x - mn.x) * sinv.x, (mx.y - mn.y) * sinv.y, (mx.z - mn.z) * sinv.z);
+    const float side = split_cbrt(e.x * e.y * e.z), spare = side * side;      /* (volume)^(2/3): an area again; a flat box has none */
+    if (!(spare > 0.0f)) return 0.0f;
+    return split_cbrt(spare / (float) (1u << level));
+}
+NORI_HD uint32_t split_count(float priority, float D, uint32_t cap) {
+    const float c = D * priority;
+    return !(c >= 1.0f) ? 0u : (c >= (float) cap ? cap : (uint32_t) c);
+}
+/* What else lies in a triangle's box: a cut only pays where OTHER geometry stands in the empty part of the box -- the tilted face of
+   a block in an empty room gains nothing from hugging boxes, only nodes.  The triangles' box centres are counted into a kSplitGrid^3
+   grid over the scene box (split_grid_cell), the counts summed into a summed-volume table (entry (x, y, z) = centres in cells
+   [0, x) x [0, y) x [0, z), dimension kSplitGrid + 1), and split_inside reads the number of centres in the cells a box touches with
+   eight look-ups.  Integer counts: the same on any device, in any order. */
+constexpr int kSplitGrid = 64;
+NORI_HD int split_grid_coord(float v, float s0, float sinv) {
+    const float c = (v - s0) * sinv * (float) kSplitGrid;
+    return c >= (float) (kSplitGrid - 1) ? kSplitGrid - 1 : (c > 0.0f ? (int) c : 0);
+}
+NORI_HD uint32_t split_grid_cell(f3 mn, f3 mx, f3 smin, f3 sinv) {
+    const int x = split_grid_coord(0.5f * (mn.x + mx.x), smin.x, sinv.x), y = split_grid_coord(0.5f * (mn.y + mx.y), smin.y, sinv.y), z = split_grid_coord(0.5f * (mn.z + mx.z), smin.z, sinv.z);
+    return (uint32_t) ((z * kSplitGrid + y) * kSplitGrid + x);
+}
+NORI_HD uint32_t split_sat_at(const uint32_t *sat, int x, int y, int z) { return sat[(z * (kSplitGrid + 1) + y) * (kSplitGrid + 1) + x]; }
+NORI_HD uint32_t split_inside(const uint32_t *sat, f3 mn, f3 mx, f3 smin, f3 sinv) {
+    const int x0 = split_grid_coord(mn.x, smin.x, sinv.x), y0 = split_grid_coord(mn.y, smin.y, sinv.y), z0 = split_grid_coord(mn.z, smin.z, sinv.z);
+    const int x1 = split_grid_coord(mx.x, smin.x, sinv.x) + 1, y1 = split_grid_coord(mx.y, smin.y, sinv.y) + 1, z1 = split_grid_coord(mx.z, smin.z, sinv.z) + 1;
+    const uint32_t cells = split_sat_at(sat, x1, y1, z1) - split_sat_at(sat, x0, y1, z1) - split_sat_at(sat, x1, y0, z1) - split_sat_at(sat, x1, y1, z0)
+                         + split_sat_at(sat, x0, y0, z1) + split_sat_at(sat, x0, y1, z0) + split_sat_at(sat, x1, y0, z0) - split_sat_at(sat, x0, y0, z0);
+    /* the box's share of the cells it touches (a thin slab touches a whole layer of cells and holds next to nothing of it) */
+    const float fx = fminf(1.0f, (mx.x - mn.x) * sinv.x * (float) kSplitGrid / (float) (x1 - x0)), fy = fminf(1.0f, (mx.y - mn.y) * sinv.y * (float) kSplitGrid / (float) (y1 - y0)),
+                fz = fminf(1.0f, (mx.z - mn.z) * sinv.z * (float) kSplitGrid / (float) (z1 - z0));
+    return (uint32_t) ((float) cells * (fx * (fy * fz)));
+}
+/* box of the triangle's part inside the cell [cmn, cmx] (binary64 clipping, rounded outwards); false: nothing there */
+NORI_HD bool split_part_box(const double tri[3][3], f3 cmn, f3 cmx, f3 &mn, f3 &mx) {
+    double a[10][3], b[10][3];
+    int n = 3;
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) a[i][k] = tri[i][k];
+    const double lo[3] = {cmn.x, cmn.y, cmn.z}, hi[3] = {cmx.x, cmx.y, cmx.z};
+    for (int plane = 0; plane < 6 && n > 0; ++plane) {
+        const int axis = plane >> 1; const bool above = (plane & 1) == 0; const double where = above ? lo[axis] : hi[axis];
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const double *p = a[i], *q = a[(i + 1) % n];
+            const double dp = above ? p[axis] - where : where - p[axis], dq = above ? q[axis] - where : where - q[axis];
+            if (dp >= 0.0) { for (int k = 0; k < 3; ++k) b[m][k] = p[k]; ++m; }
+            if ((dp > 0.0 && dq < 0.0) || (dp < 0.0 && dq > 0.0)) {
+                const double t = dp / (dp - dq);
+                for (int k = 0; k < 3; ++k) b[m][k] = p[k] + t * (q[k] - p[k]);
+                b[m][axis] = where; ++m;
+            }
+        }
+        n = m < 10 ? m : 10;
+        for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) a[i][k] = b[i][k];
+    }
+    if (n <= 0) return false;
+    double dmn[3] = {a[0][0], a[0][1], a[0][2]}, dmx[3] = {a[0][0], a[0][1], a[0][2]};
+    for (int i = 1; i < n; ++i) for (int k = 0; k < 3; ++k) { dmn[k] = a[i][k] < dmn[k] ? a[i][k] : dmn[k]; dmx[k] = a[i][k] > dmx[k] ? a[i][k] : dmx[k]; }
+    float fmn[3], fmx[3];
+    for (int k = 0; k < 3; ++k) {
+        float f = (float) dmn[k]; if ((double) f > dmn[k]) f = u2f(f > 0.0f ? f2u(f) - 1u : (f < 0.0f ? f2u(f) + 1u : 0x80000001u)); fmn[k] = f;
+        float g = (float) dmx[k]; if ((double) g < dmx[k]) g = u2f(g > 0.0f ? f2u(g) + 1u : (g < 0.0f ? f2u(g) - 1u : 0x00000001u)); fmx[k] = g;
+    }
+    mn = mk3(fmn[0], fmn[1], fmn[2]); mx = mk3(fmx[0], fmx[1], fmx[2]);
+    return true;
+}
+/* the references of triangle t, at most 1 + cuts (a part no grid plane crosses keeps its cuts unused): counted (write = false: the
+   builder's scan places every triangle's run) or written at out[first ...]; returns how many */
+NORI_HD uint32_t split_emit(const f4 *pos, const uint32_t *idx, uint32_t t, uint32_t cuts, float pad0, f3 smin, f3 sinv, bool write, const RefOut &out, uint32_t first) {
+    f3 tmn, tmx; tri_box(pos, idx, t, tmn, tmx);
+    const f3 p0 = xyz(pos[idx[3 * (size_t) t]]), p1 = xyz(pos[idx[3 * (size_t) t + 1]]), p2 = xyz(pos[idx[3 * (size_t) t + 2]]);
+    bool unbounded;
+    const float pad = tri_box_pad(p1 - p0, p2 - p0, pad0, unbounded);
+    if (cuts == 0u || unbounded) {      /* the whole triangle, exactly as tri_leaf_box / the Morton key of its box see it */
+        if (write) {
+            f4 a, b; tri_leaf_box(pos, idx, t, pad0, a, b);
+            out.tri[first] = t; out.mn[first] = a; out.mx[first] = b;
+            out.key[first] = unbounded ? 0x8000000000000000ull : morton63(tmn, tmx, smin, sinv);
+        }
+        return 1u;
+    }
+    const double tri[3][3] = {{p0.x, p0.y, p0.z}, {p1.x, p1.y, p1.z}, {p2.x, p2.y, p2.z}};
+    struct Part { f3 mn, mx; uint32_t cuts; };      /* box of (triangle within the part's cell) = the cell of what it is cut into */
+    Part stack[kSplitMaxParts];
+    int sp = 0;
+    uint32_t written = 0;
+    stack[sp].mn = tmn; stack[sp].mx = tmx; stack[sp].cuts = cuts < (uint32_t) kSplitMaxParts - 1u ? cuts : (uint32_t) kSplitMaxParts - 1u; ++sp;
+    while (sp > 0) {
+        const Part pt = stack[--sp];
+        int axis = 0, level = 0; float where = 0.0f;
+        bool cut = pt.cuts > 0u && sp + 2 <= kSplitMaxParts && split_plane(pt.mn, pt.mx, smin, sinv, axis, level, where);
+        Part lo = pt, hi = pt;
+        if (cut) {
+            f3 lo_cmx = pt.mx, hi_cmn = pt.mn;
+            if (axis == 0) { lo_cmx.x = where; hi_cmn.x = where; } else if (axis == 1) { lo_cmx.y = where; hi_cmn.y = where; } else { lo_cmx.z = where; hi_cmn.z = where; }
+            cut = split_part_box(tri, pt.mn, lo_cmx, lo.mn, lo.mx) && split_part_box(tri, hi_cmn, pt.mx, hi.mn, hi.mx);
+        }
+        if (!cut) {
+            if (write) {
+                f4 a, b;
+                a.x = pt.mn.x - pad; a.y = pt.mn.y - pad; a.z = pt.mn.z - pad; a.w = 0.0f;
+                b.x = pt.mx.x + pad; b.y = pt.mx.y + pad; b.z = pt.mx.z + pad; b.w = 0.0f;
+                out.tri[first + written] = t; out.mn[first + written] = a; out.mx[first + written] = b;
+                out.key[first + written] = morton63(pt.mn, pt.mx, smin, sinv);
+            }
+            ++written;
+            continue;
+        }
+        const float wl = half_area(lo.mn, lo.mx), wh = half_area(hi.mn, hi.mx);
+        const uint32_t rest = pt.cuts - 1u;
+        uint32_t cl = (wl + wh) > 0.0f ? (uint32_t) ((float) rest * (wl / (wl + wh)) + 0.5f) : rest / 2u;
+        if (cl > rest) cl = rest;
+        lo.cuts = cl; hi.cuts = rest - cl;
+        stack[sp++] = hi; stack[sp++] = lo;
+    }
+    return written;
+}
+
 /* ---- treelet restructuring (Karras & Aila 2013) of the PLOC tree ----
  * PLOC chooses every merge locally; what it leaves on the table sits inside small subtrees (a
  * top-down SAH rebuild ABOVE the subtrees recovers only a third of the gap to the host's SAH tree).  A treelet is a node
@@ -229,7 +414,7 @@ NORI_HD void tri_leaf_box(const f4 *pos, const uint32_t *idx, uint32_t g, float 
  * Per node: box (xyz of two f4), SAH cost of its subtree  C(node) = c_node A(node) + C(left) + C(right),  C(triangle) =
  * c_tri A(triangle).  Treelets that contain an unbounded box (numerically collinear triangles) are left alone. */
 constexpr int kTreeletLeaves = 7;
-struct TreeletData { f4 *nmn, *nmx; float *cost; };
+struct TreeletData { f4 *nmn, *nmx; float *cost; const f4 *lmn, *lmx; };      /* inner nodes by id: box, subtree cost; leaves by position: the references' padded boxes */
 struct TreeletParams { float c_node, c_tri; };
 
 /* How the treelet code reads and writes what OTHER waves of the same launch wrote or will read (links, counts, boxes, costs): on the
@@ -260,11 +445,9 @@ NORI_HD f4 coh_ld4(const f4 *p) { return *p; }
 NORI_HD void coh_st4(f4 *p, const f4 &v) { *p = v; }
 #endif
 
-NORI_HD void treelet_child(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
-                           TreeletParams tp, uint32_t child, f3 &mn, f3 &mx, float &cost, uint32_t &count) {
+NORI_HD void treelet_child(const PlocNodes &nodes, const TreeletData &td, TreeletParams tp, uint32_t child, f3 &mn, f3 &mx, float &cost, uint32_t &count) {
     if (child & kLeafBit) {
-        f4 a, b; tri_leaf_box(pos, idx, order[child & ~kLeafBit], pad, a, b);
-        mn = xyz(a); mx = xyz(b); count = 1u;
+        mn = xyz(td.lmn[child & ~kLeafBit]); mx = xyz(td.lmx[child & ~kLeafBit]); count = 1u;
         cost = tp.c_tri * half_area(mn, mx);
     } else {
         mn = xyz(coh_ld4(&td.nmn[child])); mx = xyz(coh_ld4(&td.nmx[child])); count = coh_ld(&nodes.count[child]); cost = coh_ld(&td.cost[child]);
@@ -286,12 +469,11 @@ struct TreeletWork {
 /* box and cost of node `id` from its children (first sweep: nothing is known yet), then its treelet: the node's two children, and
    while fewer than seven, the inner one of largest area replaced by its children.  False: nothing to optimise (an unbounded box
    in reach, or two leaves only). */
-NORI_HD bool treelet_form(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
-                          TreeletParams tp, uint32_t id, TreeletWork &w) {
+NORI_HD bool treelet_form(const PlocNodes &nodes, const TreeletData &td, TreeletParams tp, uint32_t id, TreeletWork &w) {
     int k = 2, n_inner = 1;
     w.inner[0] = id;
     w.leaf[0] = coh_ld(&nodes.left[id]); w.leaf[1] = coh_ld(&nodes.right[id]);
-    for (int i = 0; i < 2; ++i) treelet_child(nodes, td, pos, idx, order, pad, tp, w.leaf[i], w.lmn[i], w.lmx[i], w.lcost[i], w.cnt[i]);
+    for (int i = 0; i < 2; ++i) treelet_child(nodes, td, tp, w.leaf[i], w.lmn[i], w.lmx[i], w.lcost[i], w.cnt[i]);
     const bool bounded = w.lmx[0].x < kBoxInf && w.lmx[1].x < kBoxInf;
     {   /* this node as it stands */
         const f3 mn = mk3(fminf(w.lmn[0].x, w.lmn[1].x), fminf(w.lmn[0].y, w.lmn[1].y), fminf(w.lmn[0].z, w.lmn[1].z));
@@ -314,8 +496,8 @@ NORI_HD bool treelet_form(const PlocNodes &nodes, const TreeletData &td, const f
         w.inner[n_inner++] = open;
         const uint32_t a = coh_ld(&nodes.left[open]), b = coh_ld(&nodes.right[open]);
         w.leaf[best] = a; w.leaf[k] = b;
-        treelet_child(nodes, td, pos, idx, order, pad, tp, a, w.lmn[best], w.lmx[best], w.lcost[best], w.cnt[best]);
-        treelet_child(nodes, td, pos, idx, order, pad, tp, b, w.lmn[k], w.lmx[k], w.lcost[k], w.cnt[k]);
+        treelet_child(nodes, td, tp, a, w.lmn[best], w.lmx[best], w.lcost[best], w.cnt[best]);
+        treelet_child(nodes, td, tp, b, w.lmn[k], w.lmx[k], w.lcost[k], w.cnt[k]);
         if (!(w.lmx[best].x < kBoxInf) || !(w.lmx[k].x < kBoxInf)) return false;
         ++k;
     }
@@ -368,10 +550,9 @@ NORI_HD void treelet_rewire(const PlocNodes &nodes, const TreeletData &td, uint3
 }
 
 /* one thread does it all: the CPU harness, and the device when NORI_HIP_TREELET_SERIAL is set */
-NORI_HD void treelet_optimize(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
-                              TreeletParams tp, uint32_t id) {
+NORI_HD void treelet_optimize(const PlocNodes &nodes, const TreeletData &td, TreeletParams tp, uint32_t id) {
     TreeletWork w;
-    if (!treelet_form(nodes, td, pos, idx, order, pad, tp, id, w)) return;
+    if (!treelet_form(nodes, td, tp, id, w)) return;
     /* dynamic programming over the subsets of the k leaves */
     const int k = w.k, full = (1 << k) - 1;
     float area[1 << kTreeletLeaves], copt[1 << kTreeletLeaves];
@@ -397,8 +578,7 @@ NORI_HD void treelet_optimize(const PlocNodes &nodes, const TreeletData &td, con
 /* One sweep = treelet_climb for every triangle position k (visits[] zeroed before).  On the device the arrival counter is an
    atomic with a fence on either side: what the other subtree's thread wrote must be visible, and this CU's L1 may still
    hold lines from before it was written (MI355X: the vector L1 is not refreshed by other CUs' stores). */
-NORI_HD void treelet_climb(const PlocNodes &nodes, const TreeletData &td, const f4 *pos, const uint32_t *idx, const uint32_t *order, float pad,
-                           TreeletParams tp, uint32_t *visits, uint32_t root_id, uint32_t k) {
+NORI_HD void treelet_climb(const PlocNodes &nodes, const TreeletData &td, TreeletParams tp, uint32_t *visits, uint32_t root_id, uint32_t k) {
     uint32_t p = nodes.parent_prim[k];
     for (uint32_t guard = 0; guard < 4096u; ++guard) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -409,7 +589,7 @@ NORI_HD void treelet_climb(const PlocNodes &nodes, const TreeletData &td, const 
         const uint32_t before = visits[p]++;
 #endif
         if (before == 0u) return;
-        treelet_optimize(nodes, td, pos, idx, order, pad, tp, p);
+        treelet_optimize(nodes, td, tp, p);
         if (p == root_id) return;
         p = coh_ld(&nodes.parent_node[p]);
     }
@@ -436,7 +616,6 @@ NORI_HD void treelet_climb(const PlocNodes &nodes, const TreeletData &td, const 
  * The root keeps its id (the last node): neither it nor its children move, nothing is hung above it.  Subtrees with an
  * unbounded box (numerically collinear triangles) stay where they are. */
 struct ReinsData {
-    f4 *lmn, *lmx;                 /* the triangles' padded boxes, by position in the builder's order */
     unsigned long long *lock;      /* [2 n - 1] by slot: inner node id, or n - 1 + position of a triangle */
     unsigned long long *key;       /* [2 n - 1] the candidate's (gain bits << 32 | slot), 0 = no move */
     uint32_t *target, *pivot;      /* [2 n - 1] y and p_k (kNoParent: y is an ancestor of x, the move goes beside the shrunken y) */
@@ -446,7 +625,7 @@ NORI_HD uint32_t reins_slot(uint32_t id, uint32_t n_inner) { return (id & kLeafB
 NORI_HD uint32_t reins_id(uint32_t slot, uint32_t n_inner) { return slot < n_inner ? slot : (kLeafBit | (slot - n_inner)); }
 NORI_HD uint32_t reins_parent(const PlocNodes &nd, uint32_t id) { return (id & kLeafBit) ? nd.parent_prim[id & ~kLeafBit] : nd.parent_node[id]; }
 NORI_HD void reins_box(const TreeletData &td, const ReinsData &rd, uint32_t id, f3 &mn, f3 &mx) {
-    if (id & kLeafBit) { mn = xyz(rd.lmn[id & ~kLeafBit]); mx = xyz(rd.lmx[id & ~kLeafBit]); }
+    if (id & kLeafBit) { mn = xyz(td.lmn[id & ~kLeafBit]); mx = xyz(td.lmx[id & ~kLeafBit]); }
     else { mn = xyz(td.nmn[id]); mx = xyz(td.nmx[id]); }
 }
 NORI_HD float reins_union_area(f3 amn, f3 amx, f3 bmn, f3 bmx) {
@@ -567,7 +746,7 @@ NORI_HD void reins_refit_node(const PlocNodes &nd, const TreeletData &td, const 
     const uint32_t c[2] = {coh_ld(&nd.left[id]), coh_ld(&nd.right[id])};
     f3 mn[2], mx[2]; float cost[2]; uint32_t cnt[2];
     for (int i = 0; i < 2; ++i) {
-        if (c[i] & kLeafBit) { mn[i] = xyz(rd.lmn[c[i] & ~kLeafBit]); mx[i] = xyz(rd.lmx[c[i] & ~kLeafBit]); cnt[i] = 1u; cost[i] = tp.c_tri * half_area(mn[i], mx[i]); }
+        if (c[i] & kLeafBit) { mn[i] = xyz(td.lmn[c[i] & ~kLeafBit]); mx[i] = xyz(td.lmx[c[i] & ~kLeafBit]); cnt[i] = 1u; cost[i] = tp.c_tri * half_area(mn[i], mx[i]); }
         else { mn[i] = xyz(coh_ld4(&td.nmn[c[i]])); mx[i] = xyz(coh_ld4(&td.nmx[c[i]])); cnt[i] = coh_ld(&nd.count[c[i]]); cost[i] = coh_ld(&td.cost[c[i]]); }
     }
     const f3 bmn = mk3(fminf(mn[0].x, mn[1].x), fminf(mn[0].y, mn[1].y), fminf(mn[0].z, mn[1].z));

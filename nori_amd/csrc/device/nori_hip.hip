@@ -407,6 +407,7 @@ struct nori_hip_ctx {
     nori_accel_info info;
     int stack_depth = 32;
     uint64_t lbvh_bytes = 0;
+    uint32_t lbvh_refs = 0;      /* references the device builder built the tree over (0: the host built it) */
     int engine = -1;                /* -1 auto, 0 megakernel, 1 wavefront */
     int accel_layout = -1;          /* -1 auto (wide from 2^20 triangles), 0 bvh2, 1 bvh4q (wide nodes) */
     bool film_reference = false;    /* film_order = reference: samples added in the reference's own order (film.h) */
@@ -576,10 +577,12 @@ int nori_hip_upload_scene(nori_hip_ctx *ctx, const nori_scene_desc *scene) {
 int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     if (!ctx) return NORI_ERR_INVALID_ARGUMENT;
     if (!ctx->have_scene) { ctx->error = "build_accel: no scene uploaded"; return NORI_ERR_NOT_READY; }
-    /* auto: from 2^20 triangles (where the tree is emitted as wide nodes) the device's builder -- with re-insertion its tree traces within
-       1.5 % of the host's on the 10 M-triangle terrain and is built in 142 ms instead of 2.4 s (profiles/r6_16_c5_build_matrix.txt); below, the
-       host's: 30 - 90 ms, and spatial splits, which the device does not have, are worth 34 % of wf_extend on the pa5 table scene */
-    if (builder == NORI_ACCEL_AUTO) builder = ctx->dev.n_triangles >= (1u << 20) ? NORI_ACCEL_GPU_PLOC : NORI_ACCEL_HOST_SAH;
+    /* auto: the device's builder.  With triangle splitting and parallel re-insertion (round 6, lbvh.hip) its trees trace within 1 % of the
+       host's on the Cornell box, the pa5 table and the AO scene and within 3 % on the 10 M-triangle terrain, and are built in 19 / 28 / 33 /
+       144 ms against 30 / 56 / 90 / 2 400 (profiles/r6_19_split_scale.txt); the host's builder if the device's gives up (a tree deeper than the
+       traversal stack) */
+    const bool was_auto = builder == NORI_ACCEL_AUTO;
+    if (was_auto) builder = ctx->dev.n_triangles > 0 ? NORI_ACCEL_GPU_PLOC : NORI_ACCEL_HOST_SAH;
     if (builder != NORI_ACCEL_HOST_SAH && builder != NORI_ACCEL_GPU_LBVH && builder != NORI_ACCEL_GPU_PLOC) { ctx->error = "build_accel: unknown builder"; return NORI_ERR_INVALID_ARGUMENT; }
     DeviceGuard g(ctx->device);
     free_pool(ctx->allocs_accel);
@@ -612,6 +615,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
         if (res.d_nodes) ctx->allocs_accel.push_back(res.d_nodes);
         if (res.d_tris) ctx->allocs_accel.push_back(res.d_tris);
         if (err.empty() && res.max_depth + 1 > 64) err = "LBVH deeper than the traversal stack (64); use NORI_ACCEL_HOST_SAH";
+        if (!err.empty() && was_auto) { free_pool(ctx->allocs_accel); return nori_hip_build_accel(ctx, NORI_ACCEL_HOST_SAH); }
         if (!err.empty()) { ctx->error = err; free_pool(ctx->allocs_accel); return NORI_ERR_INTERNAL; }
         ctx->bvh = HostBvh();
         ctx->bvh.wide = res.wide;
@@ -619,6 +623,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
         ctx->bvh.max_depth = res.max_depth; ctx->bvh.build_ms = res.build_ms; ctx->bvh.sah_cost = 0.0f;
         ctx->dev.nodes = res.d_nodes; ctx->dev.tris = res.d_tris;
         ctx->lbvh_bytes = (uint64_t) std::max<uint32_t>(res.n_nodes, 1) * kNodeQuads * 16 + (uint64_t) res.n_pairs * kPairQuads * 16;
+        ctx->lbvh_refs = res.n_refs;
     } else {
         const bool wide = want_wide;
         std::string err = build_bvh_sah(ctx->host, 64, ctx->bvh, wide);
@@ -627,7 +632,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
         int rc;
         if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.nodes, &ctx->dev.nodes))) return rc;
         if ((rc = upload(ctx, ctx->allocs_accel, ctx->bvh.tris, &ctx->dev.tris))) return rc;
-        ctx->lbvh_bytes = 0;
+        ctx->lbvh_bytes = 0; ctx->lbvh_refs = 0;
     }
     if (const char *e = getenv("NORI_HIP_LAB_DEPTH_ADD")) ctx->bvh.max_depth += (uint32_t) std::max(0, atoi(e));      /* experiments: a tree priced as if it were deeper (the spilling stack, the smaller LDS image) */
     ctx->dev.root = ctx->bvh.root;
@@ -676,6 +681,7 @@ int nori_hip_build_accel(nori_hip_ctx *ctx, int builder) {
     in.total_bytes = ctx->lbvh_bytes ? ctx->lbvh_bytes : (uint64_t) ctx->bvh.nodes.size() * 16 + (uint64_t) ctx->bvh.tris.size() * 16;
     in.build_ms = ctx->bvh.build_ms; in.sah_cost = ctx->bvh.sah_cost;
     in.node_children = ctx->bvh.wide ? 4u : 2u; in.node_records_32b = ctx->dev.nodes_q != nullptr ? 1u : 0u;
+    in.built_on_device = ctx->lbvh_bytes ? 1u : 0u; in.n_references = ctx->lbvh_refs;
     ctx->have_accel = true;
     return NORI_OK;
 }

@@ -45,6 +45,7 @@ struct emu_ctx {
     std::vector<f4> top_image;      /* rt_top.h: the records wf_extend keeps in LDS; the harness walks through them too */
     std::vector<f4> nodes_q, top_image_q;      /* rt_nodeq.h: the 32-B node records and the image that holds them */
     std::string error;
+    uint32_t n_refs = 0;      /* references the device builders' steps built the tree over (emu_builder.h) */
 };
 
 static void bind(emu_ctx *c) {
@@ -298,6 +299,7 @@ int emu_create(const nori_scene_desc *scene, emu_ctx **out) {
             if (err.empty() && c->bvh.max_depth + 1 > 64 && wide) err = build_bvh_steps_host(c->host, false, 0u, c->bvh, &st);
         }
         if (err.empty() && c->bvh.max_depth + 1 > 64) err = "tree deeper than the traversal stack";
+        c->n_refs = st.n_refs;
     } else {
         if (err.empty()) err = build_bvh_sah(c->host, 64, c->bvh, wide);
         if (!err.empty() && wide) err = build_bvh_sah(c->host, 64, c->bvh, false);
@@ -317,6 +319,7 @@ int emu_accel_info(const emu_ctx *c, nori_accel_info *in) {
     in->build_ms = c->bvh.build_ms; in->sah_cost = c->bvh.sah_cost;
     in->node_children = c->bvh.wide ? 4u : 2u;
     in->node_records_32b = c->dev.nodes_q != nullptr ? 1u : 0u;
+    in->built_on_device = 0u; in->n_references = c->n_refs;
     return NORI_OK;
 }
 int emu_border_size(const emu_ctx *c) { return c->host.filter.border; }

@@ -21,11 +21,11 @@
 
 namespace nrt {
 
-struct EmuBuilderStats { uint32_t ploc_iterations = 0, reinserted = 0; float sah_cost = 0.0f; };
+struct EmuBuilderStats { uint32_t ploc_iterations = 0, reinserted = 0, n_refs = 0; float sah_cost = 0.0f; };
 
 inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint32_t ploc_radius, HostBvh &out, EmuBuilderStats *stats = nullptr) {
     out = HostBvh();
-    const uint32_t n = (uint32_t) scene.tri_mesh.size();
+    uint32_t n = (uint32_t) scene.tri_mesh.size();
     if (n == 0) return "empty scene";
     if (n <= 4) wide = false;
     const uint32_t pair_base = wide ? 1u : 0u;
@@ -43,17 +43,53 @@ inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint3
     const float pad = box_pad_rel() * sqrtf(ex * ex + ey * ey + ez * ez) + 1e-30f;
     const f3 sinv = mk3(ex > 0 ? 1.0f / ex : 0.0f, ey > 0 ? 1.0f / ey : 0.0f, ez > 0 ? 1.0f / ez : 0.0f);
 
-    /* 2, 3. Morton keys, sorted (stable in the triangle index, like the radix sort) */
-    std::vector<unsigned long long> key(n), keys(n);
-    std::vector<uint32_t> order(n);
-    for (uint32_t t = 0; t < n; ++t) {
-        if (tri_unbounded(pos, idx, t)) { key[t] = 0x8000000000000000ull; continue; }
-        f3 mn, mx; tri_box(pos, idx, t, mn, mx);
-        key[t] = morton63(mn, mx, smin, sinv);
+    /* 2. references (lbvh_steps.h): every triangle once, or -- with a budget -- the triangles with the emptiest boxes as several parts */
+    const uint32_t n_tris = n;
+    const SplitTuning stn = split_tuning(n_tris);
+    std::vector<uint32_t> cuts(n_tris, 0u), ref_first(n_tris, 0u);
+    if (stn.budget > 0.0f && ploc_radius != 0u) {      /* (as build_bvh_lbvh_device: not in front of the radix tree) */
+        std::vector<float> prio(n_tris);
+        for (uint32_t t = 0; t < n_tris; ++t) prio[t] = split_priority(pos, idx, t, smin, sinv);
+        /* what else lies in every triangle's box (lbvh_steps.h): centres per grid cell, summed-volume table, a cap on the triangle's cuts */
+        std::vector<uint32_t> limit(n_tris, stn.cap);
+        if (stn.inside > 0u) {
+            const int G = kSplitGrid, G1 = kSplitGrid + 1;
+            std::vector<uint32_t> cells((size_t) G * G * G, 0u), sat((size_t) G1 * G1 * G1, 0u);
+            for (uint32_t t = 0; t < n_tris; ++t) { f3 mn, mx; tri_box(pos, idx, t, mn, mx); if (!tri_unbounded(pos, idx, t)) cells[split_grid_cell(mn, mx, smin, sinv)]++; }
+            split_sat(cells.data(), sat.data());
+            for (uint32_t t = 0; t < n_tris; ++t) {
+                if (!(prio[t] > 0.0f)) continue;
+                f3 mn, mx; tri_box(pos, idx, t, mn, mx);
+                limit[t] = std::min(stn.cap, split_inside(sat.data(), mn, mx, smin, sinv) / stn.inside);
+            }
+        }
+        const unsigned long long want = (unsigned long long) ((double) stn.budget * (double) n_tris);
+        auto total = [&](float D) { unsigned long long sum = 0; for (uint32_t t = 0; t < n_tris; ++t) sum += split_count(prio[t], D, limit[t]); return sum; };
+        unsigned long long sum_bits = 0, have = 0;
+        for (uint32_t t = 0; t < n_tris; ++t) if (prio[t] > 0.0f) { sum_bits += f2u(prio[t]); ++have; }
+        const float D = have ? split_choose_D(total, want, split_scale_D(sum_bits, have, stn.scale)) : 0.0f;
+        for (uint32_t t = 0; t < n_tris; ++t) cuts[t] = split_count(prio[t], D, limit[t]);
     }
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
-    for (uint32_t k = 0; k < n; ++k) keys[k] = key[order[k]];
+    uint32_t m = 0;
+    const RefOut none{nullptr, nullptr, nullptr, nullptr};
+    for (uint32_t t = 0; t < n_tris; ++t) { ref_first[t] = m; m += split_emit(pos, idx, t, cuts[t], pad, smin, sinv, false, none, 0u); }
+    std::vector<uint32_t> ref_tri(m); std::vector<f4> ref_mn(m), ref_mx(m); std::vector<unsigned long long> key(m);
+    const RefOut refs{ref_tri.data(), ref_mn.data(), ref_mx.data(), key.data()};
+    for (uint32_t t = 0; t < n_tris; ++t) (void) split_emit(pos, idx, t, cuts[t], pad, smin, sinv, true, refs, ref_first[t]);
+    if (stats) stats->n_refs = m;
+    n = m;      /* from here on: references */
+
+    /* 3. sorted by Morton key (stable in the reference index, like the radix sort); order[k] = triangle of the reference at position k,
+       lmn / lmx[k] = its padded box */
+    std::vector<unsigned long long> keys(n);
+    std::vector<uint32_t> order(n);
+    std::vector<f4> lmn(n), lmx(n);
+    {
+        std::vector<uint32_t> by_key(n);
+        std::iota(by_key.begin(), by_key.end(), 0u);
+        std::stable_sort(by_key.begin(), by_key.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+        for (uint32_t k = 0; k < n; ++k) { keys[k] = key[by_key[k]]; order[k] = ref_tri[by_key[k]]; lmn[k] = ref_mn[by_key[k]]; lmx[k] = ref_mx[by_key[k]]; }
+    }
 
     std::vector<uint32_t> leaf_cnt(n, 0u), leaf_pairs(n, 0u), pair_start(n, 0u);
     std::vector<RadixNode> rnodes;
@@ -72,7 +108,7 @@ inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint3
             PlocClusters ca{amn.data(), amx.data()}, cb{bmn.data(), bmx.data()};
             PlocNodes pn{nl.data(), nr.data(), nc.data(), npn.data(), npp.data()};
             for (uint32_t k = 0; k < n; ++k) {
-                f4 mn, mx; tri_leaf_box(pos, idx, order[k], pad, mn, mx);
+                f4 mn = lmn[k], mx = lmx[k];
                 mn.w = u2f(kLeafBit | k); mx.w = u2f(1u);
                 ca.mn[k] = mn; ca.mx[k] = mx;
             }
@@ -97,23 +133,21 @@ inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint3
                 const BuildTuning rp = build_tuning(n);
                 const int sweeps = rp.sweeps;
                 std::vector<f4> nmn(n), nmx(n); std::vector<float> ncost(n);
-                TreeletData td{nmn.data(), nmx.data(), ncost.data()};
+                TreeletData td{nmn.data(), nmx.data(), ncost.data(), lmn.data(), lmx.data()};
                 TreeletParams tp; tp.c_node = 1.0f; tp.c_tri = 1.0f;
                 std::vector<uint32_t> visits(n);
                 auto sweep = [&] {
                     std::fill(visits.begin(), visits.end(), 0u);
-                    for (uint32_t k = 0; k < n; ++k) treelet_climb(pn, td, pos, idx, order.data(), pad, tp, visits.data(), n - 2u, k);
+                    for (uint32_t k = 0; k < n; ++k) treelet_climb(pn, td, tp, visits.data(), n - 2u, k);
                 };
                 for (int sw = 0; sw < sweeps; ++sw) sweep();
                 /* parallel re-insertion (lbvh_steps.h), as build_bvh_lbvh_device runs it: every iteration the candidates of one
                    residue class search the same tree, mark, check, the winners move, the tree is refitted */
                 if (rp.iterations > 0) {
                     const uint32_t n_inner = n - 1u, n_slots = 2u * n - 1u;
-                    std::vector<f4> lmn(n), lmx(n);
-                    std::vector<unsigned long long> lock(n_slots), key(n_slots);
+                    std::vector<unsigned long long> lock(n_slots), rkey(n_slots);
                     std::vector<uint32_t> target(n_slots), pivot(n_slots), win(n_slots);
-                    ReinsData rd{lmn.data(), lmx.data(), lock.data(), key.data(), target.data(), pivot.data(), win.data()};
-                    for (uint32_t k = 0; k < n; ++k) tri_leaf_box(pos, idx, order[k], pad, lmn[k], lmx[k]);
+                    ReinsData rd{lock.data(), rkey.data(), target.data(), pivot.data(), win.data()};
                     auto refit = [&] {
                         std::fill(visits.begin(), visits.end(), 0u);
                         for (uint32_t k = 0; k < n; ++k) reins_refit_climb(pn, td, rd, tp, visits.data(), n - 2u, k);
@@ -123,7 +157,7 @@ inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint3
                     for (int it = 0; it < rp.iterations; ++it) {
                         const uint32_t phase = (uint32_t) it % rp.stride;
                         std::fill(lock.begin(), lock.end(), 0ull);
-                        std::fill(key.begin(), key.end(), 0ull);
+                        std::fill(rkey.begin(), rkey.end(), 0ull);
                         for (uint32_t sl = phase; sl < n_slots; sl += rp.stride) reins_search(pn, td, rd, n_inner, sl);
                         for (uint32_t sl = phase; sl < n_slots; sl += rp.stride) (void) reins_locks(pn, rd, n_inner, sl, true);
                         for (uint32_t sl = phase; sl < n_slots; sl += rp.stride) win[sl] = reins_locks(pn, rd, n_inner, sl, false) ? 1u : 0u;
@@ -137,16 +171,17 @@ inline std::string build_bvh_steps_host(const HostScene &scene, bool wide, uint3
                     for (int sw = 0; sw < rp.sweeps_after; ++sw) sweep();
                 }
             }
-            for (uint32_t k = 0; k < n; ++k) { leaf_pos[k] = ploc_first_position(pn, n - 1u, kLeafBit | k); order2[leaf_pos[k]] = order[k]; }
+            std::vector<f4> lmn2(n), lmx2(n);
+            for (uint32_t k = 0; k < n; ++k) { leaf_pos[k] = ploc_first_position(pn, n - 1u, kLeafBit | k); order2[leaf_pos[k]] = order[k]; lmn2[leaf_pos[k]] = lmn[k]; lmx2[leaf_pos[k]] = lmx[k]; }
             for (uint32_t id = 0; id + 1 < n; ++id) rnodes[n - 2u - id] = ploc_finish(pn, n - 1u, id, leaf_pos.data(), pin.data(), plf.data());
-            order.swap(order2);
+            order.swap(order2); lmn.swap(lmn2); lmx.swap(lmx2);
         }
         /* 5. segment tree of boxes */
         while (N < n) N <<= 1;
         tmin.resize((size_t) 2 * N); tmax.resize((size_t) 2 * N);
         for (uint32_t k = 0; k < N; ++k) {
             f4 mn4, mx4;
-            if (k < n) tri_leaf_box(pos, idx, order[k], pad, mn4, mx4);
+            if (k < n) { mn4 = lmn[k]; mx4 = lmx[k]; mn4.w = mx4.w = 0.0f; }
             else { mn4.x = mn4.y = mn4.z = kInf; mx4.x = mx4.y = mx4.z = -kInf; mn4.w = mx4.w = 0.0f; }
             tmin[N + k] = mn4; tmax[N + k] = mx4;
         }

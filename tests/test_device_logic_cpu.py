@@ -177,7 +177,8 @@ def test_tree_invariants_after_spatial_splits_and_reinsertion(monkeypatch):
         assert counts["default"]["sah_cost"] <= counts["plain"]["sah_cost"]
 
 
-@pytest.mark.parametrize("builder,env", [("lbvh", {}), ("ploc", {"NORI_HIP_REINSERT_ITERS": "0"}), ("ploc", {}), ("ploc", {"NORI_HIP_REINSERT_ITERS": "12", "NORI_HIP_REINSERT_STRIDE": "1"})])
+@pytest.mark.parametrize("builder,env", [("lbvh", {}), ("ploc", {"NORI_HIP_REINSERT_ITERS": "0"}), ("ploc", {}), ("ploc", {"NORI_HIP_REINSERT_ITERS": "12", "NORI_HIP_REINSERT_STRIDE": "1"}),
+                                         ("ploc", {"NORI_HIP_SPLIT_BUDGET": "1.0", "NORI_HIP_SPLIT_SCALE": "0", "NORI_HIP_SPLIT_INSIDE": "0"})])
 def test_tree_invariants_of_the_device_builders_trees(builder, env):
     """The same structural check on what the DEVICE builders' steps emit (lbvh_steps.h run as loops, tests/emu/emu_builder.h): radix tree,
     PLOC + sweeps, and after parallel re-insertion -- every winner's move relinks five nodes while others move elsewhere in the same
@@ -583,6 +584,46 @@ def test_treelet_sweeps_improve_the_ploc_tree():
     sah = st["n_node_tests"] / (st["n_closest_rays"] + st["n_shadow_rays"])
     assert nodes[1] < 0.95 * nodes[0] and nodes[2] <= nodes[1] * 1.01, nodes
     assert nodes[2] < 1.02 * sah, (nodes, sah)
+
+
+def test_triangle_splitting_in_front_of_the_device_builder():
+    """References (lbvh_steps.h): a triangle whose box is several times the scene's typical one AND holds other geometry enters the tree
+    as several parts.  On the pa5 table scene that takes a third of the triangle tests per ray without adding node tests; the Cornell box
+    (tilted faces of blocks in an empty room), a patch of terrain and a soup of like-sized triangles are left exactly as they were -- one
+    reference per triangle, the same tree; hits are the brute-force scan's either way, and with the criteria switched off and every
+    triangle cut as often as the cap allows (parts of one triangle in neighbouring leaves, in the same leaf, flat and sliver parts)."""
+    from nori_amd import workloads
+    for name, kw, cut in (("c4-table-mis", {}, True), ("pa4-cbox-path_mis", {}, False), ("c5-terrain-10m", {"triangles": 20000}, False)):
+        sc = workloads.load(name, width=32, height=32, spp=2, **kw).scene
+        rays = scenes.random_rays(3000, seed=35)
+        ref = Oracle(sc).intersect(rays)
+        got = {}
+        for label, env in (("off", {"NORI_HIP_SPLIT_BUDGET": "0"}), ("on", {}), ("forced", {"NORI_HIP_SPLIT_BUDGET": "2.0", "NORI_HIP_SPLIT_SCALE": "0", "NORI_HIP_SPLIT_INSIDE": "0", "NORI_HIP_SPLIT_CAP": "7"})):
+            e = _with_env(dict(env, NORI_EMU_BUILDER="ploc", NORI_HIP_ACCEL_LAYOUT="bvh2"), lambda: Emu(sc))
+            hit = e.intersect(rays)
+            assert all(np.array_equal(ref[k], hit[k], equal_nan=ref[k].dtype.kind == "f") for k in ref.dtype.names), (name, label)
+            info = e.accel_info()
+            _, st = e.render_host(count_traversal=True)
+            nr = st["n_closest_rays"] + st["n_shadow_rays"]
+            got[label] = (info["n_references"], info["n_nodes"], st["n_node_tests"] / nr, st["n_tri_tests"] / nr)
+            e.close()
+        assert got["off"][0] == info["n_triangles"] and got["forced"][0] > 1.5 * info["n_triangles"], (name, got)
+        if cut:
+            assert info["n_triangles"] < got["on"][0] <= 1.3 * info["n_triangles"], (name, got)
+            assert got["on"][3] < 0.72 * got["off"][3] and got["on"][2] < 1.0 * got["off"][2], (name, got)
+        else:
+            assert got["on"] == got["off"], (name, got)
+    for seed in (3, 4):
+        sc = scenes.soup_scene(400, seed)
+        rays = scenes.random_rays(5000, seed=seed + 50)
+        ref = Oracle(sc).intersect(rays)
+        for layout in ("bvh2", "bvh4q"):
+            e = _with_env({"NORI_EMU_BUILDER": "ploc", "NORI_HIP_ACCEL_LAYOUT": layout, "NORI_HIP_SPLIT_BUDGET": "3.0", "NORI_HIP_SPLIT_SCALE": "0", "NORI_HIP_SPLIT_INSIDE": "0"}, lambda: Emu(sc))
+            assert e.accel_info()["n_references"] > 2 * 400
+            hit = e.intersect(rays)
+            assert all(np.array_equal(ref[k], hit[k], equal_nan=ref[k].dtype.kind == "f") for k in ref.dtype.names), (seed, layout)
+            assert np.array_equal(Oracle(sc).intersect(rays, True)["mesh"], e.intersect(rays, True)["mesh"])
+            e.close()
 
 
 @pytest.mark.parametrize("stride", [1, 3])

@@ -36,9 +36,10 @@ def probe(name, sc, variants, check_hits=True):
         e.close()
 
 V = [("host SAH", {"NORI_EMU_BUILDER": "sah"}),
-     ("PLOC (no reinsert)", {"NORI_EMU_BUILDER": "ploc", "NORI_HIP_REINSERT_ITERS": "0"})]
-for it, stride, sa in [(16,1,1),(32,2,1),(32,4,1),(64,4,1),(64,8,1),(128,8,1)]:
-    V.append((f"PLOC reins it{it} st{stride} sw{sa}", {"NORI_EMU_BUILDER": "ploc", "NORI_HIP_REINSERT_ITERS": str(it), "NORI_HIP_REINSERT_STRIDE": str(stride), "NORI_HIP_REINSERT_SWEEPS_AFTER": str(sa)}))
+     ]
+V.append(("PLOC no splitting", {"NORI_EMU_BUILDER": "ploc", "NORI_HIP_SPLIT_BUDGET": "0"}))
+for scale, inside in ((4, 4),):
+    V.append((f"PLOC split scale {scale} inside {inside}", {"NORI_EMU_BUILDER": "ploc", "NORI_HIP_SPLIT_SCALE": str(scale), "NORI_HIP_SPLIT_INSIDE": str(inside)}))
 which = sys.argv[1] if len(sys.argv) > 1 else "cbox"
 if which == "cbox": probe("cbox", workloads.load("pa4-cbox-path_mis", width=64, height=64, spp=4).scene, V)
 if which == "table": probe("table", workloads.load("c4-table-mis", width=64, height=64, spp=4).scene, V)
