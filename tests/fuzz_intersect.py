@@ -3,7 +3,8 @@
 
     python tests/fuzz_intersect.py [--seconds 60] [--seed 0]
 
-Scene shapes exercise what the fixed tests do not: odd / even leaf sizes (triangle pairs and their padding),
+Scene shapes exercise what the fixed tests do not: odd / even leaf sizes (triangle pairs and their padding), a few large tilted triangles among
+small ones (what the device builder cuts into parts; in half the rounds its knobs are drawn too: every triangle cut, re-insertion over residue classes),
 duplicated triangles (ties), degenerate triangles, axis-aligned sheets (rays in the plane of a box face),
 coincident centroids (equal Morton codes), huge and tiny coordinate scales, several meshes, rays with
 zero direction components, rays starting on surfaces, finite maxt.  Exits non-zero at the first mismatch
@@ -57,6 +58,9 @@ def make_meshes(rng, kind, n, scale):
             q[:, u] = [a[i, 0], b[i, 0], b[i, 0], a[i, 0]]; q[:, w] = [a[i, 1], a[i, 1], b[i, 1], b[i, 1]]
             tris += [q[[0, 1, 2]], q[[0, 2, 3]]]
         v = np.array(tris).reshape(-1, 3)
+    elif kind == "mixed":                      # a few triangles many times the size of the rest, tilted: what the device builder cuts into parts
+        m = max(1, n // 8)
+        v = np.concatenate([soup(n, 0.03).reshape(-1, 3, 3), soup(m, rng.choice([0.5, 1.0])).reshape(-1, 3, 3)]).reshape(-1, 3)
     elif kind == "stacked":                    # many triangles with the same centroid
         m = n
         ang = rng.uniform(0, 2 * np.pi, (m, 1)); r = rng.uniform(0.05, 0.8, (m, 1))
@@ -112,7 +116,7 @@ def ill_posed(ray, hit_a, hit_b, tris):
 
 def one_round(seed, renderer_cls, n_rays=20000, verbose=False):
     rng = np.random.default_rng(seed)
-    kind = ["soup", "dups", "degenerate", "sheets", "stacked"][seed % 5]
+    kind = ["soup", "dups", "degenerate", "sheets", "stacked", "mixed"][seed % 6]
     n = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 33, 500, 5000]))
     scale = float(rng.choice([1.0, 1.0, 1e-3, 1e3, 37.5]))
     meshes = make_meshes(rng, kind, n, scale)
@@ -122,7 +126,23 @@ def one_round(seed, renderer_cls, n_rays=20000, verbose=False):
     o = Oracle(sc)
     a, sa = o.intersect(rays), o.intersect(rays, True)
     for builder in BUILDERS:
-        r = renderer_cls(0).upload(sc, builder=builder)
+        # the device builder's stages (lbvh.hip) as shipped, or with drawn knobs: every triangle cut as often as a drawn cap allows, re-insertion
+        # rounds over all slots / a residue class / none
+        env = {}
+        if rng.integers(0, 2):
+            env = {"NORI_HIP_SPLIT_BUDGET": str(float(rng.choice([0.5, 1.0, 3.0]))), "NORI_HIP_SPLIT_SCALE": "0", "NORI_HIP_SPLIT_INSIDE": str(int(rng.choice([0, 0, 2]))),
+                   "NORI_HIP_SPLIT_CAP": str(int(rng.choice([1, 3, 15, 63]))), "NORI_HIP_REINSERT_ITERS": str(int(rng.choice([0, 3, 16]))),
+                   "NORI_HIP_REINSERT_STRIDE": str(int(rng.choice([1, 2, 5])))}
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            r = renderer_cls(0).upload(sc, builder=builder)
+        finally:
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         b, sb = r.intersect(rays), r.intersect(rays, True)
         r.close()
         for f in FIELDS:
@@ -133,7 +153,7 @@ def one_round(seed, renderer_cls, n_rays=20000, verbose=False):
                 bad = [r for r in bad if not ill_posed(rays[r], a[r], b[r], tris)]
                 TOLERATED[0] += n_bad - len(bad) if f == "tri" else 0
                 if bad:
-                    raise AssertionError(f"seed {seed} kind {kind} n {n} scale {scale} builder {builder}: field {f} differs on "
+                    raise AssertionError(f"seed {seed} kind {kind} n {n} scale {scale} builder {builder} {env}: field {f} differs on "
                                          f"{len(bad)} rays, first {bad[0]}: oracle {a[bad[0]]} device {b[bad[0]]}")
         if not np.array_equal(sa["mesh"] != 0xFFFFFFFF, sb["mesh"] != 0xFFFFFFFF):
             raise AssertionError(f"seed {seed} kind {kind} n {n} builder {builder}: shadow-ray answers differ")

@@ -383,6 +383,55 @@ def test_gpu_lbvh_builder_same_hits_as_brute_force(renderer_factory, n_tris, see
     assert np.array_equal(o.intersect(rays, True)["mesh"], r.intersect(rays, True)["mesh"])
 
 
+def test_gpu_triangle_splitting_and_reinsertion_in_the_device_builder(renderer_factory):
+    """lbvh.hip, round 6: references (a triangle whose box is several times the scene's typical one and holds other geometry enters the tree
+    as several parts) and parallel re-insertion.  The pa5 table scene: the device tree's hits are the host tree's, record for record, at
+    no more node tests and fewer triangle tests than the host's SAH + SBVH tree needs by more than 5 %; the Cornell box is not cut.  The
+    kernels are one thread per element over the steps the CPU harness runs as loops (tests/emu/emu_builder.h) and every decision is made
+    in integer sums or in IEEE operations both compilers round alike: the device's tree has the harness's reference, node and level
+    counts (computed on the CPU, pinned here).  And every triangle of a soup cut as often as the cap allows: the scan's answers."""
+    import os
+    from nori_amd.scene import Scene
+    table = Scene.load_npz(os.path.join(os.path.dirname(__file__), "golden", "pa5-table_mis.npz"))
+    table.camera.width, table.camera.height, table.sample_count = 160, 120, 2
+    cbox = Scene.load_npz(os.path.join(os.path.dirname(__file__), "golden", "pa4-cbox-path_mis.npz"))
+    cbox.camera.width, cbox.camera.height, cbox.sample_count = 96, 96, 2
+    for sc, pinned in ((table, (22766, 26100, 11436, 33)), (cbox, (7948, 7948, 3778, 23))):
+        host, dev = renderer_factory(sc, builder=0), renderer_factory(sc, builder=3)
+        ih, idv = host.accel_info(), dev.accel_info()
+        assert ih["built_on_device"] == 0 and idv["built_on_device"] == 1
+        assert (idv["n_triangles"], idv["n_references"], idv["n_nodes"], idv["max_depth"]) == pinned, idv
+        v = np.concatenate([m.positions for m in sc.meshes])
+        centre, half = 0.5 * (v.min(0) + v.max(0)), 0.5 * float(np.linalg.norm(v.max(0) - v.min(0)))
+        rays = scenes.random_rays(200000, seed=77, extent=1.5, target_extent=0.5)      # a shell around the scene, aimed into it
+        rays["o"] = (rays["o"] * half + centre).astype(np.float32)
+        rays["mint"] = 1e-4 * half
+        a, b = host.intersect(rays), dev.intersect(rays)
+        for k in ITS_FIELDS:
+            assert np.array_equal(a[k], b[k]), k
+        fa, sa = host.render_host(count_traversal=True)
+        fb, sb = dev.render_host(count_traversal=True)
+        assert sa["n_closest_rays"] == sb["n_closest_rays"] and sa["n_shadow_rays"] == sb["n_shadow_rays"]
+        np.testing.assert_allclose(fb, fa, rtol=1e-4, atol=1e-5)
+        assert sb["n_node_tests"] <= 1.05 * sa["n_node_tests"] and sb["n_tri_tests"] <= 1.05 * sa["n_tri_tests"], (sa, sb)
+    sc = scenes.soup_scene(20000, 7)
+    rays = scenes.random_rays(50000, seed=27)
+    env = {"NORI_HIP_SPLIT_BUDGET": "3.0", "NORI_HIP_SPLIT_SCALE": "0", "NORI_HIP_SPLIT_INSIDE": "0"}
+    os.environ.update(env)
+    try:
+        r = renderer_factory(sc, builder=3)
+    finally:
+        for k in env:
+            del os.environ[k]
+    info = r.accel_info()
+    assert (info["n_references"], info["n_nodes"], info["max_depth"]) == (79924, 42706, 28), info
+    o = Oracle(sc)
+    a, b = o.intersect(rays), r.intersect(rays)
+    for k in ITS_FIELDS:
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(o.intersect(rays, True)["mesh"], r.intersect(rays, True)["mesh"])
+
+
 def test_treelet_wave_builds_the_tree_of_the_serial_form():
     """Treelet restructuring on the device: a WAVE per treelet (lbvh.hip, treelet_optimize_wave: subset areas two per lane, the dynamic
     programme's (subset, partition) pairs spread over the lanes, winners by a 64-bit LDS minimum that keeps the serial loop's tie rule)
