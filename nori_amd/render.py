@@ -72,6 +72,9 @@ class Renderer:
 
     # ------------------------------------------------------------ load time
     def upload(self, scene: Scene, build: bool = True, builder: int = 0):
+        """builder: nori_accel_builder.  The default here is 0, the host's SAH builder, whose trees the suite's fixed expectations (depths,
+        costs, which traversal-stack variant runs) were written for; the library's own default -- NORI_ACCEL_AUTO = 2, what the C++ host,
+        bench.py, smoke() and the tools pass -- is the device's builder (lbvh.hip)."""
         desc, keep = scene.c_desc()
         self._check(self._lib.nori_hip_upload_scene(self._h, C.byref(desc)), "upload_scene")
         del keep

@@ -34,7 +34,7 @@ result = {"what": "PROJECTION from one GPU -- not a measured scaling curve (no m
 for name, spp in (("pa4-cbox-path_mis", None), ("c4-table-mis", 128), ("c5-terrain-10m", 128)):
     wl = workloads.load(name, spp=spp)
     sc = wl.scene
-    r = Renderer(0).upload(sc)
+    r = Renderer(0).upload(sc, builder=2)
     frame = torch.zeros(r.frame_shape(), device="cuda")
     n_spp = sc.sample_count
     rows = []

@@ -4,7 +4,7 @@ import torch
 from nori_amd.render import Renderer
 from nori_amd import workloads
 sc = workloads.load(os.environ.get("WORKLOAD", "pa4-cbox-path_mis"), spp=int(os.environ["SPP"]) if "SPP" in os.environ else None).scene
-r = Renderer(0).upload(sc, builder=int(os.environ.get("BUILDER", 0)))
+r = Renderer(0).upload(sc, builder=int(os.environ.get("BUILDER", 2)))
 print(r.accel_info())
 r.set_option("engine", os.environ.get("ENGINE", "wavefront"))
 if "PATHS" in os.environ: r.set_option("wavefront_paths", int(os.environ["PATHS"]))          # the pool: paths in flight
