@@ -1,43 +1,43 @@
 /*
- * lbvh.hip -- Accel::build on the GPU: a linear BVH (Morton order + radix
- * tree) emitted directly in the traversal layout of rt_types.h.
+ * lbvh.hip -- Accel::build on the GPU, emitted directly in the traversal layout of rt_types.h.  Since round 6 this is what
+ * NORI_ACCEL_AUTO builds: every benchmark line is rendered through a tree these kernels made.
  *
- * The reference's Accel::build is a no-op (src/accel.cpp:19-21) and its
- * rayIntersect scans every triangle; a BVH is this project's replacement, and
- * for the 10-M-triangle configuration (BASELINE config 5) a host build would
- * dominate wall-clock, so the whole build runs in HIP kernels:
+ * The reference's Accel::build is a no-op (src/accel.cpp:19-21) and its rayIntersect scans every triangle; a BVH is this
+ * project's replacement.  The kernels are one thread (or wave) per element over the steps of lbvh_steps.h, which the CPU test
+ * harness runs as loops (tests/emu/emu_builder.h) -- same steps, same arithmetic, the same tree:
  *
- *   1. k_scene_bounds   per-triangle boxes (src/mesh.cpp:78-83) -> scene box
- *                       (float atomics on order-preserving integer keys)
- *   2. k_morton         63-bit Morton code of the box centre (src/mesh.cpp:85-90
- *                       uses the vertex centroid; any centre orders as well)
- *   3. hipcub radix sort of (code, triangle) pairs
- *   4. k_hierarchy      Karras 2012: one thread per internal node finds its key
- *                       range and split with clz(key_i ^ key_j); equal codes are
- *                       told apart by their sorted position
- *   5. k_leaf_boxes / k_tree_level   padded triangle boxes in sorted order and
- *                       a min/max segment tree over them (one launch per level):
- *                       every node covers a CONTIGUOUS sorted range, so its box
- *                       is a range query -- no bottom-up atomics, no
- *                       inter-workgroup visibility hazards
- *   6. k_collapse       which subtrees of <= 4 triangles become one leaf (surface-area heuristic)
- *   7. k_mark_leaves / scans / k_emit_pairs / k_emit_nodes   the surviving radix nodes renumbered
- *                       densely as 64-B two-child-box records; the leaves' triangles as 96-B
- *                       de-indexed pair records, leaf by leaf
- *   8. k_depth          longest root-to-leaf chain (sizes the LDS stack)
+ *   1. k_scene_bounds   per-triangle boxes (src/mesh.cpp:78-83) -> scene box (float atomics on order-preserving integer keys)
+ *   2. references       k_split_priority / _grid / _limit / _total / _emit: the tree is built over (triangle, box) references; a
+ *                       triangle whose box is several times the scene's typical one, has volume and holds other geometry enters as
+ *                       several clipped parts (the host builder's spatial splits, decided up front).  Every reference gets the
+ *                       63-bit Morton code of its box centre (src/mesh.cpp:85-90 uses the vertex centroid; any centre orders as well)
+ *   3. hipcub radix sort of (code, reference) pairs; k_refs_gather: triangle and padded box by position
+ *   4. k_hierarchy      radix tree (Karras 2012: one thread per internal node finds its key range and split with clz(key_i ^ key_j);
+ *                       equal codes are told apart by their sorted position), or
+ *   4'. k_ploc_*        PLOC (Meister & Bittner 2018): clusters in Morton order merge with their nearest neighbour by area, then
+ *       k_treelet_wave  treelet restructuring (Karras & Aila 2013), a wave per treelet, and
+ *       k_reins_*       parallel re-insertion (Meister & Bittner 2018): every subtree searches the same tree for the place where the
+ *                       inner nodes' areas shrink most, marks the nodes its move touches by a 64-bit maximum, winners relink, refit;
+ *                       k_ploc_leaf_positions / k_ploc_finish: the tree's leaves left to right = the order everything below uses
+ *   5. k_leaf_boxes / k_tree_level   the references' boxes in that order and a min/max segment tree over them (one launch per
+ *                       level): every node covers a CONTIGUOUS range, so its box is a range query -- no bottom-up atomics
+ *   6. k_collapse       which subtrees of <= 4 references become one leaf (surface-area heuristic)
+ *   7. k_mark_leaves / scans / k_emit_pairs / k_emit_nodes   the surviving nodes renumbered densely as 64-B two-child-box
+ *                       records; the leaves' triangles as 96-B de-indexed pair records, leaf by leaf
+ *   8. k_depth          levels of emitted nodes above the deepest leaf (sizes the traversal stack)
  *   wide = true (scenes beyond the caches): instead of 7's two-box records the tree is emitted as WIDE nodes (BVH4,
- *       quantised child boxes; rt_types.h).  k_wide_expand walks the kept radix nodes top-down, one launch per level
- *       of the wide tree: a wide node takes its radix node's two children and twice replaces the inner child of largest
+ *       quantised child boxes; rt_types.h).  k_wide_expand walks the kept nodes top-down, one launch per level
+ *       of the wide tree: a wide node takes its node's two children and twice replaces the inner child of largest
  *       surface area by that child's children; the inner children that remain are the wide nodes of the next level.
- *       k_emit_wide quantises the (<= 4) child boxes against their union (rt_wide.h) -- the radix nodes in between vanish.
+ *       k_emit_wide quantises the (<= 4) child boxes against their union (rt_wide.h) -- the nodes in between vanish.
  *
  * Numerically collinear triangles (rt_types.h, tri_box_pad) get Morton bit 63: the root separates them
- * from the spatial hierarchy, their boxes are infinite.
+ * from the spatial hierarchy, their boxes are infinite; they are never cut and never moved.
  *
- * Any valid BVH returns the same hits as the linear scan (conservative node
- * test + tie rule in rt_trace.h); tests/test_gpu_parity.py checks this builder
- * against the oracle's brute force as well.  The SAH builder (scene_prep.cpp)
- * gives trees that traverse faster and stays the default for small scenes.
+ * Any valid BVH returns the same hits as the linear scan (conservative node test + tie rule in rt_trace.h);
+ * tests/test_gpu_parity.py checks these trees against the oracle's brute force and against the host builder's (scene_prep.cpp:
+ * binned SAH + spatial splits + re-insertion on CPU threads -- the fall-back, and the yardstick: wf_extend with the device tree
+ * runs within 1 % of it on the Cornell box, the pa5 table and the AO scene, within 3 % on the 10 M-triangle terrain).
  */
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
