@@ -312,26 +312,31 @@ def test_obj_loader_errors(tmp_path, face, msg):
 
 
 def test_committed_bench_line_follows_the_contract():
-    """The latest committed bench line (profiles/*_default_bench.json, written by `python bench.py` on the
-    GPU box) carries every field the driver and the judge read, with consistent values."""
+    """The latest committed default bench line (profiles/r*_bench_default.json, written by `python bench.py` on the GPU box in the round's
+    profile set) carries every field the driver and the judge read, with consistent values; since round 6 its tree is device-built."""
     import glob
     import json
-    path = sorted(glob.glob(os.path.join(os.path.dirname(os.path.dirname(__file__)), "profiles", "*_default_bench.json")))[-1]
+    import re
+    root = os.path.dirname(os.path.dirname(__file__))
+    files = [f for f in glob.glob(os.path.join(root, "profiles", "r*_bench_default.json")) if re.match(r"r\d+_\d+_bench_default\.json$", os.path.basename(f))]
+    path = sorted(files, key=lambda f: tuple(int(x) for x in re.match(r"r(\d+)_(\d+)_", os.path.basename(f)).groups()))[-1]
     d = json.load(open(path))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity", "accel"):
         assert k in d, k
-    assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32"
+    assert d["unit"] == "Mrays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None and d["dtype"] == "f32" and d["n_gpus"] == 1
     assert d["config"]["workload"] == "pa4-cbox-path_mis" and (d["config"]["width"], d["config"]["height"], d["config"]["spp"]) == (1024, 1024, 256)
     assert abs(d["value"] - d["config"]["rays_per_step"] / d["ms_per_step"] / 1e3) < 1e-3 * d["value"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "algorithmic_bytes"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms", "bound_evidence", "hbm_measured_frac"):
         assert k in r, k
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
-    assert abs(r["achieved"] - r["algorithmic_bytes"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
-    assert r["kernel_ms"] < d["ms_per_step"] and (r["traffic"] is None or r["traffic"] > 0)
+    assert r["bound"] in ("valu", "hbm") and r["unit"] in ("Tops/s", "GB/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["kernel_ms"] < d["ms_per_step"] and r["traffic"] is not None and r["traffic"] > 0      # the counters of the line's own build were on file
+    assert r["bound_evidence"]["source"].startswith("profiles/") and os.path.exists(os.path.join(root, r["bound_evidence"]["source"]))
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["unit"] == "Mrays/s" and c["cores"] >= 1 and c["value"] > 0
+    assert d["parity"]["ok"] is True and d["parity"]["rays_cpu"] == d["parity"]["rays_gpu"]
+    assert d["accel"]["builder"] == "ploc" and d["accel"]["built_on_device"] == 1 and d["accel"]["n_references"] >= d["accel"]["n_triangles"]
