@@ -13,9 +13,23 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long-running CPU test")
 
 
-@pytest.fixture(scope="session")
+def pytest_collection_modifyitems(config, items):
+    """A limit per GPU test (pytest-timeout, where installed: it is on the GPU box).  The suite takes ~95 s and its longest test ~20 s;
+    once in ten runs of round 6 a box did not return from a test within 40 minutes (profiles/r6_33_suite_repeated.txt: not reproduced in
+    five repeats, nor in fourteen of the test it stopped in) -- with a limit such a run ends in minutes with the stacks of all threads on
+    stderr instead of at the caller's own limit with nothing."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") is not None and item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600, method="thread"))
+
+
+@pytest.fixture(scope="module")
 def renderer_factory():
-    """Factory of HIP renderers; fails loudly (no fallback) when the library or GPU is missing."""
+    """Factory of HIP renderers; fails loudly (no fallback) when the library or GPU is missing.  Module scope: the contexts a test file
+    made -- among them those of the full-size BASELINE configurations, with pools of tens of GB -- are destroyed when the file is done
+    instead of staying alive under everything that follows."""
     from nori_amd.render import Renderer
 
     made = []
