@@ -104,6 +104,7 @@ def emu_lib():
             "emu_border_size": (C.c_int, [_P]),
             "emu_intersect": (C.c_int, [_P, _P, _P, C.c_size_t, C.c_int]),
             "emu_nodeq_check": (C.c_longlong, [_P, _P, C.c_size_t, _P]),
+            "emu_split_parts": (C.c_int, [_P, C.c_uint32, C.c_float, _P, _P, _P, _P, C.c_int]),
             "emu_node_records": (C.c_longlong, [_P, _P, _P, _P, C.c_size_t]),
             "emu_packed_vs_scalar": (C.c_size_t, [C.c_size_t, C.c_uint64]),
             "emu_libm_eval": (C.c_int, [C.c_int, _P, C.c_size_t, _P]),

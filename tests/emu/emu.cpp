@@ -324,6 +324,28 @@ int emu_accel_info(const emu_ctx *c, nori_accel_info *in) {
 }
 int emu_border_size(const emu_ctx *c) { return c->host.filter.border; }
 
+/* the references split_emit (lbvh_steps.h) makes of ONE triangle cut `cuts` times, in a scene box [smin, smax]: their padded boxes as
+   (mn.xyz, mx.xyz) rows and Morton keys; returns how many (tests/test_device_logic_cpu.py: every point of the triangle lies in one of them) */
+int emu_split_parts(const float *tri9, uint32_t cuts, float pad0, const float *smin3, const float *smax3, float *boxes6, unsigned long long *keys, int cap) {
+    f4 pos[3]; uint32_t idx[3] = {0u, 1u, 2u};
+    for (int k = 0; k < 3; ++k) { pos[k].x = tri9[3 * k]; pos[k].y = tri9[3 * k + 1]; pos[k].z = tri9[3 * k + 2]; pos[k].w = 0.0f; }
+    const f3 smin = mk3(smin3[0], smin3[1], smin3[2]);
+    const f3 ext = mk3(smax3[0] - smin3[0], smax3[1] - smin3[1], smax3[2] - smin3[2]);
+    const f3 sinv = mk3(ext.x > 0 ? 1.0f / ext.x : 0.0f, ext.y > 0 ? 1.0f / ext.y : 0.0f, ext.z > 0 ? 1.0f / ext.z : 0.0f);
+    const RefOut none{nullptr, nullptr, nullptr, nullptr};
+    const uint32_t n = split_emit(pos, idx, 0u, cuts, pad0, smin, sinv, false, none, 0u);
+    if ((int) n > cap) return -1;
+    std::vector<uint32_t> tri(n); std::vector<f4> mn(n), mx(n); std::vector<unsigned long long> key(n);
+    const RefOut out{tri.data(), mn.data(), mx.data(), key.data()};
+    if (split_emit(pos, idx, 0u, cuts, pad0, smin, sinv, true, out, 0u) != n) return -2;
+    for (uint32_t k = 0; k < n; ++k) {
+        boxes6[6 * k] = mn[k].x; boxes6[6 * k + 1] = mn[k].y; boxes6[6 * k + 2] = mn[k].z;
+        boxes6[6 * k + 3] = mx[k].x; boxes6[6 * k + 4] = mx[k].y; boxes6[6 * k + 5] = mx[k].z;
+        keys[k] = key[k];
+    }
+    return (int) n;
+}
+
 /* raw records for an independent look at the 32-B form (tests/test_device_logic_cpu.py): copies up to `cap` nodes as 16 floats
    (64-B form) and 8 dwords (32-B form) each, the grid as (mn[3], scale[3]); returns the number of nodes, -1 without 32-B records */
 long long emu_node_records(emu_ctx *c, float *nodes64, uint32_t *nodes32, float *grid, size_t cap) {

@@ -586,6 +586,44 @@ def test_treelet_sweeps_improve_the_ploc_tree():
     assert nodes[2] < 1.02 * sah, (nodes, sah)
 
 
+def test_split_parts_cover_the_triangle():
+    """split_emit (lbvh_steps.h) on single triangles: whatever the shape -- slivers, axis-parallel, tiny in a huge scene box, far from the origin --
+    and however many cuts, every point of the triangle lies in the box of at least one part (the parts are the triangle clipped to cells
+    that tile its box; boxes evaluated in binary64, rounded outwards, padded as the whole triangle is -- a sliver's parts keep the sliver's
+    wide pad) and no part reaches beyond the triangle's own padded box."""
+    from tests.backends import emu_lib, ptr
+    lib = emu_lib()
+    rng = np.random.default_rng(5)
+    w = rng.uniform(0, 1, (4000, 3)); w /= w.sum(1, keepdims=True)
+    w[:3] = np.eye(3); w[3:6] = [[0.5, 0.5, 0], [0, 0.5, 0.5], [0.5, 0, 0.5]]      # the corners and edge midpoints too
+    n_cut = 0
+    for trial in range(400):
+        scale = float(rng.choice([1e-3, 1.0, 1.0, 50.0, 1e4]))
+        centre = rng.uniform(-1, 1, 3) * scale * float(rng.choice([0.0, 1.0, 100.0]))
+        tri = centre + rng.uniform(-1, 1, (3, 3)) * scale * rng.choice([1.0, 1.0, 1e-3], 3)      # thin along some axes
+        if trial % 7 == 0:
+            tri[:, rng.integers(0, 3)] = centre[0]                                              # axis-parallel: a flat box
+        tri = tri.astype(np.float32)
+        lo, hi = tri.min(0), tri.max(0)
+        grow = float(rng.choice([0.0, 3.0, 1000.0])) * (hi - lo).max()
+        smin, smax = (lo - grow * rng.uniform(0, 1, 3)).astype(np.float32), (hi + grow * rng.uniform(0, 1, 3)).astype(np.float32)
+        pad = np.float32(2e-6 * np.linalg.norm(smax - smin) + 1e-30)
+        cuts = int(rng.choice([1, 2, 3, 7, 15, 63]))
+        boxes = np.zeros((64, 6), np.float32); keys = np.zeros(64, np.uint64)
+        n = lib.emu_split_parts(ptr(np.ascontiguousarray(tri)), cuts, pad, ptr(smin), ptr(smax), ptr(boxes), ptr(keys), 64)
+        assert 1 <= n <= cuts + 1, (trial, n, cuts)
+        b = boxes[:n].astype(np.float64)
+        pts = w @ tri.astype(np.float64)
+        eps = 1e-12 * (1.0 + np.abs(pts))[:, None, :]      # (the points are binary64 combinations of the vertices: their own rounding, 1e-16 relative)
+        inside = ((pts[:, None, :] >= b[None, :, :3] - eps) & (pts[:, None, :] <= b[None, :, 3:] + eps)).all(2).any(1)
+        assert inside.all(), (trial, cuts, n, tri, pts[~inside][:3])
+        whole = np.zeros((1, 6), np.float32); k1 = np.zeros(1, np.uint64)
+        assert lib.emu_split_parts(ptr(np.ascontiguousarray(tri)), 0, pad, ptr(smin), ptr(smax), ptr(whole), ptr(k1), 1) == 1
+        assert (b[:, :3] >= whole[0, :3].astype(np.float64) - 1e-6 * scale).all() and (b[:, 3:] <= whole[0, 3:].astype(np.float64) + 1e-6 * scale).all(), trial
+        n_cut += 1 if n > 1 else 0
+    assert n_cut > 200
+
+
 def test_triangle_splitting_in_front_of_the_device_builder():
     """References (lbvh_steps.h): a triangle whose box is several times the scene's typical one AND holds other geometry enters the tree
     as several parts.  On the pa5 table scene that takes a third of the triangle tests per ray without adding node tests; the Cornell box
